@@ -1,0 +1,305 @@
+"""ectrans_amd -- Python host mirror of the ecTrans API over libectrans_mi.so (C-ABI, HIP).
+
+The names and argument meaning follow the reference Fortran interface
+(/root/reference/src/trans/include/ectrans/{setup_trans0,setup_trans,inv_trans,dir_trans,
+trans_inq,specnorm}.h): ``setup_trans0``, ``setup_trans`` (returns KRESOL), ``inv_trans``,
+``dir_trans``, ``trans_inq``, ``specnorm``, ``trans_release``, ``trans_end``.  Errors that the
+reference reports through ABORT_TRANS are raised as :class:`TransError` with the same text.
+
+Arrays are passed with the *Fortran* index order reversed (C-contiguous):
+``PSPEC(nfld, nspec2)`` is a ``(nspec2, nfld)`` array, ``PGP(nproma, nfld, ngpblks)`` is
+``(ngpblks, nfld, nproma)``, ``PSPSC3A(nlev, nspec2, nvar)`` is ``(nvar, nspec2, nlev)``,
+``PGPUV(nproma, nlev, nvar, ngpblks)`` is ``(ngpblks, nvar, nlev, nproma)``.
+numpy arrays are staged through PCIe (EMI_MEM_HOST); torch CUDA tensors are used in place
+(EMI_MEM_DEVICE).  There is no CPU implementation in this package: without the HIP library
+and a GPU every call fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["TransError", "setup_trans0", "setup_trans", "inv_trans", "dir_trans", "trans_inq", "specnorm",
+           "trans_release", "trans_end", "lib", "build"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libectrans_mi.so")
+_L = None
+
+EMI_MEM_HOST, EMI_MEM_DEVICE = 0, 1
+
+
+class TransError(RuntimeError):
+    """What the reference would have reported through ABORT_TRANS."""
+
+
+class _Init(C.Structure):
+    _fields_ = [("kmax_resol", C.c_int), ("kprintlev", C.c_int), ("prad", C.c_double), ("nproc", C.c_int),
+                ("myproc", C.c_int), ("device", C.c_int)]
+
+
+class _Setup(C.Structure):
+    _fields_ = [("ksmax", C.c_int), ("kdgl", C.c_int), ("kloen", C.POINTER(C.c_int)), ("kdlon", C.c_int),
+                ("precision", C.c_int), ("lduseflt", C.c_int), ("ldll", C.c_int), ("ldstretch", C.c_int)]
+
+
+class _Inv(C.Structure):
+    _fields_ = [("mem_space", C.c_int), ("spvor", C.c_void_p), ("spdiv", C.c_void_p), ("nf_uv", C.c_int),
+                ("spscalar", C.c_void_p), ("nf_scalar", C.c_int), ("spsc3a", C.c_void_p), ("sc3a_nlev", C.c_int),
+                ("sc3a_nvar", C.c_int), ("spsc3b", C.c_void_p), ("sc3b_nlev", C.c_int), ("sc3b_nvar", C.c_int),
+                ("spsc2", C.c_void_p), ("nf_sc2", C.c_int), ("ldscders", C.c_int), ("ldvorgp", C.c_int),
+                ("lddivgp", C.c_int), ("lduvder", C.c_int), ("kproma", C.c_int), ("gp", C.c_void_p),
+                ("gp_nfld", C.c_int), ("gpuv", C.c_void_p), ("gp3a", C.c_void_p), ("gp3b", C.c_void_p),
+                ("gp2", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class _Dir(C.Structure):
+    _fields_ = [("mem_space", C.c_int), ("spvor", C.c_void_p), ("spdiv", C.c_void_p), ("nf_uv", C.c_int),
+                ("spscalar", C.c_void_p), ("nf_scalar", C.c_int), ("spsc3a", C.c_void_p), ("sc3a_nlev", C.c_int),
+                ("sc3a_nvar", C.c_int), ("spsc3b", C.c_void_p), ("sc3b_nlev", C.c_int), ("sc3b_nvar", C.c_int),
+                ("spsc2", C.c_void_p), ("nf_sc2", C.c_int), ("kproma", C.c_int), ("gp", C.c_void_p),
+                ("gp_nfld", C.c_int), ("gpuv", C.c_void_p), ("gp3a", C.c_void_p), ("gp3b", C.c_void_p),
+                ("gp2", C.c_void_p), ("stream", C.c_void_p)]
+
+
+def build(force=False):
+    """Compile libectrans_mi.so for gfx950 with hipcc (in-tree)."""
+    import subprocess
+    src = os.path.join(_HERE, "csrc", "ectrans_mi.hip")
+    deps = [src] + [os.path.join(_HERE, "csrc", f) for f in ("emi_kernels.h", "emi_rt.h", "emi_setup.h")]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "ectrans_mi.h"))
+    if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(d) for d in deps):
+        return _LIBPATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", _LIBPATH, src]
+    subprocess.check_call(cmd)
+    return _LIBPATH
+
+
+def _bind(L):
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.emi_init.argtypes = [C.POINTER(_Init)]
+    L.emi_setup.argtypes = [C.POINTER(_Setup), ip]
+    L.emi_inq_int.argtypes = [C.c_int, C.c_char_p, ip]
+    L.emi_inq_int_array.argtypes = [C.c_int, C.c_char_p, ip, C.c_int]
+    L.emi_inq_real_array.argtypes = [C.c_int, C.c_char_p, dp, C.c_int]
+    L.emi_inq_legendre.argtypes = [C.c_int, C.c_int, C.c_int, dp, ip, ip]
+    L.emi_inv_trans.argtypes = [C.c_int, C.POINTER(_Inv)]
+    L.emi_dir_trans.argtypes = [C.c_int, C.POINTER(_Dir)]
+    L.emi_specnorm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, dp]
+    L.emi_release.argtypes = [C.c_int]
+    L.emi_finalize.argtypes = []
+    L.emi_last_error.restype = C.c_char_p
+    L.emi_work_model.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+    L.emi_last_phase_ms.argtypes = [dp]
+    L.emi_set_max_batch.argtypes = [C.c_int]
+    return L
+
+
+def lib():
+    """The HIP shared library.  No fallback: a missing library is an error."""
+    global _L
+    if _L is None:
+        if not os.path.exists(_LIBPATH):
+            raise TransError("libectrans_mi.so is not built (run __graft_entry__.build()); "
+                             "ectrans_amd has no CPU implementation")
+        _L = _bind(C.CDLL(_LIBPATH))
+    return _L
+
+
+def _use_library_for_tests(path):
+    """tests/emu only: point the wrapper at the CPU functional emulator build."""
+    global _L
+    _L = _bind(C.CDLL(path))
+    return _L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise TransError(lib().emi_last_error().decode())
+
+
+def _is_torch(a):
+    return a is not None and type(a).__module__.startswith("torch")
+
+
+def _ptr(a, space):
+    """(pointer, keep-alive object) of an array living in `space`."""
+    if a is None:
+        return None, None
+    if _is_torch(a):
+        if not a.is_contiguous() or str(a.dtype) != "torch.float64":
+            raise TransError("device arrays must be contiguous float64 tensors")
+        if space[0] is None:
+            space[0] = EMI_MEM_DEVICE if a.is_cuda else EMI_MEM_HOST
+        elif space[0] != (EMI_MEM_DEVICE if a.is_cuda else EMI_MEM_HOST):
+            raise TransError("all arrays of one call must live in the same memory space")
+        return a.data_ptr(), a
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+        raise TransError("host arrays must be C-contiguous float64 numpy arrays")
+    if space[0] is None:
+        space[0] = EMI_MEM_HOST
+    elif space[0] != EMI_MEM_HOST:
+        raise TransError("all arrays of one call must live in the same memory space")
+    return a.ctypes.data, a
+
+
+def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, **unsupported):
+    """SETUP_TRANS0 (setup_trans0.h:12-89).  LDMPOFF-style single-task setup."""
+    for k, v in unsupported.items():
+        if k.lower() in ("kprgpns", "kprgpew", "kprtrw") and v not in (None, 1):
+            raise TransError("SETUP_TRANS0: %s=%r -- multi-task runs go through ectrans_amd.dist" % (k, v))
+    cfg = _Init(kmax_resol, kprintlev, prad if prad else 0.0, 1, 1, device)
+    _chk(lib().emi_init(C.byref(cfg)))
+
+
+def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, pstret=None):
+    """SETUP_TRANS (setup_trans.h:12-115); returns KRESOL."""
+    cfg = _Setup()
+    cfg.ksmax, cfg.kdgl, cfg.kdlon, cfg.precision = int(ksmax), int(kdgl), int(kdlon), 8
+    keep = None
+    if kloen is not None:
+        keep = np.ascontiguousarray(kloen, dtype=np.int32)
+        if keep.size < kdgl:
+            raise TransError("SETUP_TRANS: KLOEN TOO SHORT")
+        cfg.kloen = keep.ctypes.data_as(C.POINTER(C.c_int))
+    cfg.lduseflt, cfg.ldll = int(bool(lduseflt)), int(bool(ldll))
+    cfg.ldstretch = int(pstret is not None and abs(pstret - 1.0) > 100 * np.finfo(float).eps)
+    kresol = C.c_int(0)
+    _chk(lib().emi_setup(C.byref(cfg), C.byref(kresol)))
+    return kresol.value
+
+
+_INT_SCALARS = ("nspec2", "nspec2g", "nspec", "ngptot", "ngptotg", "nump", "ndgl", "nsmax", "ndlon")
+_INT_ARRAYS = {"nloen": "ndgl", "nmen": "ndgl", "ndglu": "nsmax+1", "nasm0": "nsmax+1", "myms": "nsmax+1"}
+_REAL_ARRAYS = {"rmu": "ndgl", "pmu": "ndgl", "rgw": "ndgl", "pgw": "ndgl", "racthe": "ndgl"}
+
+
+def trans_inq(kresol, name):
+    """TRANS_INQ (trans_inq.h): one quantity by (lower-case) name."""
+    L = lib()
+    name = name.lower()
+    if name in _INT_SCALARS:
+        v = C.c_int(0)
+        _chk(L.emi_inq_int(kresol, name.encode(), C.byref(v)))
+        return v.value
+    dims = {"ndgl": trans_inq(kresol, "ndgl"), "nsmax+1": trans_inq(kresol, "nsmax") + 1}
+    if name in _INT_ARRAYS:
+        out = np.zeros(dims[_INT_ARRAYS[name]], dtype=np.int32)
+        _chk(L.emi_inq_int_array(kresol, name.encode(), out.ctypes.data_as(C.POINTER(C.c_int)), out.size))
+        return out
+    if name in _REAL_ARRAYS:
+        out = np.zeros(dims[_REAL_ARRAYS[name]])
+        _chk(L.emi_inq_real_array(kresol, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
+        return out
+    raise TransError("TRANS_INQ: unknown quantity %r" % name)
+
+
+def legendre_panel(kresol, m, symmetric):
+    """S%FA(m)%RPNMS / RPNMA as the reference lays them out; numpy [col(n desc)][lat]."""
+    L = lib()
+    r, c = C.c_int(), C.c_int()
+    _chk(L.emi_inq_legendre(kresol, m, int(symmetric), None, C.byref(r), C.byref(c)))
+    out = np.zeros((c.value, r.value))
+    if out.size:
+        _chk(L.emi_inq_legendre(kresol, m, int(symmetric), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(r),
+                                C.byref(c)))
+    return out
+
+
+def _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2):
+    def chk2(x, nm):
+        if x is not None and (x.ndim != 2 or x.shape[0] != nspec2):
+            raise TransError("%s must have shape (nspec2=%d, nfld)" % (nm, nspec2))
+
+    chk2(pspvor, "PSPVOR"), chk2(pspdiv, "PSPDIV"), chk2(pspscalar, "PSPSCALAR"), chk2(pspsc2, "PSPSC2")
+    for x, nm in ((pspsc3a, "PSPSC3A"), (pspsc3b, "PSPSC3B")):
+        if x is not None and (x.ndim != 3 or x.shape[1] != nspec2):
+            raise TransError("%s must have shape (nvar, nspec2=%d, nlev)" % (nm, nspec2))
+    if (pspvor is None) != (pspdiv is None):
+        raise TransError("PSPVOR and PSPDIV must be given together")
+    if pspvor is not None and pspvor.shape != pspdiv.shape:
+        raise TransError("PSPVOR and PSPDIV shapes differ")
+    for nm, x in (("spvor", pspvor), ("spdiv", pspdiv), ("spscalar", pspscalar), ("spsc3a", pspsc3a),
+                  ("spsc3b", pspsc3b), ("spsc2", pspsc2)):
+        p, k = _ptr(x, space)
+        setattr(a, nm, p)
+        keep.append(k)
+    a.nf_uv = 0 if pspvor is None else pspvor.shape[1]
+    a.nf_scalar = 0 if pspscalar is None else pspscalar.shape[1]
+    a.nf_sc2 = 0 if pspsc2 is None else pspsc2.shape[1]
+    a.sc3a_nvar, a.sc3a_nlev = (0, 0) if pspsc3a is None else (pspsc3a.shape[0], pspsc3a.shape[2])
+    a.sc3b_nvar, a.sc3b_nlev = (0, 0) if pspsc3b is None else (pspsc3b.shape[0], pspsc3b.shape[2])
+
+
+def _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks):
+    for nm, x in (("gp", pgp), ("gpuv", pgpuv), ("gp3a", pgp3a), ("gp3b", pgp3b), ("gp2", pgp2)):
+        if x is not None and (x.shape[0] != ngpblks or x.shape[-1] != nproma):
+            raise TransError("P%s: first/last extents must be (ngpblks=%d, ..., nproma=%d), got %s"
+                             % (nm.upper(), ngpblks, nproma, tuple(x.shape)))
+        p, k = _ptr(x, space)
+        setattr(a, nm, p)
+        keep.append(k)
+    a.gp_nfld = 0 if pgp is None else pgp.shape[1]
+
+
+def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
+              ldscders=False, ldvorgp=False, lddivgp=False, lduvder=False, kproma=None, pgp=None, pgpuv=None,
+              pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+    """INV_TRANS (inv_trans.h:12-163): spectral -> grid point, results written into pgp*/..."""
+    a, space, keep = _Inv(), [None], []
+    nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
+    nproma = int(kproma) if kproma else ngptot
+    ngpblks = (ngptot - 1) // nproma + 1
+    _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks)
+    a.ldscders, a.ldvorgp, a.lddivgp, a.lduvder = int(ldscders), int(ldvorgp), int(lddivgp), int(lduvder)
+    a.kproma = nproma
+    a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
+    a.stream = stream
+    _chk(lib().emi_inv_trans(kresol, C.byref(a)))
+
+
+def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
+              kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+    """DIR_TRANS (dir_trans.h:12-140): grid point -> spectral, results written into psp*."""
+    a, space, keep = _Dir(), [None], []
+    nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
+    nproma = int(kproma) if kproma else ngptot
+    ngpblks = (ngptot - 1) // nproma + 1
+    _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks)
+    a.kproma = nproma
+    a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
+    a.stream = stream
+    _chk(lib().emi_dir_trans(kresol, C.byref(a)))
+
+
+def specnorm(kresol, pspec):
+    """SPECNORM (specnorm.h:12): per-field spectral L2 norm, returned as a numpy array."""
+    space = [None]
+    p, keep = _ptr(pspec, space)
+    out = np.zeros(pspec.shape[1])
+    _chk(lib().emi_specnorm(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def trans_release(kresol):
+    _chk(lib().emi_release(kresol))
+
+
+def trans_end():
+    _chk(lib().emi_finalize())
+
+
+def work_model(kresol, nfields):
+    """Algorithmic work per direction for `nfields` Fourier-space fields."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    _chk(lib().emi_work_model(kresol, nfields, C.byref(a), C.byref(b), C.byref(c)))
+    return {"legendre_flops": a.value, "fft_flops": b.value, "fourier_bytes": c.value}
+
+
+def last_phase_ms():
+    out = (C.c_double * 3)()
+    lib().emi_last_phase_ms(out)
+    return list(out)

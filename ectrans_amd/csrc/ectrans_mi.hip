@@ -1,0 +1,1183 @@
+// ectrans_mi.hip -- host orchestration + C-ABI (include/ectrans_mi.h) of libectrans_mi.so.
+// Built with hipcc --offload-arch=gfx950 (product) or g++ -x c++ -DEMI_CPU_EMU (test emulator).
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ectrans_mi.h"
+#include "emi_kernels.h"
+#include "emi_setup.h"
+
+#ifdef EMI_CPU_EMU
+thread_local EmuCtx *emu_ctx = nullptr;
+#endif
+
+// ------------------------------------------------------------------------------------------
+// errors + runtime helpers
+// ------------------------------------------------------------------------------------------
+static char g_err[1024] = "";
+void emi_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *emi_last_error(void) { return g_err; }
+
+#define EMI_FAIL(code, ...)     \
+  do {                          \
+    emi_set_error(__VA_ARGS__); \
+    return (code);              \
+  } while (0)
+
+#ifndef EMI_CPU_EMU
+int emi_dev_malloc(void **p, size_t bytes) {
+  EMI_CHECK(hipMalloc(p, bytes ? bytes : 16));
+  return 0;
+}
+int emi_dev_free(void *p) {
+  if (p) EMI_CHECK(hipFree(p));
+  return 0;
+}
+int emi_dev_memset(void *p, int v, size_t bytes, emi_stream_t s) {
+  EMI_CHECK(hipMemsetAsync(p, v, bytes, s));
+  return 0;
+}
+int emi_h2d(void *d, const void *s, size_t b, emi_stream_t st) {
+  EMI_CHECK(hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, st));
+  return 0;
+}
+int emi_d2h(void *d, const void *s, size_t b, emi_stream_t st) {
+  EMI_CHECK(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, st));
+  return 0;
+}
+int emi_d2d(void *d, const void *s, size_t b, emi_stream_t st) {
+  EMI_CHECK(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+int emi_stream_sync(emi_stream_t s) {
+  EMI_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+int emi_mem_info(size_t *f, size_t *t) {
+  EMI_CHECK(hipMemGetInfo(f, t));
+  return 0;
+}
+#else
+int emi_dev_malloc(void **p, size_t bytes) {
+  *p = aligned_alloc(64, ((bytes ? bytes : 16) + 63) / 64 * 64);
+  return *p ? 0 : -1;
+}
+int emi_dev_free(void *p) {
+  free(p);
+  return 0;
+}
+int emi_dev_memset(void *p, int v, size_t bytes, emi_stream_t) {
+  memset(p, v, bytes);
+  return 0;
+}
+int emi_h2d(void *d, const void *s, size_t b, emi_stream_t) {
+  memcpy(d, s, b);
+  return 0;
+}
+int emi_d2h(void *d, const void *s, size_t b, emi_stream_t) {
+  memcpy(d, s, b);
+  return 0;
+}
+int emi_d2d(void *d, const void *s, size_t b, emi_stream_t) {
+  memmove(d, s, b);
+  return 0;
+}
+int emi_stream_sync(emi_stream_t) { return 0; }
+int emi_mem_info(size_t *f, size_t *t) {
+  *f = (size_t)8 << 30;
+  *t = (size_t)8 << 30;
+  return 0;
+}
+#endif
+
+template <class T>
+static int upload(const std::vector<T> &h, T **d) {
+  void *p = nullptr;
+  if (emi_dev_malloc(&p, h.size() * sizeof(T))) return -1;
+  if (!h.empty() && emi_h2d(p, h.data(), h.size() * sizeof(T), 0)) return -1;
+  if (emi_stream_sync(0)) return -1;  // the host vector may die right after this call
+  *d = (T *)p;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-resolution plan
+// ------------------------------------------------------------------------------------------
+struct FftClass {
+  std::vector<int> lats;
+  int *d_lats = nullptr;
+  int *d_pref = nullptr;    // rebuilt when the field count changes
+  int pref_nfld = -1;
+  long long nblocks = 0;
+  size_t lds = 0;
+};
+
+struct Plan {
+  bool active = false;
+  int nsmax = 0, ndgl = 0, ndgnh = 0, ngptot = 0, nspec2 = 0;
+  bool reduced = false;
+  double ra = 6371229.0;
+  std::vector<int> nloen, nmen, ndglu, gpoff, nasm0, fbase, wbase, wrows, ldp, lattile_pref, ktile_pref;
+  std::vector<long long> offS, offA;
+  std::vector<double> rmu, rw, racthe, cos2;
+  long long frows = 0, wrows_total = 0, p_elems = 0;
+  // device
+  EmiGeomDev g{};
+  std::vector<void *> dev_allocs;
+  double *d_P = nullptr;
+  // fft
+  std::vector<FftPlanDev> fplans;
+  std::vector<int> planid;
+  FftTabDev ftab{};
+  FftClass fclass[3];
+  // work buffers (grown on demand)
+  double *d_W = nullptr, *d_FB = nullptr;
+  size_t cap_W = 0, cap_FB = 0;
+  void *d_desc = nullptr;
+  size_t cap_desc = 0;
+};
+
+static struct {
+  bool init = false;
+  int max_resol = 1;
+  double ra = 6371229.0;
+  int nproc = 1, myproc = 1;
+  std::vector<Plan *> plans;
+  int max_batch = 0;
+  double phase_ms[3] = {0, 0, 0};
+  bool profile = false;
+} G;
+
+static Plan *get_plan(int kresol) {
+  if (!G.init || kresol < 1 || kresol > (int)G.plans.size() || !G.plans[kresol - 1] || !G.plans[kresol - 1]->active) return nullptr;
+  return G.plans[kresol - 1];
+}
+
+extern "C" int emi_init(const emi_init_t *cfg) {
+  // SETUP_TRANS0 is idempotent (setup_trans0.F90:108-111)
+  if (G.init) return EMI_SUCCESS;
+  emi_init_t c{};
+  if (cfg) c = *cfg;
+  G.max_resol = c.kmax_resol > 0 ? c.kmax_resol : 1;
+  G.ra = c.prad > 0 ? c.prad : 6371229.0;
+  G.nproc = c.nproc > 0 ? c.nproc : 1;
+  G.myproc = c.myproc > 0 ? c.myproc : 1;
+  if (G.nproc != 1) EMI_FAIL(EMI_ERR_UNSUPPORTED, "emi_init: nproc > 1 goes through ectrans_amd.dist (row 8e), not this entry point");
+#ifndef EMI_CPU_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    EMI_FAIL(EMI_ERR_RUNTIME, "emi_init: no HIP device visible -- libectrans_mi has no CPU path");
+  if (c.device >= 0) EMI_CHECK(hipSetDevice(c.device));
+#endif
+  G.plans.assign(G.max_resol, nullptr);
+  const char *pe = getenv("EMI_PROFILE");
+  G.profile = pe && atoi(pe) != 0;
+  const char *mb = getenv("EMI_MAX_BATCH");
+  if (mb) G.max_batch = atoi(mb);
+  G.init = true;
+  return EMI_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------
+// SETUP_TRANS
+// ------------------------------------------------------------------------------------------
+static int roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+static int build_fft_plans(Plan &P) {
+  std::map<int, int> idx;
+  std::vector<d2> tw, rtw, chirp, bhat;
+  std::vector<uint16_t> perm;
+  P.planid.assign(P.ndgl, 0);
+  for (int j = 0; j < P.ndgl; j++) {
+    int n = P.nloen[j];
+    auto it = idx.find(n);
+    if (it != idx.end()) {
+      P.planid[j] = it->second;
+      continue;
+    }
+    FftPlanDev pl{};
+    pl.n = n;
+    pl.cmode = (n % 2 != 0);
+    pl.sz = pl.cmode ? n : n / 2;
+    std::vector<int> fac;
+    pl.blue = !emi::factorize_smooth(pl.sz, fac);
+    pl.S = pl.sz;
+    if (pl.blue) {
+      pl.S = emi::next_235(2 * pl.sz - 1);
+      emi::factorize_smooth(pl.S, fac);
+    }
+    if (pl.S > 65535 || fac.size() > 14) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d not supported (work size %d)", n, pl.S);
+    pl.nfac = (int)fac.size();
+    for (int i = 0; i < pl.nfac; i++) pl.fac[i] = fac[i];
+    pl.tw_off = (int)tw.size();
+    pl.perm_off = (int)perm.size();
+    pl.rtw_off = (int)rtw.size();
+    pl.chirp_off = (int)chirp.size();
+    pl.bhat_off = (int)bhat.size();
+    const double tpi = 2.0 * M_PI;
+    for (int k = 0; k < pl.S; k++) {
+      double a = tpi * (double)k / (double)pl.S;
+      tw.push_back(d2{std::cos(a), -std::sin(a)});
+    }
+    std::vector<uint16_t> pm;
+    emi::dit_positions(pl.S, fac, pm);
+    perm.insert(perm.end(), pm.begin(), pm.end());
+    for (int k = 0; k <= pl.sz; k++) {
+      double a = tpi * (double)k / (double)n;
+      rtw.push_back(d2{std::cos(a), -std::sin(a)});
+    }
+    if (pl.blue) {
+      std::vector<d2> c(pl.sz);
+      for (int k = 0; k < pl.sz; k++) {
+        long long k2 = ((long long)k * k) % (2LL * pl.sz);
+        double a = M_PI * (double)k2 / (double)pl.sz;
+        c[k] = d2{std::cos(a), -std::sin(a)};  // exp(-i pi k^2/sz)
+      }
+      chirp.insert(chirp.end(), c.begin(), c.end());
+      // filter b_j = conj(c_|j|) wrapped to length L; Bhat = DFT_L(b) (direct O(L*sz) sum in
+      // long double: setup only, keeps the table accurate to ~1e-17)
+      const int L = pl.S;
+      std::vector<d2> bh(L);
+      std::vector<long double> cr(L), ci(L);
+      for (int k = 0; k < L; k++) {
+        long double a = 2.0L * (long double)M_PIl * (long double)k / (long double)L;
+        cr[k] = cosl(a);
+        ci[k] = -sinl(a);
+      }
+      emi::parallel_for(L, [&](int k) {
+        long double sr = c[0].x, si = -c[0].y;
+        for (int jj = 1; jj < pl.sz; jj++) {
+          // b_j + b_{L-j} term: conj(c_j) * (w^{jk} + w^{-jk}) = conj(c_j) * 2 cos(2 pi j k/L)
+          long double cs = 2.0L * cr[(int)(((long long)jj * k) % L)];
+          sr += (long double)c[jj].x * cs;
+          si += -(long double)c[jj].y * cs;
+        }
+        bh[pm[k]] = d2{(double)sr, (double)si};
+      });
+      bhat.insert(bhat.end(), bh.begin(), bh.end());
+    }
+    // fields per workgroup: as many as fit ~32 KiB of LDS (power of two, <= 16)
+    size_t per_field = (size_t)pl.S * 16;
+    int fbk = 16;
+    while (fbk > 1 && fbk * per_field > 32768) fbk >>= 1;
+    pl.fbk = fbk;
+    size_t need = fbk * per_field;
+    pl.lds_class = need <= 32768 ? 0 : (need <= 65536 ? 1 : 2);
+    if (need > 160 * 1024) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d needs %zu B of LDS (> 160 KiB)", n, need);
+    int id = (int)P.fplans.size();
+    P.fplans.push_back(pl);
+    idx[n] = id;
+    P.planid[j] = id;
+  }
+  for (int c = 0; c < 3; c++) {
+    P.fclass[c].lats.clear();
+    P.fclass[c].lds = 0;
+  }
+  for (int j = 0; j < P.ndgl; j++) {
+    const FftPlanDev &pl = P.fplans[P.planid[j]];
+    FftClass &fc = P.fclass[pl.lds_class];
+    fc.lats.push_back(j);
+    fc.lds = std::max(fc.lds, (size_t)pl.fbk * pl.S * 16);
+  }
+  d2 *d_tw, *d_rtw, *d_chirp, *d_bhat;
+  uint16_t *d_perm;
+  FftPlanDev *d_plans;
+  int *d_planid;
+  if (upload(tw, &d_tw) || upload(rtw, &d_rtw) || upload(chirp, &d_chirp) || upload(bhat, &d_bhat) || upload(perm, &d_perm) ||
+      upload(P.fplans, &d_plans) || upload(P.planid, &d_planid))
+    return EMI_ERR_RUNTIME;
+  for (void *p : {(void *)d_tw, (void *)d_rtw, (void *)d_chirp, (void *)d_bhat, (void *)d_perm, (void *)d_plans, (void *)d_planid})
+    P.dev_allocs.push_back(p);
+  P.ftab.tw = d_tw;
+  P.ftab.rtw = d_rtw;
+  P.ftab.chirp = d_chirp;
+  P.ftab.bhat = d_bhat;
+  P.ftab.perm = d_perm;
+  P.ftab.plans = d_plans;
+  P.ftab.planid = d_planid;
+  for (int c = 0; c < 3; c++) {
+    if (upload(P.fclass[c].lats, &P.fclass[c].d_lats)) return EMI_ERR_RUNTIME;
+    P.dev_allocs.push_back(P.fclass[c].d_lats);
+  }
+  return 0;
+}
+
+extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
+  if (!G.init) EMI_FAIL(EMI_ERR_STATE, "SETUP_TRANS: SETUP_TRANS0 HAS TO BE CALLED BEFORE SETUP_TRANS");
+  if (!cfg) EMI_FAIL(EMI_ERR_ARG, "emi_setup: null config");
+  if (cfg->kdgl <= 0 || cfg->kdgl % 2 != 0) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KDGL IS NOT A POSITIVE, EVEN NUMBER");
+  if (cfg->lduseflt) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: LDUSEFLT not supported (as gpu/external/setup_trans.F90:442)");
+  if (cfg->ldll) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: LDLL lat-lon grids not supported (as gpu/external/setup_trans.F90:309)");
+  if (cfg->ldstretch) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: PSTRET stretching not supported");
+  if (cfg->precision != 0 && cfg->precision != 8) EMI_FAIL(EMI_ERR_UNSUPPORTED, "emi_setup: only the fp64 (_dp) library is built");
+  if (cfg->ksmax < 0) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KSMAX < 0");
+  int slot = -1;
+  for (int i = 0; i < G.max_resol; i++)
+    if (!G.plans[i] || !G.plans[i]->active) {
+      slot = i;
+      break;
+    }
+  if (slot < 0) EMI_FAIL(EMI_ERR_STATE, "SETUP_TRANS:IDEF_RESOL > NMAX_RESOL");
+  Plan *pp = new Plan();
+  Plan &P = *pp;
+  P.nsmax = cfg->ksmax;
+  P.ndgl = cfg->kdgl;
+  P.ndgnh = (P.ndgl + 1) / 2;
+  P.ra = G.ra;
+  const int N = P.nsmax, L = P.ndgl;
+  int ndlon = cfg->kdlon > 0 ? cfg->kdlon : 2 * L;
+  P.nloen.assign(L, ndlon);
+  if (cfg->kloen) {
+    ndlon = 0;
+    for (int j = 0; j < L; j++) {
+      if (cfg->kloen[j] <= 0) {
+        delete pp;
+        EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KLOEN INVALID (ONE or MORE POINTS <= 0)");
+      }
+      ndlon = std::max(ndlon, cfg->kloen[j]);
+    }
+    for (int j = 0; j < L; j++) {
+      P.nloen[j] = cfg->kloen[j];
+      if (cfg->kloen[j] != ndlon) P.reduced = true;
+    }
+  }
+  P.nspec2 = (N + 1) * (N + 2);
+  P.gpoff.assign(L, 0);
+  {
+    long long off = 0;
+    for (int j = 0; j < L; j++) {
+      P.gpoff[j] = (int)off;
+      off += P.nloen[j];
+    }
+    if (off > 2000000000LL) {
+      delete pp;
+      EMI_FAIL(EMI_ERR_UNSUPPORTED, "grid too large for 32-bit point offsets");
+    }
+    P.ngptot = (int)off;
+  }
+  // Gaussian latitudes / weights, cos^2, 1/(a cos)  (suleg_mod.F90:264-293, 386-394)
+  emi::gauss_latitudes(L, P.rmu, P.rw);
+  P.cos2.assign(L, 0.0);
+  P.racthe.assign(L, 0.0);
+  for (int j = 0; j < L; j++) {
+    double th = std::asin(P.rmu[j]), c = std::cos(th);
+    P.cos2[j] = c * c;
+    P.racthe[j] = 1.0 / c / P.ra;
+  }
+  emi::wavenumber_cutoffs(N, L, P.nloen, P.reduced, P.cos2, P.nmen, P.ndglu);
+  // index tables
+  P.nasm0.assign(N + 1, 0);
+  P.wbase.assign(N + 2, 0);
+  P.wrows.assign(N + 1, 0);
+  P.ldp.assign(N + 1, 0);
+  P.offS.assign(N + 1, 0);
+  P.offA.assign(N + 1, 0);
+  P.lattile_pref.assign(N + 2, 0);
+  P.ktile_pref.assign(N + 2, 0);
+  std::vector<int> ebase(N + 1, 0);
+  std::vector<double> eps;
+  {
+    int ipos = 0;
+    long long poff = 0;
+    for (int m = 0; m <= N; m++) {
+      P.nasm0[m] = ipos;  // 0-based (D%NASM0 - 1, suwavedi_mod.F90:128-133)
+      ipos += (N - m + 1) * 2;
+      P.wrows[m] = roundup(N + 2 - m, 16);
+      P.wbase[m + 1] = P.wbase[m] + P.wrows[m];
+      int nd = std::min(P.ndgnh, P.ndglu[m]);
+      P.ldp[m] = roundup(std::max(nd, 1), 64);
+      long long pan = (long long)(P.wrows[m] / 2) * P.ldp[m];
+      P.offS[m] = poff;
+      P.offA[m] = poff + pan;
+      poff += 2 * pan;
+      P.lattile_pref[m + 1] = P.lattile_pref[m] + (nd + 63) / 64;
+      P.ktile_pref[m + 1] = P.ktile_pref[m] + (P.wrows[m] / 2 + 63) / 64;
+      ebase[m] = (int)eps.size();
+      for (int n = m; n <= N + 2; n++)  // REPSNM (pre_suleg_mod.F90:55-63)
+        eps.push_back(std::sqrt((double)(n * n - m * m) / (double)(4 * n * n - 1)));
+    }
+    P.p_elems = poff;
+    P.wrows_total = P.wbase[N + 1];
+  }
+  std::vector<int> rowm(P.wrows_total);
+  for (int m = 0; m <= N; m++)
+    for (int r = 0; r < P.wrows[m]; r++) rowm[P.wbase[m] + r] = m;
+  P.fbase.assign(L + 1, 0);
+  for (int j = 0; j < L; j++) P.fbase[j + 1] = P.fbase[j] + P.nmen[j] + 1;
+  P.frows = P.fbase[L];
+  std::vector<double> lapin(N + 4, 0.0);  // RLAPIN(-1:N+2) (pre_suleg_mod.F90:64-69)
+  for (int n = 1; n <= N + 2; n++) lapin[n + 1] = -(P.ra * P.ra / (double)(n * (n + 1)));
+
+  // Legendre panels: PS[k][j] = P_{m+2k}^m(mu_{isl0+j}), PA[k][j] = P_{m+2k+1}^m, zero padded
+  void *dP = nullptr;
+  if (emi_dev_malloc(&dP, (size_t)P.p_elems * 8)) {
+    delete pp;
+    EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB for the Legendre panels", P.p_elems * 8.0 / (1 << 30));
+  }
+  P.d_P = (double *)dP;
+  P.dev_allocs.push_back(dP);
+  {
+    std::atomic<int> bad{0};
+    emi::parallel_for(N + 1, [&](int m) {
+      const int nd = std::min(P.ndgnh, P.ndglu[m]), isl0 = P.ndgnh - nd;
+      const int ld = P.ldp[m], nk = P.wrows[m] / 2;
+      const int nmax = N + 2;
+      std::vector<double> pan((size_t)2 * nk * ld, 0.0), col(nmax + 1);
+      std::vector<int> corr(nmax + 1);
+      emi::LegCoef lc = emi::legendre_coefficients(m, nmax);
+      for (int j = 0; j < nd; j++) {
+        double mu = P.rmu[isl0 + j];
+        for (int par = 0; par < 2; par++) {
+          emi::legendre_column(lc, mu, par, col.data(), corr.data());
+          double *dst = pan.data() + (size_t)par * nk * ld;
+          for (int k = 0; m + 2 * k + par <= N + 1; k++) dst[(size_t)k * ld + j] = col[m + 2 * k + par];
+        }
+      }
+      if (emi_h2d(P.d_P + P.offS[m], pan.data(), pan.size() * 8, 0)) bad = 1;
+      emi_stream_sync(0);
+    });
+    if (bad) {
+      delete pp;
+      return EMI_ERR_RUNTIME;
+    }
+  }
+  // device tables
+  int *d_nloen, *d_nmen, *d_ndglu, *d_gpoff, *d_nasm0, *d_fbase, *d_wbase, *d_wrows, *d_rowm, *d_ebase, *d_ldp, *d_ltp, *d_ktp;
+  double *d_eps, *d_lapin, *d_rw, *d_racthe;
+  long long *d_offS, *d_offA;
+  if (upload(P.nloen, &d_nloen) || upload(P.nmen, &d_nmen) || upload(P.ndglu, &d_ndglu) || upload(P.gpoff, &d_gpoff) ||
+      upload(P.nasm0, &d_nasm0) || upload(P.fbase, &d_fbase) || upload(P.wbase, &d_wbase) || upload(P.wrows, &d_wrows) ||
+      upload(rowm, &d_rowm) || upload(ebase, &d_ebase) || upload(P.ldp, &d_ldp) || upload(P.lattile_pref, &d_ltp) ||
+      upload(P.ktile_pref, &d_ktp) || upload(eps, &d_eps) || upload(lapin, &d_lapin) || upload(P.rw, &d_rw) ||
+      upload(P.racthe, &d_racthe) || upload(P.offS, &d_offS) || upload(P.offA, &d_offA)) {
+    delete pp;
+    return EMI_ERR_RUNTIME;
+  }
+  for (void *p : {(void *)d_nloen, (void *)d_nmen, (void *)d_ndglu, (void *)d_gpoff, (void *)d_nasm0, (void *)d_fbase, (void *)d_wbase,
+                  (void *)d_wrows, (void *)d_rowm, (void *)d_ebase, (void *)d_ldp, (void *)d_ltp, (void *)d_ktp, (void *)d_eps,
+                  (void *)d_lapin, (void *)d_rw, (void *)d_racthe, (void *)d_offS, (void *)d_offA})
+    P.dev_allocs.push_back(p);
+  EmiGeomDev &g = P.g;
+  g.nsmax = N;
+  g.ndgl = L;
+  g.ndgnh = P.ndgnh;
+  g.ngptot = P.ngptot;
+  g.nloen = d_nloen;
+  g.nmen = d_nmen;
+  g.ndglu = d_ndglu;
+  g.gpoff = d_gpoff;
+  g.nasm0 = d_nasm0;
+  g.fbase = d_fbase;
+  g.wbase = d_wbase;
+  g.wrows = d_wrows;
+  g.rowm = d_rowm;
+  g.ebase = d_ebase;
+  g.eps = d_eps;
+  g.lapin = d_lapin;
+  g.rw = d_rw;
+  g.racthe = d_racthe;
+  g.P = P.d_P;
+  g.offS = d_offS;
+  g.offA = d_offA;
+  g.ldp = d_ldp;
+  g.lattile_pref = d_ltp;
+  g.ktile_pref = d_ktp;
+  int rc = build_fft_plans(P);
+  if (rc) {
+    delete pp;
+    return rc;
+  }
+  emi_stream_sync(0);
+  P.active = true;
+  if (G.plans[slot]) delete G.plans[slot];
+  G.plans[slot] = pp;
+  if (kresol) *kresol = slot + 1;
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_release(int kresol) {
+  Plan *P = get_plan(kresol);
+  if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_RELEASE: unknown resolution %d", kresol);
+  emi_stream_sync(0);
+  for (void *p : P->dev_allocs) emi_dev_free(p);
+  for (int c = 0; c < 3; c++) emi_dev_free(P->fclass[c].d_pref);
+  emi_dev_free(P->d_W);
+  emi_dev_free(P->d_FB);
+  emi_dev_free(P->d_desc);
+  P->active = false;
+  delete P;
+  G.plans[kresol - 1] = nullptr;
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_finalize(void) {
+  if (!G.init) return EMI_SUCCESS;
+  for (int i = 0; i < (int)G.plans.size(); i++)
+    if (G.plans[i] && G.plans[i]->active) emi_release(i + 1);
+  G.plans.clear();
+  G.init = false;
+  return EMI_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------
+// TRANS_INQ
+// ------------------------------------------------------------------------------------------
+extern "C" int emi_inq_int(int kresol, const char *name, int *value) {
+  Plan *P = get_plan(kresol);
+  if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_INQ: unknown resolution %d", kresol);
+  std::string s(name ? name : "");
+  if (s == "nspec2" || s == "nspec2g" || s == "nspec2mx")
+    *value = P->nspec2;
+  else if (s == "nspec" || s == "nspecg")
+    *value = P->nspec2 / 2;
+  else if (s == "ngptot" || s == "ngptotg" || s == "ngptotmx")
+    *value = P->ngptot;
+  else if (s == "nump")
+    *value = P->nsmax + 1;
+  else if (s == "ndgl")
+    *value = P->ndgl;
+  else if (s == "nsmax")
+    *value = P->nsmax;
+  else if (s == "ndlon")
+    *value = *std::max_element(P->nloen.begin(), P->nloen.end());
+  else
+    EMI_FAIL(EMI_ERR_ARG, "emi_inq_int: unknown name '%s'", s.c_str());
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_inq_int_array(int kresol, const char *name, int *out, int len) {
+  Plan *P = get_plan(kresol);
+  if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_INQ: unknown resolution %d", kresol);
+  std::string s(name ? name : "");
+  const std::vector<int> *v = nullptr;
+  std::vector<int> tmp;
+  if (s == "nloen")
+    v = &P->nloen;
+  else if (s == "nmen" || s == "nmeng")
+    v = &P->nmen;
+  else if (s == "ndglu")
+    v = &P->ndglu;
+  else if (s == "nasm0") {
+    tmp = P->nasm0;
+    for (auto &x : tmp) x += 1;  // Fortran 1-based D%NASM0
+    v = &tmp;
+  } else if (s == "myms") {
+    tmp.resize(P->nsmax + 1);
+    for (int m = 0; m <= P->nsmax; m++) tmp[m] = m;
+    v = &tmp;
+  } else
+    EMI_FAIL(EMI_ERR_ARG, "emi_inq_int_array: unknown name '%s'", s.c_str());
+  if (len < (int)v->size()) EMI_FAIL(EMI_ERR_ARG, "TRANS_INQ: %s TOO SMALL (%d < %zu)", s.c_str(), len, v->size());
+  std::copy(v->begin(), v->end(), out);
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_inq_real_array(int kresol, const char *name, double *out, int len) {
+  Plan *P = get_plan(kresol);
+  if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_INQ: unknown resolution %d", kresol);
+  std::string s(name ? name : "");
+  const std::vector<double> *v = nullptr;
+  if (s == "rmu" || s == "pmu")
+    v = &P->rmu;
+  else if (s == "rgw" || s == "pgw" || s == "rw")
+    v = &P->rw;
+  else if (s == "racthe")
+    v = &P->racthe;
+  else
+    EMI_FAIL(EMI_ERR_ARG, "emi_inq_real_array: unknown name '%s'", s.c_str());
+  if (len < (int)v->size()) EMI_FAIL(EMI_ERR_ARG, "TRANS_INQ: %s TOO SMALL", s.c_str());
+  std::copy(v->begin(), v->end(), out);
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_inq_legendre(int kresol, int m, int symmetric, double *out, int *nrows, int *ncols) {
+  Plan *P = get_plan(kresol);
+  if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_INQ: unknown resolution %d", kresol);
+  if (m < 0 || m > P->nsmax) EMI_FAIL(EMI_ERR_ARG, "emi_inq_legendre: m out of range");
+  const int N = P->nsmax, nd = std::min(P->ndgnh, P->ndglu[m]);
+  const int nc = symmetric ? (N - m + 3) / 2 : (N - m + 2) / 2;
+  if (nrows) *nrows = nd;
+  if (ncols) *ncols = nc;
+  if (!out) return EMI_SUCCESS;
+  const int ld = P->ldp[m], nk = P->wrows[m] / 2;
+  std::vector<double> pan((size_t)nk * ld);
+  if (emi_d2h(pan.data(), P->d_P + (symmetric ? P->offS[m] : P->offA[m]), pan.size() * 8, 0)) return EMI_ERR_RUNTIME;
+  emi_stream_sync(0);
+  // reference column c (0-based) holds n descending: k = nc-1-c
+  for (int c = 0; c < nc; c++)
+    for (int j = 0; j < nd; j++) out[(size_t)c * nd + j] = pan[(size_t)(nc - 1 - c) * ld + j];
+  return EMI_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------
+// transforms
+// ------------------------------------------------------------------------------------------
+struct HostStage {  // staging of host arrays through device memory (mem_space == HOST)
+  std::vector<void *> dev;
+  std::vector<std::pair<void *, std::pair<void *, size_t>>> outs;  // dev -> (host, bytes)
+  ~HostStage() {
+    for (void *p : dev) emi_dev_free(p);
+  }
+  const double *in(const void *h, size_t elems, bool host, emi_stream_t s) {
+    if (!h || !host) return (const double *)h;
+    void *d = nullptr;
+    if (emi_dev_malloc(&d, elems * 8)) return nullptr;
+    dev.push_back(d);
+    emi_h2d(d, h, elems * 8, s);
+    return (const double *)d;
+  }
+  double *out(void *h, size_t elems, bool host) {
+    if (!h || !host) return (double *)h;
+    void *d = nullptr;
+    if (emi_dev_malloc(&d, elems * 8)) return nullptr;
+    dev.push_back(d);
+    outs.push_back({d, {h, elems * 8}});
+    return (double *)d;
+  }
+  void flush(emi_stream_t s) {
+    for (auto &o : outs) emi_d2h(o.second.first, o.first, o.second.second, s);
+    emi_stream_sync(s);
+  }
+};
+
+static int ensure_work(Plan &P, int bfpad) {
+  size_t needW = (size_t)P.wrows_total * 2 * bfpad * 8, needF = (size_t)P.frows * 2 * bfpad * 8;
+  if (needW > P.cap_W) {
+    emi_stream_sync(0);
+    emi_dev_free(P.d_W);
+    P.d_W = nullptr;
+    P.cap_W = 0;
+    void *p;
+    if (emi_dev_malloc(&p, needW)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB packed-spectral work buffer", needW / 1073741824.0);
+    P.d_W = (double *)p;
+    P.cap_W = needW;
+    emi_dev_memset(p, 0, needW, 0);
+  }
+  if (needF > P.cap_FB) {
+    emi_stream_sync(0);
+    emi_dev_free(P.d_FB);
+    P.d_FB = nullptr;
+    P.cap_FB = 0;
+    void *p;
+    if (emi_dev_malloc(&p, needF)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB Fourier work buffer", needF / 1073741824.0);
+    P.d_FB = (double *)p;
+    P.cap_FB = needF;
+    emi_dev_memset(p, 0, needF, 0);
+  }
+  return 0;
+}
+
+static int ensure_desc(Plan &P, size_t bytes) {
+  if (bytes <= P.cap_desc) return 0;
+  emi_stream_sync(0);
+  emi_dev_free(P.d_desc);
+  P.d_desc = nullptr;
+  size_t cap = std::max(bytes, (size_t)1 << 16);
+  if (emi_dev_malloc(&P.d_desc, cap)) return EMI_ERR_RUNTIME;
+  P.cap_desc = cap;
+  return 0;
+}
+
+static int fft_prefix(Plan &P, int nfld) {
+  for (int c = 0; c < 3; c++) {
+    FftClass &fc = P.fclass[c];
+    if (fc.pref_nfld == nfld) continue;
+    std::vector<int> pref(fc.lats.size() + 1, 0);
+    for (size_t i = 0; i < fc.lats.size(); i++) {
+      int fbk = P.fplans[P.planid[fc.lats[i]]].fbk;
+      pref[i + 1] = pref[i] + (nfld + fbk - 1) / fbk;
+    }
+    fc.nblocks = pref.back();
+    emi_stream_sync(0);
+    emi_dev_free(fc.d_pref);
+    fc.d_pref = nullptr;
+    if (upload(pref, &fc.d_pref)) return EMI_ERR_RUNTIME;
+    fc.pref_nfld = nfld;
+  }
+  return 0;
+}
+
+static int pick_batch(Plan &P, int nfields) {
+  // fields per batch: bounded by free HBM (W + FB rows x 16 B per field) and EMI_MAX_BATCH
+  size_t fr = 0, tot = 0;
+  emi_mem_info(&fr, &tot);
+  size_t have = fr + P.cap_W + P.cap_FB;
+  double per_field = (double)(P.wrows_total + P.frows) * 16.0;
+  long long cap = (long long)((double)have * 0.85 / per_field);
+  cap = cap / 64 * 64;
+  if (cap < 64) cap = 64;
+  if (G.max_batch > 0) cap = std::min<long long>(cap, std::max(64, roundup(G.max_batch, 64)));
+  int nb = (int)((nfields + cap - 1) / cap);
+  if (nb < 1) nb = 1;
+  return (nfields + nb - 1) / nb;
+}
+
+struct PhaseTimer {
+#ifndef EMI_CPU_EMU
+  hipEvent_t ev[8];
+  int n = 0;
+  bool on;
+  emi_stream_t s;
+  PhaseTimer(bool on_, emi_stream_t s_) : on(on_), s(s_) {
+    if (on)
+      for (auto &e : ev) hipEventCreate(&e);
+  }
+  void mark() {
+    if (on && n < 8) hipEventRecord(ev[n++], s);
+  }
+  float between(int a, int b) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, ev[a], ev[b]);
+    return ms;
+  }
+  ~PhaseTimer() {
+    if (on)
+      for (auto &e : ev) hipEventDestroy(e);
+  }
+#else
+  PhaseTimer(bool, emi_stream_t) {}
+  void mark() {}
+  float between(int, int) { return 0; }
+  bool on = false;
+  int n = 0;
+#endif
+};
+
+static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, double *FB, int ldf, int nproma, emi_stream_t st) {
+  for (int c = 0; c < 3; c++) {
+    FftClass &fc = P.fclass[c];
+    if (fc.lats.empty() || fc.nblocks == 0) continue;
+    FftLaunchDev lc{fc.d_lats, fc.d_pref, (int)fc.lats.size()};
+    if (inverse)
+      EMI_LAUNCH(k_fft_inv, fc.nblocks, FFT_THREADS, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma);
+    else
+      EMI_LAUNCH(k_fft_dir, fc.nblocks, FFT_THREADS, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, FB, ldf, nproma);
+  }
+}
+
+#ifndef EMI_CPU_EMU
+static int set_lds_attrs() {
+  static bool done = false;
+  if (done) return 0;
+  EMI_CHECK(hipFuncSetAttribute((const void *)k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done = true;
+  return 0;
+}
+#else
+static int set_lds_attrs() { return 0; }
+#endif
+
+// scalar field enumeration shared by both directions: PSPSCALAR, or PSPSC2 + PSPSC3A + PSPSC3B
+// (ltinv_mod.F90:203-240 / updsp_mod.F90:128-160 ordering)
+struct ScalarRef {
+  int arr;  // 0 scalar, 1 sc2, 2 sc3a, 3 sc3b
+  int lev, var;
+};
+
+template <class ARGS>
+static int enumerate_scalars(const ARGS &a, const char *who, std::vector<ScalarRef> &sc) {
+  sc.clear();
+  if (a.spscalar) {
+    if (a.spsc3a || a.spsc3b || a.spsc2) EMI_FAIL(EMI_ERR_ARG, "%s : PSPSCALAR AND PSPSC3A/PSPSC3B/PSPSC2 BOTH PRESENT", who);
+    for (int i = 0; i < a.nf_scalar; i++) sc.push_back({0, i, 0});
+  } else {
+    if (a.spsc2)
+      for (int i = 0; i < a.nf_sc2; i++) sc.push_back({1, i, 0});
+    if (a.spsc3a)
+      for (int v = 0; v < a.sc3a_nvar; v++)
+        for (int l = 0; l < a.sc3a_nlev; l++) sc.push_back({2, l, v});
+    if (a.spsc3b)
+      for (int v = 0; v < a.sc3b_nvar; v++)
+        for (int l = 0; l < a.sc3b_nlev; l++) sc.push_back({3, l, v});
+  }
+  return 0;
+}
+
+extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "INV_TRANS: unknown resolution %d", kresol);
+  if (!ap) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS: null argument block");
+  Plan &P = *Pp;
+  const emi_invtrans_t &a = *ap;
+  emi_stream_t st = (emi_stream_t)a.stream;
+  const bool host = a.mem_space == EMI_MEM_HOST;
+  // ---- field accounting (inv_trans.F90:230-387)
+  const int nuv = (a.spvor || a.spdiv) ? a.nf_uv : 0;
+  if (nuv > 0 && !a.spvor) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS : IF_UV > 0 BUT PSPVOR MISSING");
+  if (nuv > 0 && !a.spdiv) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS : IF_UV > 0 BUT PSPDIV MISSING");
+  std::vector<ScalarRef> sc;
+  if (enumerate_scalars(a, "INV_TRANS", sc)) return EMI_ERR_ARG;
+  const int nsc = (int)sc.size();
+  bool lscders = a.ldscders && nsc > 0, lvorgp = a.ldvorgp != 0, ldivgp = a.lddivgp != 0, luvder = a.lduvder && nuv > 0;
+  if (lvorgp) ldivgp = true;  // inv_trans.F90:350
+  const int nproma = a.kproma > 0 ? a.kproma : P.ngptot;
+  const int ngpblks = (P.ngptot - 1) / nproma + 1;
+  int if_gp = 2 * nuv + nsc + (lscders ? 2 * nsc : 0) + ((nuv && lvorgp) ? nuv : 0) + ((nuv && ldivgp) ? nuv : 0) + (luvder ? 2 * nuv : 0);
+  if (a.gp) {
+    if (a.gpuv || a.gp3a || a.gp3b || a.gp2) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:PGP AND PGPUV/PGP3A/PGP3B/PGP2 CAN NOT BOTH BE PRESENT");
+    if (a.gp_nfld < if_gp) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:SECOND DIMENSION OF PGP TOO SMALL (%d < %d)", a.gp_nfld, if_gp);
+  } else {
+    if (nuv > 0 && !a.gpuv) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:PGPUV MISSING");
+    if (a.spscalar && nsc > 0) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:PGP MISSING (PSPSCALAR needs PGP)");
+    if (a.spsc2 && a.nf_sc2 > 0 && !a.gp2) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:PGP2 MISSING");
+    if (a.spsc3a && a.sc3a_nlev * a.sc3a_nvar > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:PGP3A MISSING");
+    if (a.spsc3b && a.sc3b_nlev * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:PGP3B MISSING");
+  }
+  if (if_gp == 0) return EMI_SUCCESS;
+  if (set_lds_attrs()) return EMI_ERR_RUNTIME;
+
+  // ---- stage host arrays
+  HostStage hs;
+  const size_t ns2 = P.nspec2;
+  const double *d_vor = hs.in(a.spvor, ns2 * a.nf_uv, host && nuv, st), *d_div = hs.in(a.spdiv, ns2 * a.nf_uv, host && nuv, st);
+  const double *d_sc[4] = {hs.in(a.spscalar, ns2 * a.nf_scalar, host, st), hs.in(a.spsc2, ns2 * a.nf_sc2, host, st),
+                           hs.in(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host, st),
+                           hs.in(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host, st)};
+  const int nvar_uv = ((nuv && lvorgp) ? 1 : 0) + ((nuv && ldivgp) ? 1 : 0) + 2 + (luvder ? 2 : 0);
+  const int dmul = lscders ? 3 : 1;
+  const size_t gsz = (size_t)nproma * ngpblks;
+  double *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host);
+  double *d_gpuv = hs.out(a.gpuv, gsz * nuv * nvar_uv, host && nuv);
+  double *d_gp2 = hs.out(a.gp2, gsz * a.nf_sc2 * dmul, host);
+  double *d_gp3a = hs.out(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar * dmul, host);
+  double *d_gp3b = hs.out(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar * dmul, host);
+
+  // ---- Legendre-space fields (ltinv_mod.F90:166-262): [vor][div] u v scalars [nsders]
+  std::vector<SpecSrc> lt;
+  auto sc_src = [&](const ScalarRef &r, int kind) {
+    SpecSrc s{};
+    s.kind = kind;
+    switch (r.arr) {
+      case 0: s.a = d_sc[0]; s.sa = a.nf_scalar; s.ia = r.lev; break;
+      case 1: s.a = d_sc[1]; s.sa = a.nf_sc2; s.ia = r.lev; break;
+      case 2: s.a = d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev; s.sa = a.sc3a_nlev; s.ia = r.lev; break;
+      default: s.a = d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev; s.sa = a.sc3b_nlev; s.ia = r.lev; break;
+    }
+    return s;
+  };
+  int i_vor = -1, i_div = -1, i_u = -1, i_v = -1, i_sc = -1, i_nsd = -1;
+  if (nuv) {
+    auto uvsrc = [&](int i, int kind) {
+      SpecSrc s{};
+      s.kind = kind;
+      s.a = d_vor; s.sa = a.nf_uv; s.ia = i;
+      s.b = d_div; s.sb = a.nf_uv; s.ib = i;
+      if (kind == SPK_COPY + 100) { s.kind = SPK_COPY; s.a = d_div; }
+      return s;
+    };
+    if (lvorgp) { i_vor = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_COPY)); }
+    if (ldivgp) { i_div = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_COPY + 100)); }
+    i_u = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_U));
+    i_v = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_V));
+  }
+  if (nsc) {
+    i_sc = (int)lt.size();
+    for (auto &r : sc) lt.push_back(sc_src(r, SPK_COPY));
+    if (lscders) { i_nsd = (int)lt.size(); for (auto &r : sc) lt.push_back(sc_src(r, SPK_NSD)); }
+  }
+  const int nlt = (int)lt.size();
+  // ---- grid fields (ftinv_ctl_mod.F90:228-262 order) with their destination arrays
+  struct GOut { GridFld g; int lt; };
+  std::vector<GOut> gout;
+  int gcount = 0;
+  auto dest_uv = [&](int var, int lev) {
+    GridFld g{};
+    if (d_gp) { g.base = d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
+    else { g.base = d_gpuv; g.nf_arr = nuv * nvar_uv; g.fidx = var * nuv + lev; }
+    return g;
+  };
+  auto dest_sc = [&](int isc, int kder) {
+    GridFld g{};
+    if (d_gp) { g.base = d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; return g; }
+    const ScalarRef &r = sc[isc];
+    if (r.arr == 1) { g.base = d_gp2; g.nf_arr = a.nf_sc2 * dmul; g.fidx = r.lev + kder * a.nf_sc2; }
+    else if (r.arr == 2) { g.base = d_gp3a; g.nf_arr = a.sc3a_nlev * a.sc3a_nvar * dmul; g.fidx = (r.var + kder * a.sc3a_nvar) * a.sc3a_nlev + r.lev; }
+    else { g.base = d_gp3b; g.nf_arr = a.sc3b_nlev * a.sc3b_nvar * dmul; g.fidx = (r.var + kder * a.sc3b_nvar) * a.sc3b_nlev + r.lev; }
+    return g;
+  };
+  int uvvar = 0;
+  auto push = [&](GridFld g, int mode, int src) { g.mode = mode; g.src = src; gout.push_back({g, src}); gcount++; };
+  if (nuv) {
+    if (lvorgp) { for (int i = 0; i < nuv; i++) push(dest_uv(uvvar, i), GM_PLAIN, i_vor + i); uvvar++; }
+    if (ldivgp) { for (int i = 0; i < nuv; i++) push(dest_uv(uvvar, i), GM_PLAIN, i_div + i); uvvar++; }
+    for (int i = 0; i < nuv; i++) push(dest_uv(uvvar, i), GM_ACOS, i_u + i);
+    uvvar++;
+    for (int i = 0; i < nuv; i++) push(dest_uv(uvvar, i), GM_ACOS, i_v + i);
+    uvvar++;
+  }
+  for (int i = 0; i < nsc; i++) push(dest_sc(i, 0), GM_PLAIN, i_sc + i);
+  if (lscders) for (int i = 0; i < nsc; i++) push(dest_sc(i, 1), GM_ACOS, i_nsd + i);
+  if (luvder) {
+    for (int i = 0; i < nuv; i++) push(dest_uv(uvvar, i), GM_EWDER_UV, i_u + i);
+    uvvar++;
+    for (int i = 0; i < nuv; i++) push(dest_uv(uvvar, i), GM_EWDER_UV, i_v + i);
+    uvvar++;
+  }
+  if (lscders) for (int i = 0; i < nsc; i++) push(dest_sc(i, 2), GM_EWDER, i_sc + i);
+
+  // ---- batches over Legendre-space fields
+  const int bsz = pick_batch(P, nlt);
+  const int bfpad = roundup(std::min(bsz, nlt), 64);
+  if (ensure_work(P, bfpad)) return EMI_ERR_RUNTIME;
+  const int ldw = 2 * bfpad;
+  PhaseTimer pt(G.profile, st);
+  double ms[3] = {0, 0, 0};
+  for (int b0 = 0; b0 < nlt; b0 += bsz) {
+    const int nb = std::min(bsz, nlt - b0);
+    std::vector<SpecSrc> bl(lt.begin() + b0, lt.begin() + b0 + nb);
+    std::vector<GridFld> bg;
+    for (auto &go : gout)
+      if (go.lt >= b0 && go.lt < b0 + nb) {
+        GridFld g = go.g;
+        g.src = go.lt - b0;
+        bg.push_back(g);
+      }
+    size_t off_g = (bl.size() * sizeof(SpecSrc) + 255) / 256 * 256;
+    size_t bytes = off_g + bg.size() * sizeof(GridFld);
+    if (ensure_desc(P, bytes)) return EMI_ERR_RUNTIME;
+    emi_stream_sync(st);  // descriptors of the previous batch are no longer in use
+    emi_h2d(P.d_desc, bl.data(), bl.size() * sizeof(SpecSrc), st);
+    emi_h2d((char *)P.d_desc + off_g, bg.data(), bg.size() * sizeof(GridFld), st);
+    emi_stream_sync(st);  // bl/bg are stack vectors
+    if (fft_prefix(P, (int)bg.size())) return EMI_ERR_RUNTIME;
+    const SpecSrc *d_bl = (const SpecSrc *)P.d_desc;
+    const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + off_g);
+    pt.n = 0;
+    pt.mark();
+    {
+      long long total = (long long)P.wrows_total * bfpad;
+      long long nblk = (total + 255) / 256;
+      EMI_LAUNCH(k_prepack_inv, nblk, 256, 0, st, P.g, d_bl, nb, bfpad, P.d_W, ldw, (long long)P.wrows_total);
+    }
+    pt.mark();
+    {
+      const int nct = ldw / LG_BN;
+      long long ntiles = (long long)P.lattile_pref[P.nsmax + 1] * nct;
+      EMI_LAUNCH(k_leg_inv, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_W, ldw, P.d_FB, ldw, ntiles);
+    }
+    pt.mark();
+    launch_fft(P, true, d_bg, (int)bg.size(), P.d_FB, ldw, nproma, st);
+    pt.mark();
+    if (pt.on) {
+      emi_stream_sync(st);
+      for (int i = 0; i < 3; i++) ms[i] += pt.between(i, i + 1);
+    }
+  }
+  if (G.profile)
+    for (int i = 0; i < 3; i++) G.phase_ms[i] = ms[i];
+  if (host) hs.flush(st);
+#ifndef EMI_CPU_EMU
+  EMI_CHECK(hipGetLastError());
+#endif
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "DIR_TRANS: unknown resolution %d", kresol);
+  if (!ap) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS: null argument block");
+  Plan &P = *Pp;
+  const emi_dirtrans_t &a = *ap;
+  emi_stream_t st = (emi_stream_t)a.stream;
+  const bool host = a.mem_space == EMI_MEM_HOST;
+  const int nuv = (a.spvor || a.spdiv) ? a.nf_uv : 0;
+  if (nuv > 0 && (!a.spvor || !a.spdiv)) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS : IF_UV > 0 BUT PSPVOR OR PSPDIV MISSING");
+  std::vector<ScalarRef> sc;
+  if (enumerate_scalars(a, "DIR_TRANS", sc)) return EMI_ERR_ARG;
+  const int nsc = (int)sc.size();
+  const int nproma = a.kproma > 0 ? a.kproma : P.ngptot;
+  const int ngpblks = (P.ngptot - 1) / nproma + 1;
+  const int if_gp = 2 * nuv + nsc;  // dir_trans.F90:303
+  if (a.gp) {
+    if (a.gpuv || a.gp3a || a.gp3b || a.gp2) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP AND PGPUV/PGP3A/PGP3B/PGP2 CAN NOT BOTH BE PRESENT");
+    if (a.gp_nfld < if_gp) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:SECOND DIMENSION OF PGP TOO SMALL (%d < %d)", a.gp_nfld, if_gp);
+  } else {
+    if (nuv > 0 && !a.gpuv) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGPUV MISSING");
+    if (a.spscalar && nsc > 0) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP MISSING (PSPSCALAR needs PGP)");
+    if (a.spsc2 && a.nf_sc2 > 0 && !a.gp2) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP2 MISSING");
+    if (a.spsc3a && a.sc3a_nlev * a.sc3a_nvar > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP3A MISSING");
+    if (a.spsc3b && a.sc3b_nlev * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP3B MISSING");
+  }
+  if (if_gp == 0) return EMI_SUCCESS;
+  if (set_lds_attrs()) return EMI_ERR_RUNTIME;
+
+  HostStage hs;
+  const size_t ns2 = P.nspec2, gsz = (size_t)nproma * ngpblks;
+  double *d_vor = hs.out(a.spvor, ns2 * a.nf_uv, host && nuv), *d_div = hs.out(a.spdiv, ns2 * a.nf_uv, host && nuv);
+  double *d_sc[4] = {hs.out(a.spscalar, ns2 * a.nf_scalar, host), hs.out(a.spsc2, ns2 * a.nf_sc2, host),
+                     hs.out(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host), hs.out(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host)};
+  const double *d_gp = hs.in(a.gp, gsz * a.gp_nfld, host, st);
+  const double *d_gpuv = hs.in(a.gpuv, gsz * nuv * 2, host && nuv, st);
+  const double *d_gp2 = hs.in(a.gp2, gsz * a.nf_sc2, host, st);
+  const double *d_gp3a = hs.in(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar, host, st);
+  const double *d_gp3b = hs.in(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar, host, st);
+
+  // Fourier-space fields: u(nuv) v(nuv) scalars (dir_trans.F90:301, ftdir_ctl_mod.F90)
+  std::vector<GridFld> gin;
+  int gcount = 0;
+  for (int var = 0; var < 2 && nuv; var++)
+    for (int i = 0; i < nuv; i++) {
+      GridFld g{};
+      if (d_gp) { g.base = (double *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
+      else { g.base = (double *)d_gpuv; g.nf_arr = nuv * 2; g.fidx = var * nuv + i; }
+      g.mode = GM_ACOS;
+      gin.push_back(g);
+      gcount++;
+    }
+  for (int i = 0; i < nsc; i++) {
+    GridFld g{};
+    const ScalarRef &r = sc[i];
+    if (d_gp) { g.base = (double *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
+    else if (r.arr == 1) { g.base = (double *)d_gp2; g.nf_arr = a.nf_sc2; g.fidx = r.lev; }
+    else if (r.arr == 2) { g.base = (double *)d_gp3a; g.nf_arr = a.sc3a_nlev * a.sc3a_nvar; g.fidx = r.var * a.sc3a_nlev + r.lev; }
+    else { g.base = (double *)d_gp3b; g.nf_arr = a.sc3b_nlev * a.sc3b_nvar; g.fidx = r.var * a.sc3b_nlev + r.lev; }
+    g.mode = GM_PLAIN;
+    gin.push_back(g);
+    gcount++;
+  }
+  // batches: atoms {u_i, v_i} and {scalar_j}
+  const int natoms = nuv + nsc;
+  const int cap = pick_batch(P, 2 * nuv + nsc);
+  std::vector<std::vector<int>> batches;  // Fourier field indices
+  {
+    std::vector<int> cur;
+    for (int at = 0; at < natoms; at++) {
+      int need = at < nuv ? 2 : 1;
+      if (!cur.empty() && (int)cur.size() + need > cap) {
+        batches.push_back(cur);
+        cur.clear();
+      }
+      if (at < nuv) { cur.push_back(at); cur.push_back(nuv + at); }
+      else cur.push_back(2 * nuv + (at - nuv));
+    }
+    if (!cur.empty()) batches.push_back(cur);
+  }
+  int maxb = 0;
+  for (auto &b : batches) maxb = std::max(maxb, (int)b.size());
+  const int bfpad = roundup(maxb, 64);
+  if (ensure_work(P, bfpad)) return EMI_ERR_RUNTIME;
+  const int ldw = 2 * bfpad;
+  PhaseTimer pt(G.profile, st);
+  double ms[3] = {0, 0, 0};
+  for (auto &b : batches) {
+    std::vector<GridFld> bg;
+    std::vector<SpecDst> bo;
+    std::map<int, int> loc;
+    for (size_t i = 0; i < b.size(); i++) {
+      loc[b[i]] = (int)i;
+      bg.push_back(gin[b[i]]);
+    }
+    for (size_t i = 0; i < b.size(); i++) {
+      int f = b[i];
+      if (f < nuv) {  // u_i -> vor_i and div_i outputs
+        SpecDst v{};
+        v.dst = d_vor; v.stride = a.nf_uv; v.idx = f; v.kind = SPO_VOR; v.src0 = loc[f]; v.src1 = loc[nuv + f];
+        bo.push_back(v);
+        v.dst = d_div; v.kind = SPO_DIV;
+        bo.push_back(v);
+      } else if (f >= 2 * nuv) {
+        const ScalarRef &r = sc[f - 2 * nuv];
+        SpecDst s{};
+        s.kind = SPO_COPY; s.src0 = (int)i;
+        switch (r.arr) {
+          case 0: s.dst = d_sc[0]; s.stride = a.nf_scalar; s.idx = r.lev; break;
+          case 1: s.dst = d_sc[1]; s.stride = a.nf_sc2; s.idx = r.lev; break;
+          case 2: s.dst = d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev; s.stride = a.sc3a_nlev; s.idx = r.lev; break;
+          default: s.dst = d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev; s.stride = a.sc3b_nlev; s.idx = r.lev; break;
+        }
+        bo.push_back(s);
+      }
+    }
+    size_t off_o = (bg.size() * sizeof(GridFld) + 255) / 256 * 256;
+    size_t bytes = off_o + bo.size() * sizeof(SpecDst);
+    if (ensure_desc(P, bytes)) return EMI_ERR_RUNTIME;
+    emi_stream_sync(st);
+    emi_h2d(P.d_desc, bg.data(), bg.size() * sizeof(GridFld), st);
+    emi_h2d((char *)P.d_desc + off_o, bo.data(), bo.size() * sizeof(SpecDst), st);
+    emi_stream_sync(st);
+    if (fft_prefix(P, (int)bg.size())) return EMI_ERR_RUNTIME;
+    const GridFld *d_bg = (const GridFld *)P.d_desc;
+    const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + off_o);
+    pt.n = 0;
+    pt.mark();
+    launch_fft(P, false, d_bg, (int)bg.size(), P.d_FB, ldw, nproma, st);
+    pt.mark();
+    {
+      const int nct = ldw / LG_BN;
+      long long ntiles = (long long)P.ktile_pref[P.nsmax + 1] * nct;
+      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_FB, ldw, P.d_W, ldw, ntiles);
+    }
+    pt.mark();
+    {
+      long long total = (long long)P.wrows_total * (long long)bo.size();
+      long long nblk = (total + 255) / 256;
+      EMI_LAUNCH(k_postpack_dir, nblk, 256, 0, st, P.g, d_bo, (int)bo.size(), (const double *)P.d_W, ldw, (long long)P.wrows_total);
+    }
+    pt.mark();
+    if (pt.on) {
+      emi_stream_sync(st);
+      ms[2] += pt.between(0, 1);
+      ms[1] += pt.between(1, 2);
+      ms[0] += pt.between(2, 3);
+    }
+  }
+  if (G.profile)
+    for (int i = 0; i < 3; i++) G.phase_ms[i] = ms[i];
+  if (host) hs.flush(st);
+#ifndef EMI_CPU_EMU
+  EMI_CHECK(hipGetLastError());
+#endif
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: unknown resolution %d", kresol);
+  if (!spec || nfld <= 0 || !norms) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
+  Plan &P = *Pp;
+  HostStage hs;
+  const double *d_sp = hs.in(spec, (size_t)P.nspec2 * nfld, mem_space == EMI_MEM_HOST, 0);
+  void *d_out = nullptr;
+  if (emi_dev_malloc(&d_out, (size_t)nfld * 8)) return EMI_ERR_RUNTIME;
+  EMI_LAUNCH(k_specnorm, nfld, 256, 256 * 8, (emi_stream_t)0, P.g, d_sp, nfld, (double *)d_out);
+  emi_d2h(norms, d_out, (size_t)nfld * 8, 0);
+  emi_stream_sync(0);
+  emi_dev_free(d_out);
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_work_model(int kresol, int nfields, double *leg, double *fft, double *fbytes) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "emi_work_model: unknown resolution %d", kresol);
+  Plan &P = *Pp;
+  // LT flops/direction = KF * sum_m 2*NDGLU(m)*(N-m+2)*c_m, c_0=1, c_{m>0}=2
+  double s = 0.0;
+  for (int m = 0; m <= P.nsmax; m++)
+    s += 2.0 * std::min(P.ndgnh, P.ndglu[m]) * (double)(P.nsmax - m + 2) * (m == 0 ? 1.0 : 2.0);
+  if (leg) *leg = s * nfields;
+  double f = 0.0;
+  for (int j = 0; j < P.ndgl; j++) f += 2.5 * P.nloen[j] * std::log2((double)std::max(2, P.nloen[j]));
+  if (fft) *fft = f * nfields;
+  if (fbytes) *fbytes = (double)P.frows * 16.0 * nfields;
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_last_phase_ms(double *ms3) {
+  for (int i = 0; i < 3; i++) ms3[i] = G.phase_ms[i];
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_set_max_batch(int max_fields) {
+  G.max_batch = max_fields;
+  return EMI_SUCCESS;
+}

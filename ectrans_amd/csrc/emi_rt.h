@@ -1,0 +1,134 @@
+// emi_rt.h -- thin device-runtime layer for the ectrans-mi kernels.
+//
+// Product build (hipcc, gfx950): everything maps 1:1 onto HIP.
+//
+// EMI_CPU_EMU build (g++ -fopenmp): a *functional emulator* used only by the CPU test-suite
+// (tests/emu): one OS thread per lane, `#pragma omp barrier` for __syncthreads and an
+// emulated v_mfma_f64_16x16x4_f64.  It exists so that kernel index logic can be debugged
+// in a container without a GPU.  It is never loaded by the product API (ectrans_amd/*.py
+// only opens libectrans_mi.so, the HIP build) and is not a fallback path.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifndef EMI_CPU_EMU
+#include <hip/hip_runtime.h>
+
+#define EMI_KERNEL __global__
+#define EMI_KERNEL_LB(T) __global__ __launch_bounds__(T)
+#define EMI_DEVFN __device__ __forceinline__
+#define EMI_TID ((int)threadIdx.x)
+#define EMI_BID ((int)blockIdx.x)
+#define EMI_NTHREADS ((int)blockDim.x)
+#define EMI_SYNC() __syncthreads()
+#define EMI_LDS_DECL extern __shared__ __attribute__((aligned(16))) char emi_lds_raw[]
+#define EMI_LDS_PTR (emi_lds_raw)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(16))) d2 {
+  double x, y;
+};
+
+EMI_DEVFN v4d emi_mfma_f64_16x16x4(double a, double b, v4d c) {
+  // v_mfma_f64_16x16x4_f64: A[row=l&15][k=l>>4], B[k=l>>4][col=l&15],
+  // C/D: col=l&15, row=(l>>4)+4*i  (cdna_hip_programming.md §3)
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+typedef hipStream_t emi_stream_t;
+
+#define EMI_CHECK(expr)                                                                 \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      emi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -1;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+#define EMI_LAUNCH(kernel, grid, block, lds, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(lds), (stream), __VA_ARGS__)
+
+#else  // ------------------------------- CPU functional emulator ----------------------------
+#include <omp.h>
+#include <vector>
+
+#define EMI_KERNEL
+#define EMI_KERNEL_LB(T)
+#define EMI_DEVFN inline
+struct EmuCtx {
+  int tid, bid, nthreads;
+  char *lds;
+  double *sa, *sb;  // mfma exchange scratch [nwaves][64]
+};
+extern thread_local EmuCtx *emu_ctx;
+#define EMI_TID (emu_ctx->tid)
+#define EMI_BID (emu_ctx->bid)
+#define EMI_NTHREADS (emu_ctx->nthreads)
+static inline void emu_barrier() {
+#pragma omp barrier
+}
+#define EMI_SYNC() emu_barrier()
+#define EMI_LDS_DECL
+#define EMI_LDS_PTR (emu_ctx->lds)
+
+typedef double v4d __attribute__((vector_size(32)));
+struct __attribute__((aligned(16))) d2 {
+  double x, y;
+};
+
+inline v4d emi_mfma_f64_16x16x4(double a, double b, v4d c) {
+  EmuCtx *x = emu_ctx;
+  int w = x->tid >> 6, l = x->tid & 63;
+  x->sa[w * 64 + l] = a;
+  x->sb[w * 64 + l] = b;
+#pragma omp barrier
+  for (int i = 0; i < 4; i++) {
+    int row = (l >> 4) + 4 * i, col = l & 15;
+    double s = c[i];
+    for (int k = 0; k < 4; k++) s += x->sa[w * 64 + k * 16 + row] * x->sb[w * 64 + k * 16 + col];
+    c[i] = s;
+  }
+#pragma omp barrier
+  return c;
+}
+
+typedef void *emi_stream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+
+template <class F, class... A>
+static void emu_launch(F f, long grid, int block, size_t lds, A... a) {
+  std::vector<char> sh(lds + 64);
+  std::vector<double> sa((block / 64 + 1) * 64), sb((block / 64 + 1) * 64);
+  char *ldsp = (char *)(((uintptr_t)sh.data() + 15) & ~(uintptr_t)15);
+  for (long b = 0; b < grid; b++) {
+#pragma omp parallel num_threads(block)
+    {
+      EmuCtx c{omp_get_thread_num(), (int)b, block, ldsp, sa.data(), sb.data()};
+      emu_ctx = &c;
+      f(a...);
+    }
+  }
+}
+#define EMI_LAUNCH(kernel, grid, block, lds, stream, ...) emu_launch(kernel, (long)(grid), (int)(block), (size_t)(lds), __VA_ARGS__)
+#define EMI_CHECK(expr) \
+  do {                  \
+    (void)(expr);       \
+  } while (0)
+#endif
+
+void emi_set_error(const char *fmt, ...);
+
+// ---- memory / stream helpers (same signatures in both builds) -------------------------
+int emi_dev_malloc(void **p, size_t bytes);
+int emi_dev_free(void *p);
+int emi_dev_memset(void *p, int v, size_t bytes, emi_stream_t s);
+int emi_h2d(void *dst, const void *src, size_t bytes, emi_stream_t s);
+int emi_d2h(void *dst, const void *src, size_t bytes, emi_stream_t s);
+int emi_d2d(void *dst, const void *src, size_t bytes, emi_stream_t s);
+int emi_stream_sync(emi_stream_t s);
+int emi_mem_info(size_t *free_b, size_t *total_b);

@@ -1,0 +1,152 @@
+/*
+ * ectrans_mi.h -- C-ABI of the MI355X-native spherical-harmonic transform (libectrans_mi.so).
+ *
+ * This is the drop-in boundary for the hot path SETUP_TRANS -> INV_TRANS / DIR_TRANS of
+ * ecTrans 1.7.0.  Every entry point names the reference interface it replaces
+ * (paths relative to /root/reference/src).  The Fortran shim (ectrans_amd/fortran) and the
+ * transi-compatible C layer (ectrans_amd/transi) bind to exactly these symbols; see
+ * INTEGRATION.md for the reference-side stubs.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no C++ / torch types; all functions return 0 on success and a
+ *    negative code on error, with the text available from emi_last_error().  (The reference
+ *    aborts the process through ABORT_TRANS, trans/common/internal/abort_trans_mod.F90:13-37;
+ *    the Fortran shim turns a negative code into the same abort.)
+ *  - array layouts are the Fortran ones, column-major:
+ *      spectral  PSPEC(nfld, nspec2)               -> p[ispec*nfld + f]
+ *      3-D spec  PSPSC3A(nlev, nspec2, nvar)       -> p[(v*nspec2 + ispec)*nlev + l]
+ *      grid      PGP(nproma, nfld, ngpblks)        -> p[(blk*nfld + f)*nproma + i]
+ *      grid 4-D  PGPUV(nproma, nlev, nvar, ngpblks)-> p[((blk*nvar + v)*nlev + l)*nproma + i]
+ *  - pointers are HOST pointers when mem_space == EMI_MEM_HOST (staged over PCIe, the
+ *    behaviour a Fortran/C caller of the reference expects) and DEVICE (HBM) pointers when
+ *    mem_space == EMI_MEM_DEVICE (zero-copy; what bench.py times).
+ *  - not thread-safe / not re-entrant, exactly like the reference (module-global state,
+ *    trans/cpu/internal/tpm_trans.F90:28-56).
+ */
+#ifndef ECTRANS_MI_H
+#define ECTRANS_MI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMI_MEM_HOST 0
+#define EMI_MEM_DEVICE 1
+
+#define EMI_SUCCESS 0
+#define EMI_ERR_ARG (-1)      /* what ABORT_TRANS would have reported about the arguments */
+#define EMI_ERR_STATE (-2)    /* setup order / unknown resolution handle */
+#define EMI_ERR_RUNTIME (-3)  /* HIP runtime failure */
+#define EMI_ERR_UNSUPPORTED (-4)
+
+/* ---- SETUP_TRANS0 (trans/common/external/setup_trans0.F90:13-229) ------------------- */
+typedef struct {
+  int kmax_resol;  /* KMAX_RESOL (default 1 when <= 0)                                    */
+  int kprintlev;   /* KPRINTLEV                                                           */
+  double prad;     /* PRAD, planet radius; <= 0 selects the reference default 6371229.0   */
+  int nproc;       /* number of ranks sharing the zonal-wavenumber/latitude distribution  */
+  int myproc;      /* 1-based rank (MYPROC)                                               */
+  int device;      /* HIP device ordinal, -1: keep current                                */
+} emi_init_t;
+int emi_init(const emi_init_t *cfg);
+
+/* ---- SETUP_TRANS (trans/cpu/external/setup_trans.F90:11-434) ------------------------ */
+typedef struct {
+  int ksmax;         /* KSMAX spectral truncation                                          */
+  int kdgl;          /* KDGL number of Gaussian latitudes (even)                           */
+  const int *kloen;  /* KLOEN(kdgl) points per latitude, NULL: full grid with 2*KDGL       */
+  int kdlon;         /* KDLON (used only when kloen == NULL and > 0)                       */
+  int precision;     /* 8: fp64 (the _dp library).  4 is reserved for the fp32 path        */
+  /* options the reference GPU backend also refuses (gpu/external/setup_trans.F90:309,442):
+   * a non-zero value returns EMI_ERR_UNSUPPORTED */
+  int lduseflt, ldll, ldstretch;
+} emi_setup_t;
+int emi_setup(const emi_setup_t *cfg, int *kresol);
+
+/* ---- TRANS_INQ (trans/cpu/external/trans_inq.F90:11-529), subset used by callers ----- */
+/* integer scalars: "nspec2" "nspec2g" "ngptot" "ngptotg" "nump" "ndgl" "nsmax" "ndglu"...  */
+int emi_inq_int(int kresol, const char *name, int *value);
+/* integer arrays: "nloen"(ndgl) "nmen"(ndgl) "ndglu"(nsmax+1) "nasm0"(nsmax+1, 1-based as
+ * D%NASM0) "myms"(nump)                                                                   */
+int emi_inq_int_array(int kresol, const char *name, int *out, int len);
+/* real arrays: "rmu"/"pmu"(ndgl) "rgw"/"pgw"(ndgl)                                        */
+int emi_inq_real_array(int kresol, const char *name, double *out, int len);
+/* Legendre panel of zonal wavenumber m as the reference stores it, S%FA(m)%RPNMA/RPNMS
+ * (trans/cpu/internal/suleg_mod.F90:609-615,891-897): column-major (ndglu x ncols), n
+ * descending.  out == NULL only returns the sizes.                                        */
+int emi_inq_legendre(int kresol, int m, int symmetric, double *out, int *nrows, int *ncols);
+
+/* ---- INV_TRANS (trans/include/ectrans/inv_trans.h:12-163) --------------------------- */
+typedef struct {
+  int mem_space;
+  /* spectral inputs (NULL = absent) */
+  const void *spvor, *spdiv;  /* PSPVOR/PSPDIV(nf_uv, nspec2)                              */
+  int nf_uv;
+  const void *spscalar;       /* PSPSCALAR(nf_scalar, nspec2)                              */
+  int nf_scalar;
+  const void *spsc3a;         /* PSPSC3A(sc3a_nlev, nspec2, sc3a_nvar)                     */
+  int sc3a_nlev, sc3a_nvar;
+  const void *spsc3b;
+  int sc3b_nlev, sc3b_nvar;
+  const void *spsc2;          /* PSPSC2(nf_sc2, nspec2)                                    */
+  int nf_sc2;
+  int ldscders, ldvorgp, lddivgp, lduvder; /* LDSCDERS, LDVORGP, LDDIVGP, LDUVDER          */
+  int kproma;                 /* KPROMA, <= 0: NGPTOT                                      */
+  /* grid outputs */
+  void *gp;                   /* PGP(nproma, gp_nfld, ngpblks)                             */
+  int gp_nfld;                /* second extent of PGP (>= IF_GP)                           */
+  void *gpuv;                 /* PGPUV(nproma, nf_uv, nvar_uv, ngpblks)                    */
+  void *gp3a, *gp3b;          /* PGP3A(nproma, nlev, nvar[*3], ngpblks)                    */
+  void *gp2;                  /* PGP2(nproma, nf_sc2[*3], ngpblks)                         */
+  void *stream;               /* hipStream_t, NULL: default stream                         */
+} emi_invtrans_t;
+int emi_inv_trans(int kresol, const emi_invtrans_t *args);
+
+/* ---- DIR_TRANS (trans/include/ectrans/dir_trans.h:12-140) --------------------------- */
+typedef struct {
+  int mem_space;
+  void *spvor, *spdiv;
+  int nf_uv;
+  void *spscalar;
+  int nf_scalar;
+  void *spsc3a;
+  int sc3a_nlev, sc3a_nvar;
+  void *spsc3b;
+  int sc3b_nlev, sc3b_nvar;
+  void *spsc2;
+  int nf_sc2;
+  int kproma;
+  const void *gp;    /* PGP(nproma, gp_nfld, ngpblks): u(nf_uv) v(nf_uv) scalars           */
+  int gp_nfld;
+  const void *gpuv;  /* PGPUV(nproma, nf_uv, 2, ngpblks)                                   */
+  const void *gp3a, *gp3b, *gp2;
+  void *stream;
+} emi_dirtrans_t;
+int emi_dir_trans(int kresol, const emi_dirtrans_t *args);
+
+/* ---- SPECNORM (trans/include/ectrans/specnorm.h:12) --------------------------------- */
+int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms /* host */);
+
+/* ---- TRANS_RELEASE / TRANS_END (trans/cpu/external/trans_release.F90, trans_end.F90) -- */
+int emi_release(int kresol);
+int emi_finalize(void);
+
+const char *emi_last_error(void);
+
+/* ---- measurement hooks (no reference counterpart; used by bench.py / profiles) -------- */
+/* Algorithmic work of one call on this resolution: Legendre flops and Fourier/grid bytes
+ * for `nfields` Fourier-space fields.                                      */
+int emi_work_model(int kresol, int nfields, double *legendre_flops_per_direction,
+                   double *fft_flops_per_direction, double *fourier_bytes_per_direction);
+/* Per-phase device time (ms) of the last emi_inv_trans/emi_dir_trans call when
+ * EMI_PROFILE=1: [0] pack/unpack spectral, [1] Legendre MFMA, [2] FFT.  Returns 0.        */
+int emi_last_phase_ms(double *ms3);
+/* Per-launch average duration of the dominant kernel (Legendre MFMA) over the last call.  */
+int emi_set_max_batch(int max_fields);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
