@@ -93,6 +93,8 @@ def _bind(L):
     L.emi_work_model.argtypes = [C.c_int, C.c_int, dp, dp, dp]
     L.emi_last_phase_ms.argtypes = [dp]
     L.emi_set_max_batch.argtypes = [C.c_int]
+    L.emi_set_profile.argtypes = [C.c_int]
+    L.emi_last_phase_launches.argtypes = [ip]
     return L
 
 
@@ -300,6 +302,22 @@ def work_model(kresol, nfields):
 
 
 def last_phase_ms():
+    """Device time (ms) of the last inv_trans/dir_trans call per phase
+    [spectral pack/unpack, Legendre MFMA kernel, FFT kernels] -- needs set_profile(True)."""
     out = (C.c_double * 3)()
     lib().emi_last_phase_ms(out)
     return list(out)
+
+
+def last_phase_launches():
+    out = (C.c_int * 3)()
+    lib().emi_last_phase_launches(out)
+    return list(out)
+
+
+def set_profile(on):
+    lib().emi_set_profile(int(bool(on)))
+
+
+def set_max_batch(n):
+    lib().emi_set_max_batch(int(n))

@@ -721,36 +721,53 @@ static int pick_batch(Plan &P, int nfields) {
   return (nfields + nb - 1) / nb;
 }
 
+// Per-phase device timing with HIP events recorded on the call's stream.  Nothing is
+// synchronised inside a transform call; emi_last_phase_ms() resolves the events lazily.
 struct PhaseTimer {
-#ifndef EMI_CPU_EMU
-  hipEvent_t ev[8];
+  static const int MAXEV = 4 * 64;
   int n = 0;
-  bool on;
-  emi_stream_t s;
-  PhaseTimer(bool on_, emi_stream_t s_) : on(on_), s(s_) {
-    if (on)
-      for (auto &e : ev) hipEventCreate(&e);
+  bool on = false;
+  int kinds[MAXEV];  // phase index of the interval ending at event i (-1: start marker)
+#ifndef EMI_CPU_EMU
+  hipEvent_t ev[MAXEV];
+  bool created = false;
+  emi_stream_t s = 0;
+  void begin(bool on_, emi_stream_t s_) {
+    on = on_;
+    s = s_;
+    n = 0;
+    if (on && !created) {
+      for (auto &e : ev) (void)hipEventCreate(&e);
+      created = true;
+    }
   }
-  void mark() {
-    if (on && n < 8) hipEventRecord(ev[n++], s);
+  void mark(int kind) {
+    if (on && n < MAXEV) {
+      kinds[n] = kind;
+      (void)hipEventRecord(ev[n++], s);
+    }
   }
-  float between(int a, int b) {
-    float ms = 0;
-    hipEventElapsedTime(&ms, ev[a], ev[b]);
-    return ms;
-  }
-  ~PhaseTimer() {
-    if (on)
-      for (auto &e : ev) hipEventDestroy(e);
+  void resolve(double *ms3, int *launches) {
+    for (int i = 0; i < 3; i++) ms3[i] = 0, launches[i] = 0;
+    if (!on || n == 0) return;
+    (void)hipEventSynchronize(ev[n - 1]);
+    for (int i = 1; i < n; i++)
+      if (kinds[i] >= 0) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+        ms3[kinds[i]] += ms;
+        launches[kinds[i]]++;
+      }
   }
 #else
-  PhaseTimer(bool, emi_stream_t) {}
-  void mark() {}
-  float between(int, int) { return 0; }
-  bool on = false;
-  int n = 0;
+  void begin(bool, emi_stream_t) {}
+  void mark(int) {}
+  void resolve(double *ms3, int *launches) {
+    for (int i = 0; i < 3; i++) ms3[i] = 0, launches[i] = 0;
+  }
 #endif
 };
+static PhaseTimer g_pt;
 
 static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, double *FB, int ldf, int nproma, emi_stream_t st) {
   for (int c = 0; c < 3; c++) {
@@ -930,8 +947,7 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
   const int bfpad = roundup(std::min(bsz, nlt), 64);
   if (ensure_work(P, bfpad)) return EMI_ERR_RUNTIME;
   const int ldw = 2 * bfpad;
-  PhaseTimer pt(G.profile, st);
-  double ms[3] = {0, 0, 0};
+  g_pt.begin(G.profile, st);
   for (int b0 = 0; b0 < nlt; b0 += bsz) {
     const int nb = std::min(bsz, nlt - b0);
     std::vector<SpecSrc> bl(lt.begin() + b0, lt.begin() + b0 + nb);
@@ -952,29 +968,22 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     if (fft_prefix(P, (int)bg.size())) return EMI_ERR_RUNTIME;
     const SpecSrc *d_bl = (const SpecSrc *)P.d_desc;
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + off_g);
-    pt.n = 0;
-    pt.mark();
+    g_pt.mark(-1);
     {
       long long total = (long long)P.wrows_total * bfpad;
       long long nblk = (total + 255) / 256;
       EMI_LAUNCH(k_prepack_inv, nblk, 256, 0, st, P.g, d_bl, nb, bfpad, P.d_W, ldw, (long long)P.wrows_total);
     }
-    pt.mark();
+    g_pt.mark(0);
     {
       const int nct = ldw / LG_BN;
       long long ntiles = (long long)P.lattile_pref[P.nsmax + 1] * nct;
       EMI_LAUNCH(k_leg_inv, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_W, ldw, P.d_FB, ldw, ntiles);
     }
-    pt.mark();
+    g_pt.mark(1);
     launch_fft(P, true, d_bg, (int)bg.size(), P.d_FB, ldw, nproma, st);
-    pt.mark();
-    if (pt.on) {
-      emi_stream_sync(st);
-      for (int i = 0; i < 3; i++) ms[i] += pt.between(i, i + 1);
-    }
+    g_pt.mark(2);
   }
-  if (G.profile)
-    for (int i = 0; i < 3; i++) G.phase_ms[i] = ms[i];
   if (host) hs.flush(st);
 #ifndef EMI_CPU_EMU
   EMI_CHECK(hipGetLastError());
@@ -1067,8 +1076,7 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   const int bfpad = roundup(maxb, 64);
   if (ensure_work(P, bfpad)) return EMI_ERR_RUNTIME;
   const int ldw = 2 * bfpad;
-  PhaseTimer pt(G.profile, st);
-  double ms[3] = {0, 0, 0};
+  g_pt.begin(G.profile, st);
   for (auto &b : batches) {
     std::vector<GridFld> bg;
     std::vector<SpecDst> bo;
@@ -1108,31 +1116,22 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     if (fft_prefix(P, (int)bg.size())) return EMI_ERR_RUNTIME;
     const GridFld *d_bg = (const GridFld *)P.d_desc;
     const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + off_o);
-    pt.n = 0;
-    pt.mark();
+    g_pt.mark(-1);
     launch_fft(P, false, d_bg, (int)bg.size(), P.d_FB, ldw, nproma, st);
-    pt.mark();
+    g_pt.mark(2);
     {
       const int nct = ldw / LG_BN;
       long long ntiles = (long long)P.ktile_pref[P.nsmax + 1] * nct;
       EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_FB, ldw, P.d_W, ldw, ntiles);
     }
-    pt.mark();
+    g_pt.mark(1);
     {
       long long total = (long long)P.wrows_total * (long long)bo.size();
       long long nblk = (total + 255) / 256;
       EMI_LAUNCH(k_postpack_dir, nblk, 256, 0, st, P.g, d_bo, (int)bo.size(), (const double *)P.d_W, ldw, (long long)P.wrows_total);
     }
-    pt.mark();
-    if (pt.on) {
-      emi_stream_sync(st);
-      ms[2] += pt.between(0, 1);
-      ms[1] += pt.between(1, 2);
-      ms[0] += pt.between(2, 3);
-    }
+    g_pt.mark(0);
   }
-  if (G.profile)
-    for (int i = 0; i < 3; i++) G.phase_ms[i] = ms[i];
   if (host) hs.flush(st);
 #ifndef EMI_CPU_EMU
   EMI_CHECK(hipGetLastError());
@@ -1173,7 +1172,19 @@ extern "C" int emi_work_model(int kresol, int nfields, double *leg, double *fft,
 }
 
 extern "C" int emi_last_phase_ms(double *ms3) {
-  for (int i = 0; i < 3; i++) ms3[i] = G.phase_ms[i];
+  int l[3];
+  g_pt.resolve(ms3, l);
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_last_phase_launches(int *l3) {
+  double ms[3];
+  g_pt.resolve(ms, l3);
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_set_profile(int on) {
+  G.profile = on != 0;
   return EMI_SUCCESS;
 }
 

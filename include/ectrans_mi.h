@@ -143,7 +143,11 @@ int emi_work_model(int kresol, int nfields, double *legendre_flops_per_direction
 /* Per-phase device time (ms) of the last emi_inv_trans/emi_dir_trans call when
  * EMI_PROFILE=1: [0] pack/unpack spectral, [1] Legendre MFMA, [2] FFT.  Returns 0.        */
 int emi_last_phase_ms(double *ms3);
-/* Per-launch average duration of the dominant kernel (Legendre MFMA) over the last call.  */
+/* Number of Legendre/FFT/pack phase intervals (one per field batch) behind those sums.      */
+int emi_last_phase_launches(int *l3);
+/* Switch the HIP-event phase timers on/off (default: env EMI_PROFILE).                      */
+int emi_set_profile(int on);
+/* Upper bound on Fourier-space fields per batch (0: from free HBM).                         */
 int emi_set_max_batch(int max_fields);
 
 #ifdef __cplusplus

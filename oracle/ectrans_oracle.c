@@ -878,20 +878,32 @@ static void ltinv(const orc_trans *t, int km, int kf_uv, int kf_scalars, int kf_
   int iskip = (km == 0) ? 2 : 1;
   const double *pia = COL(ista);
   const double *rpa = t->rpnma[km], *rps = t->rpnms[km];
+  double *zca = xcalloc(idglu > 0 ? idglu : 1, 8), *zcs = xcalloc(idglu > 0 ? idglu : 1, 8);
   for (int jk = 1; jk <= ifc; jk++) {
     int active = ((jk - 1) % iskip) == 0; /* m=0: imaginary columns are zero */
-    for (int ji = 1; ji <= idglu; ji++) {
-      double za = 0.0, zs = 0.0;
-      if (active) {
-        for (int j = 1; j <= ila; j++) za += rpa[(size_t)(j - 1) * idglu + (ji - 1)] * A2(pia, nlei1, ia + 1 + (j - 1) * 2, jk);
-        for (int j = 1; j <= ils; j++) zs += rps[(size_t)(j - 1) * idglu + (ji - 1)] * A2(pia, nlei1, is + 1 + (j - 1) * 2, jk);
+    for (int ji = 0; ji < idglu; ji++) zca[ji] = zcs[ji] = 0.0;
+    if (active) {
+      /* DGEMM('N','N') restated column by column: for every output latitude the sum still
+       * runs over j = 1..ILA in ascending order (axpy form keeps the panel access contiguous) */
+      for (int j = 1; j <= ila; j++) {
+        double b = A2(pia, nlei1, ia + 1 + (j - 1) * 2, jk);
+        const double *col = rpa + (size_t)(j - 1) * idglu;
+        for (int ji = 0; ji < idglu; ji++) zca[ji] += col[ji] * b;
       }
+      for (int j = 1; j <= ils; j++) {
+        double b = A2(pia, nlei1, is + 1 + (j - 1) * 2, jk);
+        const double *col = rps + (size_t)(j - 1) * idglu;
+        for (int ji = 0; ji < idglu; ji++) zcs[ji] += col[ji] * b;
+      }
+    }
+    for (int ji = 1; ji <= idglu; ji++) {
       int jgl = isl + ji - 1, igls = t->ndgl + 1 - jgl;
       /* ASRE1B: north = A+S, south = S-A */
-      FOUR(t, four, kf_out_lt, jgl, km, jk - 1) = za + zs;
-      FOUR(t, four, kf_out_lt, igls, km, jk - 1) = zs - za;
+      FOUR(t, four, kf_out_lt, jgl, km, jk - 1) = zca[ji - 1] + zcs[ji - 1];
+      FOUR(t, four, kf_out_lt, igls, km, jk - 1) = zcs[ji - 1] - zca[ji - 1];
     }
   }
+  free(zca), free(zcs);
   free(zia);
   free(zepsnm);
 #undef COL

@@ -1,0 +1,82 @@
+"""Shared helpers of the parity tests (oracle = checker, never the thing under test)."""
+import numpy as np
+
+
+def octahedral(nsmax):
+    h = nsmax + 1
+    return np.array([20 + 4 * i for i in range(h)] + [20 + 4 * i for i in reversed(range(h))], dtype=np.int32)
+
+
+def n_of_index(nasm0, nsmax, nspec2):
+    n_of = np.zeros(nspec2)
+    for m in range(nsmax + 1):
+        i0 = nasm0[m] - 1
+        n_of[i0:i0 + 2 * (nsmax - m + 1)] = np.repeat(np.arange(m, nsmax + 1), 2)
+    return n_of
+
+
+def random_spectrum(rng, nasm0, nsmax, nspec2, nf, zero00):
+    """Dense case of SURVEY 8d: U(-0.5,0.5)/(n+1), imag(m=0)=0, (0,0)=0 for vor/div."""
+    sp = rng.uniform(-0.5, 0.5, (nspec2, nf)) / (n_of_index(nasm0, nsmax, nspec2)[:, None] + 1.0)
+    sp[1:2 * (nsmax + 1):2] = 0.0
+    if zero00:
+        sp[0] = 0.0
+    return sp
+
+
+def rel_err(a, b, axis=None):
+    a, b = np.asarray(a), np.asarray(b)
+    if axis is None:
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    return (np.abs(a - b).max(axis=axis) / np.maximum(np.abs(b).max(axis=axis), 1e-300)).max()
+
+
+def block(g, nproma):
+    """(nfld, ngptot) -> (ngpblks, nfld, nproma) zero padded (PGP layout)."""
+    nf, ng = g.shape
+    nb = (ng - 1) // nproma + 1
+    out = np.zeros((nb, nf, nproma))
+    for b in range(nb):
+        w = min(nproma, ng - b * nproma)
+        out[b, :, :w] = g[:, b * nproma:b * nproma + w]
+    return out
+
+
+def unblock(gp, ngptot):
+    nb, nf, npr = gp.shape
+    return np.concatenate([gp[b] for b in range(nb)], axis=1)[:, :ngptot]
+
+
+def run_case(et, Oracle, xp, nsmax, nloen, nuv, nsc, flags=None, nproma=None, seed=1):
+    """inverse + direct through the C-ABI (`et`) against the oracle; returns (e_inv, e_dir).
+    xp(a) moves a numpy array to the memory space under test and back: (to, back)."""
+    flags = flags or {}
+    to, back = xp
+    nloen = np.asarray(nloen, dtype=np.int32)
+    r = et.setup_trans(nsmax, len(nloen), nloen)
+    try:
+        o = Oracle(nsmax, nloen)
+        rng = np.random.default_rng(seed)
+        vor = random_spectrum(rng, o.nasm0, nsmax, o.nspec2, nuv, True) if nuv else None
+        div = random_spectrum(rng, o.nasm0, nsmax, o.nspec2, nuv, True) if nuv else None
+        sc = random_spectrum(rng, o.nasm0, nsmax, o.nspec2, nsc, False) if nsc else None
+        gref = o.inv_trans(spvor=vor, spdiv=div, spsc=sc, **flags)
+        ngp, ng = gref.shape
+        npr = nproma or ng
+        gp = to(np.zeros(((ng - 1) // npr + 1, ngp, npr)))
+        kw = {k2: flags.get(k1, False) for k1, k2 in (("scders", "ldscders"), ("vorgp", "ldvorgp"),
+                                                      ("divgp", "lddivgp"), ("uvder", "lduvder"))}
+        et.inv_trans(r, pspvor=None if vor is None else to(vor), pspdiv=None if div is None else to(div),
+                     pspscalar=None if sc is None else to(sc), pgp=gp, kproma=npr, **kw)
+        e_inv = rel_err(unblock(back(gp), ng), gref, axis=1)
+        off = (nuv if flags.get("vorgp") else 0) + (nuv if (flags.get("divgp") or flags.get("vorgp")) else 0)
+        gdir = gref[off:off + 2 * nuv + nsc]
+        v2 = to(np.zeros_like(vor)) if nuv else None
+        d2 = to(np.zeros_like(div)) if nuv else None
+        s2 = to(np.zeros_like(sc)) if nsc else None
+        et.dir_trans(r, pspvor=v2, pspdiv=d2, pspscalar=s2, pgp=to(block(gdir, npr)), kproma=npr)
+        vr, dr, sr = o.dir_trans(gdir, nuv=nuv, nsc=nsc)
+        e_dir = max(rel_err(back(a), b) for a, b in ((v2, vr), (d2, dr), (s2, sr)) if b is not None)
+        return e_inv, e_dir
+    finally:
+        et.trans_release(r)

@@ -1,0 +1,121 @@
+"""CPU-side debugging aid: the HIP kernels compiled for the thread-per-lane functional emulator
+(tests/emu, see ectrans_amd/csrc/emi_rt.h) against the oracle on tiny cases.  This validates the
+host logic (field tables, batching, index tables, FFT plans) and the kernel index arithmetic without
+a GPU; the GPU parity tests proper are tests/test_gpu_parity.py."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests.common import octahedral, run_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-12  # fp64: observed ~1e-15
+
+
+@pytest.fixture(scope="module")
+def et():
+    os.environ.setdefault("OMP_NUM_THREADS", "256")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    import ectrans_amd
+    ectrans_amd._use_library_for_tests(os.path.join(ROOT, "tests", "emu", "libectrans_mi_emu.so"))
+    ectrans_amd.setup_trans0(kmax_resol=4)
+    yield ectrans_amd
+    ectrans_amd.trans_end()
+    ectrans_amd._L = None
+
+
+XP = (lambda a: a, lambda a: a)
+H = 9
+SMOOTH = [20 + 4 * i for i in range(H)]
+CASES = {
+    "octahedral_winds": (8, SMOOTH + SMOOTH[::-1], 1, 2, {}, None),
+    "bluestein_even": (8, [22, 26, 28, 30, 34, 38, 46, 58, 62] + [22, 26, 28, 30, 34, 38, 46, 58, 62][::-1], 1, 1, {}, None),
+    "odd_lengths": (8, [19, 21, 23, 25, 27, 29, 33, 35, 37] + [19, 21, 23, 25, 27, 29, 33, 35, 37][::-1], 0, 2, {}, None),
+    "derivatives": (8, SMOOTH + SMOOTH[::-1], 1, 1, dict(scders=True, vorgp=True, divgp=True, uvder=True), None),
+    "nproma_blocks": (8, SMOOTH + SMOOTH[::-1], 1, 1, dict(scders=True), 37),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_emulated_kernels_match_oracle(et, name):
+    nsmax, nloen, nuv, nsc, flags, nproma = CASES[name]
+    e_inv, e_dir = run_case(et, Oracle, XP, nsmax, nloen, nuv, nsc, flags, nproma)
+    assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
+
+
+def test_setup_tables_match_oracle(et):
+    N = 15
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    o = Oracle(N, nloen)
+    assert np.array_equal(et.trans_inq(r, "nmen"), o.nmen)
+    assert np.array_equal(et.trans_inq(r, "ndglu"), o.ndglu)
+    assert np.array_equal(et.trans_inq(r, "nasm0"), o.nasm0)
+    assert np.abs(et.trans_inq(r, "rmu") - o.rmu).max() < 1e-15
+    assert np.abs(et.trans_inq(r, "rgw") - o.rw).max() < 1e-16
+    assert abs(et.trans_inq(r, "rgw").sum() - 1.0) < 1e-10  # test_ectrans4py.py:119-121
+    for m in (0, 1, 2, 7, N):
+        for sym in (False, True):
+            assert np.abs(et.legendre_panel(r, m, sym) - o.rpnm(m, sym)).max(initial=0.0) < 1e-14
+    assert (et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")) == (o.nspec2, o.ngptot)
+    et.trans_release(r)
+
+
+def test_call_mode_2_arrays_and_batches(et):
+    """PGPUV/PGP3A/PGP2 + PSPSC3A/PSPSC2 (ectrans-benchmark call mode 2) and field batching."""
+    N = 8
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    o = Oracle(N, nloen)
+    rng = np.random.default_rng(3)
+    from tests.common import random_spectrum
+    nlev, nvar = 2, 2
+    vor = random_spectrum(rng, o.nasm0, N, o.nspec2, nlev, True)
+    div = random_spectrum(rng, o.nasm0, N, o.nspec2, nlev, True)
+    sc3 = np.stack([random_spectrum(rng, o.nasm0, N, o.nspec2, nlev, False) for _ in range(nvar)])
+    sc2 = random_spectrum(rng, o.nasm0, N, o.nspec2, 1, False)
+    # oracle sees the flat scalar list in the reference order: sc2, then sc3a (var outer, level inner)
+    scflat = np.concatenate([sc2] + [sc3[v] for v in range(nvar)], axis=1)
+    gref = o.inv_trans(spvor=vor, spdiv=div, spsc=scflat)
+    ng = o.ngptot
+    gpuv, gp3a, gp2 = np.zeros((1, 2, nlev, ng)), np.zeros((1, nvar, nlev, ng)), np.zeros((1, 1, ng))
+    et.set_max_batch(0)
+    et.inv_trans(r, pspvor=vor, pspdiv=div, pspsc3a=sc3, pspsc2=sc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+    got = np.concatenate([gpuv[0].reshape(2 * nlev, ng), gp2[0], gp3a[0].reshape(nvar * nlev, ng)])
+    assert (np.abs(got - gref).max(axis=1) / np.abs(gref).max(axis=1)).max() < TOL
+    v2, d2, s3, s2 = np.zeros_like(vor), np.zeros_like(div), np.zeros_like(sc3), np.zeros_like(sc2)
+    et.dir_trans(r, pspvor=v2, pspdiv=d2, pspsc3a=s3, pspsc2=s2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+    vr, dr, sr = o.dir_trans(gref, nuv=nlev, nsc=1 + nvar * nlev)
+    got_sc = np.concatenate([s2] + [s3[v] for v in range(nvar)], axis=1)
+    for a, b in ((v2, vr), (d2, dr), (got_sc, sr)):
+        assert np.abs(a - b).max() / np.abs(b).max() < TOL
+    et.trans_release(r)
+
+
+def test_argument_errors_mirror_abort_trans(et):
+    N = 8
+    nloen = octahedral(N)
+    with pytest.raises(et.TransError, match="KDGL IS NOT A POSITIVE, EVEN NUMBER"):
+        et.setup_trans(N, 17, nloen[:17])
+    with pytest.raises(et.TransError, match="KLOEN INVALID"):
+        bad = nloen.copy()
+        bad[3] = 0
+        et.setup_trans(N, len(bad), bad)
+    with pytest.raises(et.TransError, match="LDUSEFLT"):
+        et.setup_trans(N, len(nloen), nloen, lduseflt=True)
+    r = et.setup_trans(N, len(nloen), nloen)
+    ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+    with pytest.raises(et.TransError, match="SECOND DIMENSION OF PGP TOO SMALL"):
+        et.inv_trans(r, pspscalar=np.zeros((ns2, 3)), pgp=np.zeros((1, 2, ng)))
+    with pytest.raises(et.TransError, match="PGP AND PGPUV"):
+        et.inv_trans(r, pspscalar=np.zeros((ns2, 1)), pgp=np.zeros((1, 1, ng)), pgpuv=np.zeros((1, 1, 1, ng)))
+    with pytest.raises(et.TransError, match="BOTH PRESENT"):
+        et.inv_trans(r, pspscalar=np.zeros((ns2, 1)), pspsc2=np.zeros((ns2, 1)), pgp=np.zeros((1, 2, ng)))
+    with pytest.raises(et.TransError, match="unknown resolution"):
+        et.inv_trans(r + 1, pspscalar=np.zeros((ns2, 1)), pgp=np.zeros((1, 1, ng)))
+    et.trans_release(r)
+    with pytest.raises(et.TransError, match="unknown resolution"):
+        et.trans_inq(r, "nspec2")
