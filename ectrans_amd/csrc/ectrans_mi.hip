@@ -265,13 +265,14 @@ static int build_fft_plans(Plan &P) {
       });
       bhat.insert(bhat.end(), bh.begin(), bh.end());
     }
-    // fields per workgroup: as many as fit ~32 KiB of LDS (power of two, <= 16)
-    size_t per_field = (size_t)pl.S * 16;
+    // fields per workgroup: as many as fit ~40 KiB of LDS (power of two, <= 16); longer rows get
+    // one field per workgroup and more threads (512 / 1024) to keep the CU's SIMDs busy
+    size_t per_field = (size_t)FFT_LDS_ELEMS(pl.S) * 16;
     int fbk = 16;
-    while (fbk > 1 && fbk * per_field > 32768) fbk >>= 1;
+    while (fbk > 1 && fbk * per_field > 40960) fbk >>= 1;
     pl.fbk = fbk;
     size_t need = fbk * per_field;
-    pl.lds_class = need <= 32768 ? 0 : (need <= 65536 ? 1 : 2);
+    pl.lds_class = need <= 40960 ? 0 : (need <= 81920 ? 1 : 2);
     if (need > 160 * 1024) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d needs %zu B of LDS (> 160 KiB)", n, need);
     int id = (int)P.fplans.size();
     P.fplans.push_back(pl);
@@ -286,7 +287,7 @@ static int build_fft_plans(Plan &P) {
     const FftPlanDev &pl = P.fplans[P.planid[j]];
     FftClass &fc = P.fclass[pl.lds_class];
     fc.lats.push_back(j);
-    fc.lds = std::max(fc.lds, (size_t)pl.fbk * pl.S * 16);
+    fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 16);
   }
   d2 *d_tw, *d_rtw, *d_chirp, *d_bhat;
   uint16_t *d_perm;
@@ -773,11 +774,12 @@ static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, d
   for (int c = 0; c < 3; c++) {
     FftClass &fc = P.fclass[c];
     if (fc.lats.empty() || fc.nblocks == 0) continue;
-    FftLaunchDev lc{fc.d_lats, fc.d_pref, (int)fc.lats.size()};
+    FftLaunchDev lc{fc.d_lats, fc.d_pref, (int)fc.lats.size(), fc.nblocks};
+    const int nthr = c == 0 ? 256 : 512;
     if (inverse)
-      EMI_LAUNCH(k_fft_inv, fc.nblocks, FFT_THREADS, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma);
+      EMI_LAUNCH(k_fft_inv, fc.nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma);
     else
-      EMI_LAUNCH(k_fft_dir, fc.nblocks, FFT_THREADS, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, FB, ldf, nproma);
+      EMI_LAUNCH(k_fft_dir, fc.nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, FB, ldf, nproma);
   }
 }
 

@@ -105,12 +105,17 @@ EMI_DEVFN int upper_m(const int *pref, int nsmax, int t) {
   return lo;
 }
 
-// XCD-aware remap: consecutive logical tiles land on the same XCD (8 XCDs, round-robin
-// dispatch), so tiles that share a Legendre panel share an L2.  Bijective for any grid size.
-EMI_DEVFN long long xcd_swizzle(long long bid, long long nwg) {
-  long long q = nwg >> 3, r = nwg & 7, x = bid & 7, k = bid >> 3;
-  long long start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-  return start + k;
+// XCD-aware remap.  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels the XCD).
+// Logical tiles are cut into groups of G consecutive tiles (same Legendre panel / operand rows,
+// different column tiles); group g*8+x goes to XCD x, so (i) the tiles of a group share one L2 and
+// (ii) all XCDs walk through the m-ascending (longest-K-first) tile list at the same pace --
+// chunking the list contiguously per XCD would hand XCD 0 all the expensive low-m tiles.
+// Bijective for any grid size (the tail that does not fill 8 groups is mapped 1:1).
+EMI_DEVFN long long xcd_swizzle(long long bid, long long nwg, int G) {
+  const long long super = 8LL * G, nfull = (nwg / super) * super;
+  if (bid >= nfull) return bid;
+  const long long x = bid & 7, k = bid >> 3;
+  return ((k / G) * 8 + x) * G + (k % G);
 }
 
 // ==========================================================================================
@@ -237,75 +242,94 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
 // ---- inverse: FB[lat][m][col] = sum_n P[lat,n] W[m][n][col]; north = S+A, south = S-A
 // (leinv_mod.F90:92-186 DGEMM('N','N') x2, asre1b_mod.F90:83-102)
 // tile: 64 latitudes x 128 columns, both parities; wave (wm, wn) owns 32 lat x 64 col.
-EMI_KERNEL_LB(256) void k_leg_inv(EmiGeomDev g, int ncoltiles, const double *W, int ldw, double *FB, int ldf, long long ntiles) {
+EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, int ncoltiles, const double *W, int ldw, double *FB, int ldf, long long ntiles) {
   EMI_LDS_DECL;
   double *As = (double *)EMI_LDS_PTR;
   double *Bs = As + 2 * 8 * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int wm = w & 1, wn = w >> 1;
-  long long tile = xcd_swizzle(EMI_BID, ntiles);
+  long long tile = xcd_swizzle(EMI_BID, ntiles, ncoltiles);
   int ct = (int)(tile % ncoltiles);
   int t2 = (int)(tile / ncoltiles);
   const int m = upper_m(g.lattile_pref, g.nsmax, t2);
   const int lt = t2 - g.lattile_pref[m];
   const int ld = g.ldp[m];
-  const double *PS = g.P + g.offS[m], *PA = g.P + g.offA[m];
   const int lat0 = lt * 64, col0 = ct * LG_BN;
   const int nst = g.wrows[m] >> 4;
-  const long long wb = g.wbase[m];
 
   v4d acc[2][2][4];
+#pragma unroll
   for (int p = 0; p < 2; p++)
+#pragma unroll
     for (int i = 0; i < 2; i++)
+#pragma unroll
       for (int j = 0; j < 4; j++) acc[p][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+  // global -> register prefetch pointers (advance by one stage per iteration)
   const int arow = tid >> 5, ac2 = tid & 31;
-  d2 ra0, ra1, rb[4];
-  {
-    ra0 = *(const d2 *)(PS + (long long)(arow)*ld + lat0 + 2 * ac2);
-    ra1 = *(const d2 *)(PA + (long long)(arow)*ld + lat0 + 2 * ac2);
-    for (int i = 0; i < 4; i++) {
-      int idx = tid + 256 * i, brow = idx >> 6, bc2 = idx & 63;
-      rb[i] = *(const d2 *)(W + (wb + brow) * ldw + col0 + 2 * bc2);
-    }
-  }
+  const double *pS = g.P + g.offS[m] + (long long)arow * ld + lat0 + 2 * ac2;
+  const double *pA = g.P + g.offA[m] + (long long)arow * ld + lat0 + 2 * ac2;
+  const int brow = tid >> 6, bc2 = tid & 63;  // rows brow, brow+4, brow+8, brow+12 of the stage
+  const double *pW = W + ((long long)g.wbase[m] + brow) * ldw + col0 + 2 * bc2;
+  const long long stepA = 8LL * ld, stepW = 16LL * ldw, rowW4 = 4LL * ldw;
+  double *sA0 = As + (0 * 8 + arow) * LG_LDA + 2 * ac2;
+  double *sA1 = As + (1 * 8 + arow) * LG_LDA + 2 * ac2;
+  // W row r of the stage -> parity r&1, k = r>>1 ; r = brow + 4*i
+  double *sB0 = Bs + (((brow + 0) & 1) * 8 + ((brow + 0) >> 1)) * LG_LDB + 2 * bc2;
+  double *sB1 = Bs + (((brow + 4) & 1) * 8 + ((brow + 4) >> 1)) * LG_LDB + 2 * bc2;
+  double *sB2 = Bs + (((brow + 8) & 1) * 8 + ((brow + 8) >> 1)) * LG_LDB + 2 * bc2;
+  double *sB3 = Bs + (((brow + 12) & 1) * 8 + ((brow + 12) >> 1)) * LG_LDB + 2 * bc2;
+  d2 ra0 = *(const d2 *)pS, ra1 = *(const d2 *)pA;
+  d2 rb0 = *(const d2 *)pW, rb1 = *(const d2 *)(pW + rowW4), rb2 = *(const d2 *)(pW + 2 * rowW4), rb3 = *(const d2 *)(pW + 3 * rowW4);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
-    *(d2 *)(As + (0 * 8 + arow) * LG_LDA + 2 * ac2) = ra0;
-    *(d2 *)(As + (1 * 8 + arow) * LG_LDA + 2 * ac2) = ra1;
-    for (int i = 0; i < 4; i++) {
-      int idx = tid + 256 * i, brow = idx >> 6, bc2 = idx & 63;
-      *(d2 *)(Bs + ((brow & 1) * 8 + (brow >> 1)) * LG_LDB + 2 * bc2) = rb[i];
-    }
+    *(d2 *)sA0 = ra0;
+    *(d2 *)sA1 = ra1;
+    *(d2 *)sB0 = rb0;
+    *(d2 *)sB1 = rb1;
+    *(d2 *)sB2 = rb2;
+    *(d2 *)sB3 = rb3;
     EMI_SYNC();
     if (s + 1 < nst) {
-      ra0 = *(const d2 *)(PS + (long long)(8 * (s + 1) + arow) * ld + lat0 + 2 * ac2);
-      ra1 = *(const d2 *)(PA + (long long)(8 * (s + 1) + arow) * ld + lat0 + 2 * ac2);
-      for (int i = 0; i < 4; i++) {
-        int idx = tid + 256 * i, brow = idx >> 6, bc2 = idx & 63;
-        rb[i] = *(const d2 *)(W + (wb + 16 * (s + 1) + brow) * ldw + col0 + 2 * bc2);
-      }
+      pS += stepA;
+      pA += stepA;
+      pW += stepW;
+      ra0 = *(const d2 *)pS;
+      ra1 = *(const d2 *)pA;
+      rb0 = *(const d2 *)pW;
+      rb1 = *(const d2 *)(pW + rowW4);
+      rb2 = *(const d2 *)(pW + 2 * rowW4);
+      rb3 = *(const d2 *)(pW + 3 * rowW4);
     }
+#pragma unroll
     for (int p = 0; p < 2; p++)
+#pragma unroll
       for (int ks = 0; ks < 2; ks++) {
         const int kk = 4 * ks + (l >> 4);
         double a[2], b[4];
+#pragma unroll
         for (int i = 0; i < 2; i++) a[i] = As[(p * 8 + kk) * LG_LDA + wm * 32 + i * 16 + (l & 15)];
+#pragma unroll
         for (int j = 0; j < 4; j++) b[j] = Bs[(p * 8 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
+#pragma unroll
         for (int i = 0; i < 2; i++)
+#pragma unroll
           for (int j = 0; j < 4; j++) acc[p][i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[p][i][j]);
       }
   }
   // epilogue (ASRE1B): rows = latitudes
   const int ndglu = g.ndglu[m] < g.ndgnh ? g.ndglu[m] : g.ndgnh;
   const int isl0 = g.ndgnh - ndglu;  // 0-based first northern latitude with m <= NMEN
+#pragma unroll
   for (int i = 0; i < 2; i++)
+#pragma unroll
     for (int q = 0; q < 4; q++) {
       int j = lat0 + wm * 32 + i * 16 + (l >> 4) + 4 * q;
       if (j < ndglu) {
         int latn = isl0 + j, lats = g.ndgl - 1 - latn;
         double *pn = FB + ((long long)g.fbase[latn] + m) * ldf + col0 + wn * 64 + (l & 15);
         double *ps = FB + ((long long)g.fbase[lats] + m) * ldf + col0 + wn * 64 + (l & 15);
+#pragma unroll
         for (int jn = 0; jn < 4; jn++) {
           double sv = acc[0][i][jn][q], av = acc[1][i][jn][q];
           pn[jn * 16] = sv + av;
@@ -319,19 +343,18 @@ EMI_KERNEL_LB(256) void k_leg_inv(EmiGeomDev g, int ncoltiles, const double *W, 
 // (prfi2b_mod.F90:82-94, ledir_mod.F90:100-267 DGEMM('T','N') x2; Gaussian weights and
 //  1/(a cos) were folded into FB by k_fft_dir)
 // tile: 64 k (n-pairs) x 2 parities x 128 columns; wave (par, wn) owns 64 k x 64 col.
-EMI_KERNEL_LB(256) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double *FB, int ldf, double *W, int ldw, long long ntiles) {
+EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double *FB, int ldf, double *W, int ldw, long long ntiles) {
   EMI_LDS_DECL;
   double *As = (double *)EMI_LDS_PTR;
   double *Bs = As + 2 * 8 * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int par = w & 1, wn = w >> 1;
-  long long tile = xcd_swizzle(EMI_BID, ntiles);
+  long long tile = xcd_swizzle(EMI_BID, ntiles, ncoltiles);
   int ct = (int)(tile % ncoltiles);
   int t2 = (int)(tile / ncoltiles);
   const int m = upper_m(g.ktile_pref, g.nsmax, t2);
   const int kt = t2 - g.ktile_pref[m];
   const int ld = g.ldp[m];
-  const double *PS = g.P + g.offS[m], *PA = g.P + g.offA[m];
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int ndglu = g.ndglu[m] < g.ndgnh ? g.ndglu[m] : g.ndgnh;
@@ -340,30 +363,46 @@ EMI_KERNEL_LB(256) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double *FB,
   const long long wb = g.wbase[m];
 
   v4d acc[4][4];
+#pragma unroll
   for (int i = 0; i < 4; i++)
+#pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   const int arow = tid >> 2, ac2 = tid & 3;
   const bool aok = (k0 + arow) < nkpad;
-  d2 ra0, ra1, rn[2], rs[2];
-#define LEGDIR_LOAD(s_)                                                                         \
-  {                                                                                             \
-    ra0 = aok ? *(const d2 *)(PS + (long long)(k0 + arow) * ld + 8 * (s_) + 2 * ac2) : mk2(0, 0); \
-    ra1 = aok ? *(const d2 *)(PA + (long long)(k0 + arow) * ld + 8 * (s_) + 2 * ac2) : mk2(0, 0); \
-    for (int i = 0; i < 2; i++) {                                                               \
-      int idx = tid + 256 * i, brow = idx >> 6, bc2 = idx & 63;                                 \
-      int j = 8 * (s_) + brow;                                                                  \
-      if (j < ndglu) {                                                                          \
-        int latn = isl0 + j, lats = g.ndgl - 1 - latn;                                          \
-        rn[i] = *(const d2 *)(FB + ((long long)g.fbase[latn] + m) * ldf + col0 + 2 * bc2);      \
-        rs[i] = *(const d2 *)(FB + ((long long)g.fbase[lats] + m) * ldf + col0 + 2 * bc2);      \
-      } else {                                                                                  \
-        rn[i] = mk2(0, 0);                                                                      \
-        rs[i] = mk2(0, 0);                                                                      \
-      }                                                                                         \
-    }                                                                                           \
+  const double *pS = g.P + g.offS[m] + (long long)(k0 + arow) * ld + 2 * ac2;
+  const double *pA = g.P + g.offA[m] + (long long)(k0 + arow) * ld + 2 * ac2;
+  const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow and brow+4 of each 8-row stage
+  const double *FBc = FB + col0 + 2 * bc2;
+  d2 ra0, ra1, rn0, rn1, rs0, rs1;
+  // FB row numbers (fbase[lat]+m) are fetched one stage ahead of the FB loads that use them, so
+  // the two dependent global loads never sit in the same prefetch window.
+  long long in0, in1, is0, is1;
+#define LEGDIR_ROWS(s_)                                                            \
+  {                                                                                \
+    int j0_ = 8 * (s_) + brow, j1_ = j0_ + 4;                                      \
+    in0 = in1 = is0 = is1 = -1;                                                    \
+    if (j0_ < ndglu) {                                                             \
+      in0 = (long long)g.fbase[isl0 + j0_] + m;                                    \
+      is0 = (long long)g.fbase[g.ndgl - 1 - isl0 - j0_] + m;                       \
+    }                                                                              \
+    if (j1_ < ndglu) {                                                             \
+      in1 = (long long)g.fbase[isl0 + j1_] + m;                                    \
+      is1 = (long long)g.fbase[g.ndgl - 1 - isl0 - j1_] + m;                       \
+    }                                                                              \
   }
+#define LEGDIR_LOAD(s_)                                                            \
+  {                                                                                \
+    ra0 = aok ? *(const d2 *)(pS + 8 * (s_)) : mk2(0, 0);                          \
+    ra1 = aok ? *(const d2 *)(pA + 8 * (s_)) : mk2(0, 0);                          \
+    rn0 = in0 >= 0 ? *(const d2 *)(FBc + in0 * ldf) : mk2(0, 0);                   \
+    rs0 = is0 >= 0 ? *(const d2 *)(FBc + is0 * ldf) : mk2(0, 0);                   \
+    rn1 = in1 >= 0 ? *(const d2 *)(FBc + in1 * ldf) : mk2(0, 0);                   \
+    rs1 = is1 >= 0 ? *(const d2 *)(FBc + is1 * ldf) : mk2(0, 0);                   \
+  }
+  LEGDIR_ROWS(0);
   LEGDIR_LOAD(0);
+  LEGDIR_ROWS(1);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
     // transpose the P tile: As[par][kk = latitude in stage][k index]
@@ -371,46 +410,75 @@ EMI_KERNEL_LB(256) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double *FB,
     As[(0 * 8 + 2 * ac2 + 1) * LG_LDA + arow] = ra0.y;
     As[(1 * 8 + 2 * ac2) * LG_LDA + arow] = ra1.x;
     As[(1 * 8 + 2 * ac2 + 1) * LG_LDA + arow] = ra1.y;
-    for (int i = 0; i < 2; i++) {
-      int idx = tid + 256 * i, brow = idx >> 6, bc2 = idx & 63;
-      *(d2 *)(Bs + (0 * 8 + brow) * LG_LDB + 2 * bc2) = cadd(rn[i], rs[i]);  // symmetric part
-      *(d2 *)(Bs + (1 * 8 + brow) * LG_LDB + 2 * bc2) = csub(rn[i], rs[i]);  // antisymmetric part
-    }
+    *(d2 *)(Bs + (0 * 8 + brow) * LG_LDB + 2 * bc2) = cadd(rn0, rs0);      // symmetric part
+    *(d2 *)(Bs + (1 * 8 + brow) * LG_LDB + 2 * bc2) = csub(rn0, rs0);      // antisymmetric part
+    *(d2 *)(Bs + (0 * 8 + brow + 4) * LG_LDB + 2 * bc2) = cadd(rn1, rs1);
+    *(d2 *)(Bs + (1 * 8 + brow + 4) * LG_LDB + 2 * bc2) = csub(rn1, rs1);
     EMI_SYNC();
-    if (s + 1 < nst) LEGDIR_LOAD(s + 1);
+    if (s + 1 < nst) {
+      LEGDIR_LOAD(s + 1);
+      LEGDIR_ROWS(s + 2);
+    }
+#pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const int kk = 4 * ks + (l >> 4);
       double a[4], b[4];
+#pragma unroll
       for (int i = 0; i < 4; i++) a[i] = As[(par * 8 + kk) * LG_LDA + i * 16 + (l & 15)];
+#pragma unroll
       for (int j = 0; j < 4; j++) b[j] = Bs[(par * 8 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
+#pragma unroll
       for (int i = 0; i < 4; i++)
+#pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
     }
   }
+#undef LEGDIR_ROWS
 #undef LEGDIR_LOAD
+#pragma unroll
   for (int i = 0; i < 4; i++)
+#pragma unroll
     for (int q = 0; q < 4; q++) {
       int k = k0 + i * 16 + (l >> 4) + 4 * q;
       if (k < nkpad) {
         double *pw = W + (wb + 2 * k + par) * ldw + col0 + wn * 64 + (l & 15);
+#pragma unroll
         for (int jn = 0; jn < 4; jn++) pw[jn * 16] = acc[i][jn][q];
       }
     }
 }
 
 // ==========================================================================================
-// FFT engine in LDS: in-place mixed-radix Cooley-Tukey on `nfl` fields of S complex points.
+// FFT engine in LDS (v2): in-place mixed-radix Cooley-Tukey on `nfl` fields of S complex points.
 //   DIT: input at perm[] positions -> natural output.  DIF: natural input -> output at perm[].
-//   tw[k] = exp(-2 pi i k/S); sgn=+1 conjugates.  Radices 2,4 specialised; 3,5,7,11,13 via the
-//   generic small-prime butterfly (DFT matrix read from tw).
+//   tw[k] = exp(-2 pi i k/S); sgn=+1 conjugates.
+//   * radices 2,3,4,5,8,16 are hard-coded register butterflies; 7,11,13 use the DFT matrix from tw
+//   * the host orders the factors so that every pass stride (lenp) of a 2-3-5-smooth size is a power
+//     of two (odd radices last in DIT order) -> no integer divisions in those passes
+//   * logical element i lives at LDS slot FPAD(i) = i + (i >> 4): the pass whose butterflies are
+//     contiguous runs of R elements (stride R*16 B between lanes) becomes bank-conflict free
+//   * Bluestein: DIF passes -> [last DIF pass + pointwise filter + first DIT pass fused in
+//     registers] -> DIT passes; the final DIT pass of the inverse transform multiplies by the chirp
+//     and stores the real row straight to the user's grid array (no LDS round trip)
 // ==========================================================================================
-#define FFT_THREADS 256
-#define FFT_MAXR 13
+#define FFT_MAXR 16
+#define FPAD(i) ((i) + ((i) >> 4))
+#define FFT_LDS_ELEMS(S) ((S) + ((S) >> 4) + 1)
 
 EMI_DEVFN d2 tw_get(const d2 *tw, int idx, int sgn) {
   d2 t = tw[idx];
   if (sgn > 0) t.y = -t.y;
   return t;
+}
+// multiply by -i (forward, sgn<0) or +i (inverse)
+EMI_DEVFN d2 cmul_mi(d2 a, int sgn) { return (sgn < 0) ? mk2(a.y, -a.x) : mk2(-a.y, a.x); }
+
+EMI_DEVFN void bf4(d2 &x0, d2 &x1, d2 &x2, d2 &x3, int sgn) {
+  d2 a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = cmul_mi(csub(x1, x3), sgn);
+  x0 = cadd(a, c);
+  x1 = cadd(b, d);
+  x2 = csub(a, c);
+  x3 = csub(b, d);
 }
 
 template <int R>
@@ -420,13 +488,79 @@ EMI_DEVFN void butterfly(d2 *v, const d2 *tw, int S, int sgn) {
     v[0] = cadd(a, b);
     v[1] = csub(a, b);
   } else if (R == 4) {
-    d2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
-    // forward (sgn<0): W_4 = -i
-    d2 di = (sgn < 0) ? mk2(d.y, -d.x) : mk2(-d.y, d.x);
-    v[0] = cadd(a, c);
-    v[1] = cadd(b, di);
-    v[2] = csub(a, c);
-    v[3] = csub(b, di);
+    bf4(v[0], v[1], v[2], v[3], sgn);
+  } else if (R == 3) {
+    const double s60 = 0.86602540378443864676;
+    d2 t1 = cadd(v[1], v[2]);
+    d2 t2 = mk2(v[0].x - 0.5 * t1.x, v[0].y - 0.5 * t1.y);
+    d2 t3 = cscale(cmul_mi(csub(v[1], v[2]), sgn), s60);
+    v[0] = cadd(v[0], t1);
+    v[1] = cadd(t2, t3);
+    v[2] = csub(t2, t3);
+  } else if (R == 5) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+    d2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), d1 = csub(v[1], v[4]), d2_ = csub(v[2], v[3]);
+    d2 r1 = mk2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    d2 r2 = mk2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    d2 q1 = cmul_mi(mk2(s1 * d1.x + s2 * d2_.x, s1 * d1.y + s2 * d2_.y), sgn);
+    d2 q2 = cmul_mi(mk2(s2 * d1.x - s1 * d2_.x, s2 * d1.y - s1 * d2_.y), sgn);
+    v[0] = cadd(v[0], cadd(a1, a2));
+    v[1] = cadd(r1, q1);
+    v[4] = csub(r1, q1);
+    v[2] = cadd(r2, q2);
+    v[3] = csub(r2, q2);
+  } else if (R == 8) {
+    // n = 4 n1 + n2, k = k1 + 2 k2
+    const double h = 0.70710678118654752440;
+    d2 t0[4], t1[4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+      t0[n2] = cadd(v[n2], v[4 + n2]);
+      t1[n2] = csub(v[n2], v[4 + n2]);
+    }
+    // t1[n2] *= W8^{n2}
+    t1[1] = (sgn < 0) ? mk2(h * (t1[1].x + t1[1].y), h * (t1[1].y - t1[1].x)) : mk2(h * (t1[1].x - t1[1].y), h * (t1[1].y + t1[1].x));
+    t1[2] = cmul_mi(t1[2], sgn);
+    t1[3] = (sgn < 0) ? mk2(h * (t1[3].y - t1[3].x), -h * (t1[3].x + t1[3].y)) : mk2(-h * (t1[3].x + t1[3].y), h * (t1[3].x - t1[3].y));
+    bf4(t0[0], t0[1], t0[2], t0[3], sgn);
+    bf4(t1[0], t1[1], t1[2], t1[3], sgn);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) {
+      v[2 * k2] = t0[k2];
+      v[2 * k2 + 1] = t1[k2];
+    }
+  } else if (R == 16) {
+    // n = 4 n1 + n2, k = k1 + 4 k2
+    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+    d2 t[4][4];  // t[n2][k1]
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+      t[n2][0] = v[n2];
+      t[n2][1] = v[4 + n2];
+      t[n2][2] = v[8 + n2];
+      t[n2][3] = v[12 + n2];
+      bf4(t[n2][0], t[n2][1], t[n2][2], t[n2][3], sgn);
+    }
+    // t[n2][k1] *= W16^{n2 k1}; W16^k = cos(pi k/8) -+ i sin(pi k/8)
+    const double wc[10] = {1.0, c1, h, s1, 0.0, -s1, -h, -c1, -1.0, -c1};
+    const double ws[10] = {0.0, s1, h, c1, 1.0, c1, h, s1, 0.0, -s1};
+#pragma unroll
+    for (int n2 = 1; n2 < 4; n2++)
+#pragma unroll
+      for (int k1 = 1; k1 < 4; k1++) {
+        const int e = n2 * k1;
+        d2 w = mk2(wc[e], (sgn < 0) ? -ws[e] : ws[e]);
+        t[n2][k1] = cmul(t[n2][k1], w);
+      }
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+      bf4(t[0][k1], t[1][k1], t[2][k1], t[3][k1], sgn);
+      v[k1] = t[0][k1];
+      v[k1 + 4] = t[1][k1];
+      v[k1 + 8] = t[2][k1];
+      v[k1 + 12] = t[3][k1];
+    }
   } else {
     d2 y[R];
     const int st = S / R;
@@ -439,58 +573,131 @@ EMI_DEVFN void butterfly(d2 *v, const d2 *tw, int S, int sgn) {
   }
 }
 
+// split a butterfly number q into (block, j) for stride lenp (power of two when sh >= 0)
+EMI_DEVFN void split_q(int q, int lenp, int sh, int &blk, int &j) {
+  if (sh >= 0) {
+    blk = q >> sh;
+    j = q & (lenp - 1);
+  } else {
+    blk = q / lenp;
+    j = q - blk * lenp;
+  }
+}
+EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_clz((unsigned)v)); }
+
+// one in-place pass over nfl fields.  nvalid: logical elements >= nvalid read as zero (first DIF
+// pass of a zero-padded Bluestein input).
 template <int R, int DIF>
-EMI_DEVFN void fft_pass(d2 *a, int nfl, int S, int lenp, const d2 *tw, int sgn) {
-  const int len = lenp * R, nb = S / R, tst = S / len;
-  for (int idx = EMI_TID; idx < nfl * nb; idx += FFT_THREADS) {
-    int fld = idx / nb, q = idx - fld * nb;
-    int blk = q / lenp, j = q - blk * lenp;
-    d2 *p = a + (long long)fld * S + blk * len + j;
-    d2 v[R];
-    for (int t = 0; t < R; t++) v[t] = p[t * lenp];
-    if (!DIF && j > 0)
-      for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t * tst, sgn));
-    butterfly<R>(v, tw, S, sgn);
-    if (DIF && j > 0)
-      for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t * tst, sgn));
-    for (int t = 0; t < R; t++) p[t * lenp] = v[t];
+EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *tw, int sgn, int nvalid) {
+  const int len = lenp * R, nb = S / R, tst = S / len, sh = log2_exact(lenp);
+  for (int fl = 0; fl < nfl; fl++) {
+    d2 *af = a + (long long)fl * fstride;
+    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
+      int blk, j;
+      split_q(q, lenp, sh, blk, j);
+      const int base = blk * len + j;
+      d2 v[R];
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        const int i = base + t * lenp;
+        v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
+      }
+      if (!DIF && j > 0) {
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t * tst, sgn));
+      }
+      butterfly<R>(v, tw, S, sgn);
+      if (DIF && j > 0) {
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t * tst, sgn));
+      }
+#pragma unroll
+      for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
+    }
   }
 }
 
-template <int DIF>
-EMI_DEVFN void fft_run(d2 *a, int nfl, int S, const FftPlanDev &pl, const d2 *tw, int sgn) {
-  int lenp = DIF ? S : 1;
-  for (int ip = 0; ip < pl.nfac; ip++) {
-    const int r = DIF ? pl.fac[pl.nfac - 1 - ip] : pl.fac[ip];
-    if (DIF) lenp /= r;
-    switch (r) {
-      case 2: fft_pass<2, DIF>(a, nfl, S, lenp, tw, sgn); break;
-      case 3: fft_pass<3, DIF>(a, nfl, S, lenp, tw, sgn); break;
-      case 4: fft_pass<4, DIF>(a, nfl, S, lenp, tw, sgn); break;
-      case 5: fft_pass<5, DIF>(a, nfl, S, lenp, tw, sgn); break;
-      case 7: fft_pass<7, DIF>(a, nfl, S, lenp, tw, sgn); break;
-      case 11: fft_pass<11, DIF>(a, nfl, S, lenp, tw, sgn); break;
-      case 13: fft_pass<13, DIF>(a, nfl, S, lenp, tw, sgn); break;
-      default: break;
-    }
-    if (!DIF) lenp *= r;
+#define FFT_DISPATCH(FN, r, ...)                  \
+  switch (r) {                                    \
+    case 2: FN<2>(__VA_ARGS__); break;            \
+    case 3: FN<3>(__VA_ARGS__); break;            \
+    case 4: FN<4>(__VA_ARGS__); break;            \
+    case 5: FN<5>(__VA_ARGS__); break;            \
+    case 7: FN<7>(__VA_ARGS__); break;            \
+    case 8: FN<8>(__VA_ARGS__); break;            \
+    case 11: FN<11>(__VA_ARGS__); break;          \
+    case 13: FN<13>(__VA_ARGS__); break;          \
+    case 16: FN<16>(__VA_ARGS__); break;          \
+    default: break;                               \
+  }
+
+template <int R>
+EMI_DEVFN void pass_dit(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, int sgn, int nvalid) {
+  fft_pass<R, 0>(a, nfl, fs, S, lenp, tw, sgn, nvalid);
+}
+template <int R>
+EMI_DEVFN void pass_dif(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, int sgn, int nvalid) {
+  fft_pass<R, 1>(a, nfl, fs, S, lenp, tw, sgn, nvalid);
+}
+
+// DIT passes ip = first..last-1 (factor order); returns lenp after them
+EMI_DEVFN int run_dit(d2 *a, int nfl, int fs, int S, const int *fac, int first, int last, int lenp, const d2 *tw, int sgn) {
+  for (int ip = first; ip < last; ip++) {
+    const int r = fac[ip];
+    FFT_DISPATCH(pass_dit, r, a, nfl, fs, S, lenp, tw, sgn, S);
+    lenp *= r;
+    EMI_SYNC();
+  }
+  return lenp;
+}
+// DIF passes over factors nfac-1 down to `stop` (inclusive); nvalid applies to the first one
+EMI_DEVFN void run_dif(d2 *a, int nfl, int fs, int S, const int *fac, int nfac, int stop, const d2 *tw, int sgn, int nvalid) {
+  int lenp = S;
+  for (int ip = nfac - 1; ip >= stop; ip--) {
+    const int r = fac[ip];
+    lenp /= r;
+    FFT_DISPATCH(pass_dif, r, a, nfl, fs, S, lenp, tw, sgn, nvalid);
+    nvalid = S;
     EMI_SYNC();
   }
 }
 
-// Bluestein middle part: a (natural, zero padded to L) -> circular convolution with the chirp
-// filter -> natural.  conj_b selects the inverse-transform filter.
-EMI_DEVFN void blue_conv(d2 *a, int nfl, const FftPlanDev &pl, const FftTabDev &T, int conj_b) {
+// Bluestein middle: last DIF pass (radix fac[0], contiguous runs) * filter * first DIT pass
+template <int R>
+EMI_DEVFN void blue_middle(d2 *a, int nfl, int fs, int S, const d2 *tw, const d2 *bh, int conj_b, int nvalid) {
+  const int nb = S / R;
+  for (int fl = 0; fl < nfl; fl++) {
+    d2 *af = a + (long long)fl * fs;
+    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
+      const int base = q * R;
+      d2 v[R];
+#pragma unroll
+      for (int t = 0; t < R; t++) v[t] = (base + t < nvalid) ? af[FPAD(base + t)] : mk2(0.0, 0.0);
+      butterfly<R>(v, tw, S, -1);
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        d2 b = bh[base + t];
+        v[t] = conj_b ? cmulc(v[t], b) : cmul(v[t], b);
+      }
+      butterfly<R>(v, tw, S, +1);
+#pragma unroll
+      for (int t = 0; t < R; t++) af[FPAD(base + t)] = v[t];
+    }
+  }
+}
+
+// circular convolution with the chirp filter: a (natural, logically zero beyond nvalid) -> natural,
+// leaving the LAST DIT pass to the caller (returns its lenp) when defer_last != 0.
+EMI_DEVFN int blue_conv(d2 *a, int nfl, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid, int defer_last) {
   const int L = pl.S;
   const d2 *tw = T.tw + pl.tw_off, *bh = T.bhat + pl.bhat_off;
-  fft_run<1>(a, nfl, L, pl, tw, -1);
-  for (int idx = EMI_TID; idx < nfl * L; idx += FFT_THREADS) {
-    int pos = idx % L;
-    d2 b = bh[pos];
-    a[idx] = conj_b ? cmulc(a[idx], b) : cmul(a[idx], b);
-  }
+  run_dif(a, nfl, fs, L, pl.fac, pl.nfac, 1, tw, -1, nvalid);
+  const int r0 = pl.fac[0];
+  const int nv0 = (pl.nfac == 1) ? nvalid : L;
+  FFT_DISPATCH(blue_middle, r0, a, nfl, fs, L, tw, bh, conj_b, nv0);
   EMI_SYNC();
-  fft_run<0>(a, nfl, L, pl, tw, +1);
+  const int last = defer_last ? pl.nfac - 1 : pl.nfac;
+  return run_dit(a, nfl, fs, L, pl.fac, 1, last < 1 ? 1 : last, r0, tw, +1);
 }
 
 EMI_DEVFN long long grid_index(const GridFld &gf, long long p, int nproma) {
@@ -503,6 +710,7 @@ struct FftLaunchDev {
   const int *lats;      // latitudes of this LDS class
   const int *blk_pref;  // [nlat_class+1] prefix of chunks per latitude
   int nlat;
+  long long nblocks;
 };
 EMI_DEVFN int fft_find(const int *pref, int n, int b) {
   int lo = 0, hi = n - 1;
@@ -516,20 +724,83 @@ EMI_DEVFN int fft_find(const int *pref, int n, int b) {
   return lo;
 }
 
+// final DIT pass of the inverse real transform, stored straight to the grid array:
+// logical output z_i (i < sz): x_{2i} = Re, x_{2i+1} = Im (or x_i = Re z_i in complex mode),
+// Bluestein: z_i = a'_i * conj(chirp_i) / L.
+template <int R>
+EMI_DEVFN void dit_last_to_grid(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const FftPlanDev &pl, const d2 *chirp,
+                                const GridFld *flds, int f0, long long gp0, int nproma) {
+  const int nb = S / R, sh = log2_exact(lenp), sz = pl.sz;
+  const double invL = pl.blue ? 1.0 / (double)S : 1.0;
+  const bool contiguous = true;
+  (void)contiguous;
+  for (int fl = 0; fl < nfl; fl++) {
+    d2 *af = a + (long long)fl * fs;
+    const GridFld gf = flds[f0 + fl];
+    const bool flat = (nproma >= (int)0x7fffffff) ? true : false;
+    (void)flat;
+    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
+      int blk, j;
+      split_q(q, lenp, sh, blk, j);  // last pass: len == S, blk == 0
+      d2 v[R];
+#pragma unroll
+      for (int t = 0; t < R; t++) v[t] = af[FPAD(j + t * lenp)];
+      if (j > 0) {
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t, +1));
+      }
+      butterfly<R>(v, tw, S, +1);
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        const int i = j + t * lenp;
+        if (i < sz) {
+          d2 z = v[t];
+          if (pl.blue) z = cscale(cmulc(z, chirp[i]), invL);
+          if (!pl.cmode) {
+            const long long p = gp0 + 2LL * i;
+            const long long blk0 = p / nproma;
+            if (blk0 == (p + 1) / nproma && (((uintptr_t)gf.base & 15) == 0) && (((blk0 * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk0 * nproma)) & 1) == 0) {
+              *(d2 *)(gf.base + (blk0 * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk0 * nproma)) = z;
+            } else {
+              gf.base[grid_index(gf, p, nproma)] = z.x;
+              gf.base[grid_index(gf, p + 1, nproma)] = z.y;
+            }
+          } else {
+            gf.base[grid_index(gf, gp0 + i, nproma)] = z.x;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ==========================================================================================
 // k_fft_inv: FOURIER_IN (fourier_in_mod.F90:64-76) + FSC (fsc_mod.F90:138-187) + FTINV
 // (ftinv_mod.F90:65-84; FFTW c2r semantics, unnormalised) + TRLTOG local copy.
 // ==========================================================================================
-EMI_KERNEL_LB(256) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const double *FB,
-                          int ldf, int nproma) {
+EMI_DEVFN d2 fsc_load(const double *FB, long long row, int ldf, const GridFld &gf, int k, double racthe) {
+  d2 x = *(const d2 *)(FB + row * ldf + 2 * gf.src);
+  if (gf.mode == GM_ACOS)
+    x = cscale(x, racthe);
+  else if (gf.mode == GM_EWDER)
+    x = cscale(cmuli(x), racthe * (double)k);
+  else if (gf.mode == GM_EWDER_UV)
+    x = cscale(cmuli(x), racthe * racthe * (double)k);
+  return x;
+}
+
+EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const double *FB,
+                              int ldf, int nproma) {
   EMI_LDS_DECL;
   d2 *a = (d2 *)EMI_LDS_PTR;
-  const int li = fft_find(Lc.blk_pref, Lc.nlat, EMI_BID);
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = fft_find(Lc.blk_pref, Lc.nlat, bid);
   const int lat = Lc.lats[li];
-  const FftPlanDev pl = T.plans[T.planid[lat]];
-  const int f0 = (EMI_BID - Lc.blk_pref[li]) * pl.fbk;
+  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const int f0 = (bid - Lc.blk_pref[li]) * pl.fbk;
   const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
+  const int fs = FFT_LDS_ELEMS(S);
   const double racthe = g.racthe[lat];
   const long long frow = g.fbase[lat];
   const d2 *tw = T.tw + pl.tw_off;
@@ -537,101 +808,77 @@ EMI_KERNEL_LB(256) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, co
   const d2 *rtw = T.rtw + pl.rtw_off;
   const d2 *chirp = T.chirp + pl.chirp_off;
 
-  if (pl.blue) {
-    for (int idx = EMI_TID; idx < nfl * S; idx += FFT_THREADS) a[idx] = mk2(0, 0);
-    EMI_SYNC();
-  }
-  // ---- stage 1: logical input Z_k, k in [0,sz)
-  // field is the fastest index of the work split so that FB reads are contiguous in f
-#define LOADX(k_, fl_, out_)                                                        \
-  {                                                                                 \
-    out_ = mk2(0, 0);                                                               \
-    if ((k_) <= nmen) {                                                             \
-      GridFld gf_ = flds[f0 + (fl_)];                                               \
-      d2 x_ = *(const d2 *)(FB + (frow + (k_)) * ldf + 2 * gf_.src);                \
-      if (gf_.mode == GM_ACOS)                                                      \
-        x_ = cscale(x_, racthe);                                                    \
-      else if (gf_.mode == GM_EWDER)                                                \
-        x_ = cscale(cmuli(x_), racthe * (double)(k_));                              \
-      else if (gf_.mode == GM_EWDER_UV)                                             \
-        x_ = cscale(cmuli(x_), racthe * racthe * (double)(k_));                     \
-      out_ = x_;                                                                    \
-    }                                                                               \
-  }
-  if (!pl.cmode) {
-    const int npair = sz / 2 + 1;  // k = 0..sz/2 pairs with sz-k
-    for (int idx = EMI_TID; idx < nfl * npair; idx += FFT_THREADS) {
-      int k = idx / nfl, fl = idx - k * nfl;
-      int k2 = sz - k;
-      d2 xa, xb;
-      LOADX(k, fl, xa);
-      LOADX(k2, fl, xb);  // k=0 -> index sz (Nyquist) -> zero since nmen < sz
-      // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
-      d2 wk = cconj(rtw[k]);
-      d2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
-      d2 zk = cadd(s1, cmuli(cmul(wk, d1)));
-      d2 *af = a + (long long)fl * S;
-      if (pl.blue)
-        af[k] = cmulc(zk, chirp[k]);  // inverse chirp = conj
-      else
-        af[perm[k]] = zk;
-      if (k2 != k && k2 < sz) {
-        // Z_{sz-k}: w^{sz-k} = -conj(w^k)
-        d2 s2 = cadd(xb, cconj(xa)), d2_ = csub(xb, cconj(xa));
-        d2 wk2 = mk2(-wk.x, wk.y);
-        d2 zk2 = cadd(s2, cmuli(cmul(wk2, d2_)));
-        if (pl.blue)
-          af[k2] = cmulc(zk2, chirp[k2]);
-        else
-          af[perm[k2]] = zk2;
-      }
-    }
-  } else {
-    // complex mode (odd n): Z_k = X_k, Z_{n-k} = conj X_k
-    for (int idx = EMI_TID; idx < nfl * sz; idx += FFT_THREADS) {
-      int k = idx / nfl, fl = idx - k * nfl;
-      d2 z;
-      if (2 * k <= n) {
-        LOADX(k, fl, z);
-        if (k == 0) z.y = 0.0;
-      } else {
-        LOADX(n - k, fl, z);
-        z = cconj(z);
-      }
-      d2 *af = a + (long long)fl * S;
-      if (pl.blue)
-        af[k] = cmulc(z, chirp[k]);
-      else
-        af[perm[k]] = z;
-    }
-  }
-#undef LOADX
-  EMI_SYNC();
-  // ---- stage 2
-  if (pl.blue)
-    blue_conv(a, nfl, pl, T, 1);
-  else
-    fft_run<0>(a, nfl, S, pl, tw, +1);
-  // ---- stage 3: write the row (TRLTOG local copy)
-  const long long gp0 = g.gpoff[lat];
-  const double invL = pl.blue ? 1.0 / (double)S : 1.0;
-  for (int idx = EMI_TID; idx < nfl * n; idx += FFT_THREADS) {
-    int fl = idx / n, p = idx - fl * n;
-    const d2 *af = a + (long long)fl * S;
-    double v;
+  // ---- stage 1: logical input Z_k, k in [0,sz), to LDS (natural for Bluestein, perm[] for DIT)
+  for (int fl = 0; fl < nfl; fl++) {
+    const GridFld gf = flds[f0 + fl];
+    d2 *af = a + (long long)fl * fs;
     if (!pl.cmode) {
-      int lz = p >> 1;
-      d2 z = af[lz];
-      if (pl.blue) z = cscale(cmulc(z, chirp[lz]), invL);
-      v = (p & 1) ? z.y : z.x;
+      const int npair = sz / 2 + 1;  // k = 0..sz/2 pairs with sz-k
+      for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
+        const int k2 = sz - k;
+        d2 xa = (k <= nmen) ? fsc_load(FB, frow + k, ldf, gf, k, racthe) : mk2(0, 0);
+        d2 xb = (k2 <= nmen) ? fsc_load(FB, frow + k2, ldf, gf, k2, racthe) : mk2(0, 0);
+        // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
+        d2 wk = cconj(rtw[k]);
+        d2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
+        d2 zk = cadd(s1, cmuli(cmul(wk, d1)));
+        af[FPAD(pl.blue ? k : (int)perm[k])] = pl.blue ? cmulc(zk, chirp[k]) : zk;
+        if (k2 != k && k2 < sz) {
+          // Z_{sz-k}: w^{sz-k} = -conj(w^k)
+          d2 s2 = cadd(xb, cconj(xa)), d2_ = csub(xb, cconj(xa));
+          d2 zk2 = cadd(s2, cmuli(cmul(mk2(-wk.x, wk.y), d2_)));
+          af[FPAD(pl.blue ? k2 : (int)perm[k2])] = pl.blue ? cmulc(zk2, chirp[k2]) : zk2;
+        }
+      }
     } else {
-      d2 z = af[p];
-      if (pl.blue) z = cscale(cmulc(z, chirp[p]), invL);
-      v = z.x;
+      // complex mode (odd n): Z_k = X_k, Z_{n-k} = conj X_k
+      for (int k = EMI_TID; k < sz; k += EMI_NTHREADS) {
+        d2 z;
+        if (2 * k <= n) {
+          z = (k <= nmen) ? fsc_load(FB, frow + k, ldf, gf, k, racthe) : mk2(0, 0);
+          if (k == 0) z.y = 0.0;
+        } else {
+          z = (n - k <= nmen) ? cconj(fsc_load(FB, frow + n - k, ldf, gf, n - k, racthe)) : mk2(0, 0);
+        }
+        af[FPAD(pl.blue ? k : (int)perm[k])] = pl.blue ? cmulc(z, chirp[k]) : z;
+      }
     }
-    GridFld gf = flds[f0 + fl];
-    gf.base[grid_index(gf, gp0 + p, nproma)] = v;
   }
+  EMI_SYNC();
+  // ---- stage 2 (all passes but the last) and stage 3 (last DIT pass -> grid, TRLTOG local copy)
+  const long long gp0 = g.gpoff[lat];
+  int lenp;
+  if (pl.blue) {
+    if (pl.nfac == 1) {
+      // degenerate single-factor filter length: no separate last pass to fuse with the store
+      blue_conv(a, nfl, fs, pl, T, 1, sz, 0);
+      const double invL = 1.0 / (double)S;
+      for (int fl = 0; fl < nfl; fl++) {
+        const GridFld gf = flds[f0 + fl];
+        const d2 *af = a + (long long)fl * fs;
+        for (int p = EMI_TID; p < n; p += EMI_NTHREADS) {
+          const int i = pl.cmode ? p : (p >> 1);
+          d2 z = cscale(cmulc(af[FPAD(i)], chirp[i]), invL);
+          gf.base[grid_index(gf, gp0 + p, nproma)] = (pl.cmode || !(p & 1)) ? z.x : z.y;
+        }
+      }
+      return;
+    }
+    lenp = blue_conv(a, nfl, fs, pl, T, 1, sz, 1);
+  } else {
+    if (pl.nfac == 0) {  // sz == 1
+      for (int fl = EMI_TID; fl < nfl; fl += EMI_NTHREADS) {
+        const GridFld gf = flds[f0 + fl];
+        d2 z = a[(long long)fl * fs];
+        gf.base[grid_index(gf, gp0, nproma)] = z.x;
+        if (!pl.cmode) gf.base[grid_index(gf, gp0 + 1, nproma)] = z.y;
+      }
+      return;
+    }
+    lenp = run_dit(a, nfl, fs, S, pl.fac, 0, pl.nfac - 1, 1, tw, +1);
+  }
+  const int rl = pl.fac[pl.nfac - 1];
+  FFT_DISPATCH(dit_last_to_grid, rl, a, nfl, fs, S, lenp, tw, pl, chirp, flds, f0, gp0, nproma);
 }
 
 // ==========================================================================================
@@ -640,16 +887,18 @@ EMI_KERNEL_LB(256) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, co
 // (ledir_mod.F90:118-124) and LDFOU2's 1/(a cos) (ldfou2_mod.F90:90-96) only depend on the
 // latitude and are folded into the same scale factor.
 // ==========================================================================================
-EMI_KERNEL_LB(256) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, double *FB, int ldf,
-                          int nproma) {
+EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, double *FB, int ldf,
+                              int nproma) {
   EMI_LDS_DECL;
   d2 *a = (d2 *)EMI_LDS_PTR;
-  const int li = fft_find(Lc.blk_pref, Lc.nlat, EMI_BID);
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = fft_find(Lc.blk_pref, Lc.nlat, bid);
   const int lat = Lc.lats[li];
-  const FftPlanDev pl = T.plans[T.planid[lat]];
-  const int f0 = (EMI_BID - Lc.blk_pref[li]) * pl.fbk;
+  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const int f0 = (bid - Lc.blk_pref[li]) * pl.fbk;
   const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
+  const int fs = FFT_LDS_ELEMS(S);
   const long long frow = g.fbase[lat];
   const long long gp0 = g.gpoff[lat];
   const d2 *tw = T.tw + pl.tw_off;
@@ -657,58 +906,59 @@ EMI_KERNEL_LB(256) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, co
   const d2 *rtw = T.rtw + pl.rtw_off;
   const d2 *chirp = T.chirp + pl.chirp_off;
 
-  if (pl.blue) {
-    for (int idx = EMI_TID; idx < nfl * S; idx += FFT_THREADS) a[idx] = mk2(0, 0);
-    EMI_SYNC();
-  }
   // ---- stage 1: z_l = x_{2l} + i x_{2l+1} (or x_l in complex mode)
-  for (int idx = EMI_TID; idx < nfl * sz; idx += FFT_THREADS) {
-    int fl = idx / sz, lz = idx - fl * sz;
-    GridFld gf = flds[f0 + fl];
-    d2 z;
-    if (!pl.cmode) {
-      z.x = gf.base[grid_index(gf, gp0 + 2 * lz, nproma)];
-      z.y = gf.base[grid_index(gf, gp0 + 2 * lz + 1, nproma)];
-    } else {
-      z.x = gf.base[grid_index(gf, gp0 + lz, nproma)];
-      z.y = 0.0;
+  for (int fl = 0; fl < nfl; fl++) {
+    const GridFld gf = flds[f0 + fl];
+    d2 *af = a + (long long)fl * fs;
+    const bool flat = (gp0 + n <= (long long)nproma) && ((((uintptr_t)(gf.base + (long long)gf.fidx * nproma + gp0)) & 15) == 0);
+    const double *rowp = gf.base + (long long)gf.fidx * nproma + gp0;
+    for (int lz = EMI_TID; lz < sz; lz += EMI_NTHREADS) {
+      d2 z;
+      if (!pl.cmode) {
+        if (flat) {
+          z = *(const d2 *)(rowp + 2 * lz);
+        } else {
+          z.x = gf.base[grid_index(gf, gp0 + 2 * lz, nproma)];
+          z.y = gf.base[grid_index(gf, gp0 + 2 * lz + 1, nproma)];
+        }
+      } else {
+        z.x = gf.base[grid_index(gf, gp0 + lz, nproma)];
+        z.y = 0.0;
+      }
+      af[FPAD(pl.blue ? lz : (int)perm[lz])] = pl.blue ? cmul(z, chirp[lz]) : z;
     }
-    d2 *af = a + (long long)fl * S;
-    if (pl.blue)
-      af[lz] = cmul(z, chirp[lz]);
-    else
-      af[perm[lz]] = z;
   }
   EMI_SYNC();
   if (pl.blue)
-    blue_conv(a, nfl, pl, T, 0);
+    blue_conv(a, nfl, fs, pl, T, 0, sz, 0);
   else
-    fft_run<0>(a, nfl, S, pl, tw, -1);
+    run_dit(a, nfl, fs, S, pl.fac, 0, pl.nfac, 1, tw, -1);
   // ---- stage 3: X_k, k = 0..NMEN
   const double invL = pl.blue ? 1.0 / (double)S : 1.0;
   const double base_scale = g.rw[lat] / (double)n;
-  for (int idx = EMI_TID; idx < nfl * (nmen + 1); idx += FFT_THREADS) {
-    int k = idx / nfl, fl = idx - k * nfl;
-    const d2 *af = a + (long long)fl * S;
-    d2 x;
-    if (!pl.cmode) {
-      int ka = (k == sz) ? 0 : k, kb = (k == 0) ? 0 : sz - k;
-      d2 za = af[ka], zb = af[kb];
-      if (pl.blue) {
-        za = cscale(cmul(za, chirp[ka]), invL);
-        zb = cscale(cmul(zb, chirp[kb]), invL);
+  for (int fl = 0; fl < nfl; fl++) {
+    const GridFld gf = flds[f0 + fl];
+    const d2 *af = a + (long long)fl * fs;
+    const double sc = base_scale * ((gf.mode == GM_ACOS) ? g.racthe[lat] : 1.0);
+    for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
+      d2 x;
+      if (!pl.cmode) {
+        const int kb = (k == 0) ? 0 : sz - k;
+        d2 za = af[FPAD(k)], zb = af[FPAD(kb)];
+        if (pl.blue) {
+          za = cscale(cmul(za, chirp[k]), invL);
+          zb = cscale(cmul(zb, chirp[kb]), invL);
+        }
+        // X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ]
+        d2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
+        d2 t = cmuli(cmul(rtw[k], d1));
+        x = mk2(0.5 * (s1.x - t.x), 0.5 * (s1.y - t.y));
+      } else {
+        x = af[FPAD(k)];
+        if (pl.blue) x = cscale(cmul(x, chirp[k]), invL);
       }
-      // X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ]
-      d2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
-      d2 t = cmuli(cmul(rtw[k], d1));
-      x = mk2(0.5 * (s1.x - t.x), 0.5 * (s1.y - t.y));
-    } else {
-      x = af[k];
-      if (pl.blue) x = cscale(cmul(x, chirp[k]), invL);
+      *(d2 *)(FB + (frow + k) * ldf + 2 * (f0 + fl)) = cscale(x, sc);
     }
-    GridFld gf = flds[f0 + fl];
-    double sc = base_scale * ((gf.mode == GM_ACOS) ? g.racthe[lat] : 1.0);
-    *(d2 *)(FB + (frow + k) * ldf + 2 * (f0 + fl)) = cscale(x, sc);
   }
 }
 

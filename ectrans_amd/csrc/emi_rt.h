@@ -19,6 +19,8 @@
 
 #define EMI_KERNEL __global__
 #define EMI_KERNEL_LB(T) __global__ __launch_bounds__(T)
+#define EMI_KERNEL_LBV __global__ __launch_bounds__(512)
+#define EMI_KERNEL_LB2(T, W) __global__ __attribute__((amdgpu_flat_work_group_size(T, T), amdgpu_waves_per_eu(W, W)))
 #define EMI_DEVFN __device__ __forceinline__
 #define EMI_TID ((int)threadIdx.x)
 #define EMI_BID ((int)blockIdx.x)
@@ -28,9 +30,7 @@
 #define EMI_LDS_PTR (emi_lds_raw)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-struct __attribute__((aligned(16))) d2 {
-  double x, y;
-};
+typedef double d2 __attribute__((ext_vector_type(2)));  // native 16-byte vector: whole-value copies stay in VGPRs
 
 EMI_DEVFN v4d emi_mfma_f64_16x16x4(double a, double b, v4d c) {
   // v_mfma_f64_16x16x4_f64: A[row=l&15][k=l>>4], B[k=l>>4][col=l&15],
@@ -58,6 +58,8 @@ typedef hipStream_t emi_stream_t;
 
 #define EMI_KERNEL
 #define EMI_KERNEL_LB(T)
+#define EMI_KERNEL_LBV
+#define EMI_KERNEL_LB2(T, W)
 #define EMI_DEVFN inline
 struct EmuCtx {
   int tid, bid, nthreads;

@@ -227,9 +227,20 @@ inline void legendre_column(const LegCoef &c, double mu_in, int par, double *out
 // ---------------------------------------------------------------------------------------
 // FFT planning
 // ---------------------------------------------------------------------------------------
+// Factor list in DIT order.  Powers of two first (as radix 16, then one of 8/4/2), odd radices
+// last, so that every pass stride of a 2-3-5-smooth size is a power of two.
 inline bool factorize_smooth(int s, std::vector<int> &fac) {
   fac.clear();
-  static const int rad[] = {4, 3, 5, 7, 11, 13, 2};
+  int e2 = 0;
+  while (s % 2 == 0 && s > 1) {
+    s /= 2;
+    e2++;
+  }
+  for (; e2 >= 4; e2 -= 4) fac.push_back(16);
+  if (e2 == 3) fac.push_back(8);
+  if (e2 == 2) fac.push_back(4);
+  if (e2 == 1) fac.push_back(2);
+  static const int rad[] = {3, 5, 7, 11, 13};
   for (int r : rad)
     while (s % r == 0 && s > 1) {
       fac.push_back(r);
@@ -237,15 +248,16 @@ inline bool factorize_smooth(int s, std::vector<int> &fac) {
     }
   return s == 1;
 }
-inline int next_235(int n) {  // smallest 2^a 3^b 5^c >= n
+// Bluestein work length: smallest 2^a 3^b 5^c >= n with b <= 2, c <= 1 (few odd passes)
+inline int next_235(int n) {
   int best = 1;
   while (best < n) best *= 2;
-  for (long long p5 = 1; p5 < 2LL * best; p5 *= 5)
-    for (long long p3 = p5; p3 < 2LL * best; p3 *= 3) {
-      long long v = p3;
-      while (v < n) v *= 2;
-      if (v < best) best = (int)v;
-    }
+  static const int odd[] = {3, 5, 9, 15, 45};
+  for (int o : odd) {
+    long long v = o;
+    while (v < n) v *= 2;
+    if (v < best) best = (int)v;
+  }
   return best;
 }
 inline void dit_positions(int S, const std::vector<int> &fac, std::vector<uint16_t> &perm) {
