@@ -775,7 +775,7 @@ static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, d
     FftClass &fc = P.fclass[c];
     if (fc.lats.empty() || fc.nblocks == 0) continue;
     FftLaunchDev lc{fc.d_lats, fc.d_pref, (int)fc.lats.size(), fc.nblocks};
-    const int nthr = c == 0 ? 256 : 512;
+    const int nthr = c == 0 ? 256 : (c == 1 ? 512 : 1024);
     if (inverse)
       EMI_LAUNCH(k_fft_inv, fc.nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma);
     else

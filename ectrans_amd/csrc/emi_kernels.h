@@ -530,45 +530,20 @@ EMI_DEVFN void butterfly(d2 *v, const d2 *tw, int S, int sgn) {
       v[2 * k2] = t0[k2];
       v[2 * k2 + 1] = t1[k2];
     }
-  } else if (R == 16) {
-    // n = 4 n1 + n2, k = k1 + 4 k2
-    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
-    d2 t[4][4];  // t[n2][k1]
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) {
-      t[n2][0] = v[n2];
-      t[n2][1] = v[4 + n2];
-      t[n2][2] = v[8 + n2];
-      t[n2][3] = v[12 + n2];
-      bf4(t[n2][0], t[n2][1], t[n2][2], t[n2][3], sgn);
-    }
-    // t[n2][k1] *= W16^{n2 k1}; W16^k = cos(pi k/8) -+ i sin(pi k/8)
-    const double wc[10] = {1.0, c1, h, s1, 0.0, -s1, -h, -c1, -1.0, -c1};
-    const double ws[10] = {0.0, s1, h, c1, 1.0, c1, h, s1, 0.0, -s1};
-#pragma unroll
-    for (int n2 = 1; n2 < 4; n2++)
-#pragma unroll
-      for (int k1 = 1; k1 < 4; k1++) {
-        const int e = n2 * k1;
-        d2 w = mk2(wc[e], (sgn < 0) ? -ws[e] : ws[e]);
-        t[n2][k1] = cmul(t[n2][k1], w);
-      }
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) {
-      bf4(t[0][k1], t[1][k1], t[2][k1], t[3][k1], sgn);
-      v[k1] = t[0][k1];
-      v[k1 + 4] = t[1][k1];
-      v[k1 + 8] = t[2][k1];
-      v[k1 + 12] = t[3][k1];
-    }
   } else {
-    d2 y[R];
+    // generic small prime (7): DFT matrix rows from the twiddle table, fully unrolled
+    d2 y[R], w[R];
     const int st = S / R;
+#pragma unroll
+    for (int e = 1; e < R; e++) w[e] = tw_get(tw, e * st, sgn);
+#pragma unroll
     for (int u = 0; u < R; u++) {
       d2 s = v[0];
-      for (int t = 1; t < R; t++) s = cadd(s, cmul(v[t], tw_get(tw, ((u * t) % R) * st, sgn)));
+#pragma unroll
+      for (int t = 1; t < R; t++) s = ((u * t) % R) ? cadd(s, cmul(v[t], w[(u * t) % R])) : cadd(s, v[t]);
       y[u] = s;
     }
+#pragma unroll
     for (int u = 0; u < R; u++) v[u] = y[u];
   }
 }
@@ -625,9 +600,14 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
     case 5: FN<5>(__VA_ARGS__); break;            \
     case 7: FN<7>(__VA_ARGS__); break;            \
     case 8: FN<8>(__VA_ARGS__); break;            \
-    case 11: FN<11>(__VA_ARGS__); break;          \
-    case 13: FN<13>(__VA_ARGS__); break;          \
-    case 16: FN<16>(__VA_ARGS__); break;          \
+    default: break;                               \
+  }
+// Bluestein lengths are 2^a * {1,3,5,9,15}: their first DIT factor is a power of two
+#define FFT_DISPATCH_POW2(FN, r, ...)             \
+  switch (r) {                                    \
+    case 2: FN<2>(__VA_ARGS__); break;            \
+    case 4: FN<4>(__VA_ARGS__); break;            \
+    case 8: FN<8>(__VA_ARGS__); break;            \
     default: break;                               \
   }
 
@@ -694,7 +674,7 @@ EMI_DEVFN int blue_conv(d2 *a, int nfl, int fs, const FftPlanDev &pl, const FftT
   run_dif(a, nfl, fs, L, pl.fac, pl.nfac, 1, tw, -1, nvalid);
   const int r0 = pl.fac[0];
   const int nv0 = (pl.nfac == 1) ? nvalid : L;
-  FFT_DISPATCH(blue_middle, r0, a, nfl, fs, L, tw, bh, conj_b, nv0);
+  FFT_DISPATCH_POW2(blue_middle, r0, a, nfl, fs, L, tw, bh, conj_b, nv0);
   EMI_SYNC();
   const int last = defer_last ? pl.nfac - 1 : pl.nfac;
   return run_dit(a, nfl, fs, L, pl.fac, 1, last < 1 ? 1 : last, r0, tw, +1);
@@ -732,13 +712,9 @@ EMI_DEVFN void dit_last_to_grid(d2 *a, int nfl, int fs, int S, int lenp, const d
                                 const GridFld *flds, int f0, long long gp0, int nproma) {
   const int nb = S / R, sh = log2_exact(lenp), sz = pl.sz;
   const double invL = pl.blue ? 1.0 / (double)S : 1.0;
-  const bool contiguous = true;
-  (void)contiguous;
   for (int fl = 0; fl < nfl; fl++) {
     d2 *af = a + (long long)fl * fs;
     const GridFld gf = flds[f0 + fl];
-    const bool flat = (nproma >= (int)0x7fffffff) ? true : false;
-    (void)flat;
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
       int blk, j;
       split_q(q, lenp, sh, blk, j);  // last pass: len == S, blk == 0

@@ -19,7 +19,7 @@
 
 #define EMI_KERNEL __global__
 #define EMI_KERNEL_LB(T) __global__ __launch_bounds__(T)
-#define EMI_KERNEL_LBV __global__ __launch_bounds__(512)
+#define EMI_KERNEL_LBV __global__ __launch_bounds__(1024)
 #define EMI_KERNEL_LB2(T, W) __global__ __attribute__((amdgpu_flat_work_group_size(T, T), amdgpu_waves_per_eu(W, W)))
 #define EMI_DEVFN __device__ __forceinline__
 #define EMI_TID ((int)threadIdx.x)

@@ -227,8 +227,9 @@ inline void legendre_column(const LegCoef &c, double mu_in, int par, double *out
 // ---------------------------------------------------------------------------------------
 // FFT planning
 // ---------------------------------------------------------------------------------------
-// Factor list in DIT order.  Powers of two first (as radix 16, then one of 8/4/2), odd radices
-// last, so that every pass stride of a 2-3-5-smooth size is a power of two.
+// Factor list in DIT order.  Powers of two first (radix 8, then one of 4/2), odd radices last, so
+// that every pass stride of a 2-3-5-smooth size is a power of two.  Radix 8 keeps the butterfly
+// at 32 data VGPRs, so the FFT kernels fit 128 VGPRs and every CU holds 16 waves.
 inline bool factorize_smooth(int s, std::vector<int> &fac) {
   fac.clear();
   int e2 = 0;
@@ -236,11 +237,10 @@ inline bool factorize_smooth(int s, std::vector<int> &fac) {
     s /= 2;
     e2++;
   }
-  for (; e2 >= 4; e2 -= 4) fac.push_back(16);
-  if (e2 == 3) fac.push_back(8);
+  for (; e2 >= 3; e2 -= 3) fac.push_back(8);
   if (e2 == 2) fac.push_back(4);
   if (e2 == 1) fac.push_back(2);
-  static const int rad[] = {3, 5, 7, 11, 13};
+  static const int rad[] = {3, 5, 7};
   for (int r : rad)
     while (s % r == 0 && s > 1) {
       fac.push_back(r);
@@ -248,17 +248,22 @@ inline bool factorize_smooth(int s, std::vector<int> &fac) {
     }
   return s == 1;
 }
-// Bluestein work length: smallest 2^a 3^b 5^c >= n with b <= 2, c <= 1 (few odd passes)
+// Bluestein work length: among 2^a * {1,3,5,9,15} >= n, the one minimising L * (passes + 1)
 inline int next_235(int n) {
-  int best = 1;
-  while (best < n) best *= 2;
-  static const int odd[] = {3, 5, 9, 15, 45};
+  static const int odd[] = {1, 3, 5, 9, 15};
+  long long best = -1, bestcost = 0;
   for (int o : odd) {
     long long v = o;
     while (v < n) v *= 2;
-    if (v < best) best = (int)v;
+    std::vector<int> f;
+    factorize_smooth((int)v, f);
+    long long cost = v * (long long)(f.size() + 1);
+    if (best < 0 || cost < bestcost) {
+      best = v;
+      bestcost = cost;
+    }
   }
-  return best;
+  return (int)best;
 }
 inline void dit_positions(int S, const std::vector<int> &fac, std::vector<uint16_t> &perm) {
   perm.assign(S, 0);
