@@ -194,7 +194,7 @@ static int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
 static int build_fft_plans(Plan &P) {
   std::map<int, int> idx;
-  std::vector<d2> tw, rtw, chirp, bhat;
+  std::vector<d2> tw, rtw, chirp, bhat, ptw;
   std::vector<uint16_t> perm;
   P.planid.assign(P.ndgl, 0);
   for (int j = 0; j < P.ndgl; j++) {
@@ -227,6 +227,20 @@ static int build_fft_plans(Plan &P) {
     for (int k = 0; k < pl.S; k++) {
       double a = tpi * (double)k / (double)pl.S;
       tw.push_back(d2{std::cos(a), -std::sin(a)});
+    }
+    {  // per-pass twiddle tables, [t-1][j] with j fastest (coalesced reads)
+      long long lenp = 1;
+      for (int ip = 0; ip < pl.nfac; ip++) {
+        const int R = fac[ip];
+        pl.ptw_off[ip] = (int)ptw.size();
+        if (lenp > 1)
+          for (int t = 1; t < R; t++)
+            for (long long j = 0; j < lenp; j++) {
+              long double a = 2.0L * (long double)M_PIl * (long double)((j * t) % (lenp * R)) / (long double)(lenp * R);
+              ptw.push_back(d2{(double)cosl(a), (double)-sinl(a)});
+            }
+        lenp *= R;
+      }
     }
     std::vector<uint16_t> pm;
     emi::dit_positions(pl.S, fac, pm);
@@ -289,16 +303,17 @@ static int build_fft_plans(Plan &P) {
     fc.lats.push_back(j);
     fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 16);
   }
-  d2 *d_tw, *d_rtw, *d_chirp, *d_bhat;
+  d2 *d_tw, *d_rtw, *d_chirp, *d_bhat, *d_ptw;
   uint16_t *d_perm;
   FftPlanDev *d_plans;
   int *d_planid;
-  if (upload(tw, &d_tw) || upload(rtw, &d_rtw) || upload(chirp, &d_chirp) || upload(bhat, &d_bhat) || upload(perm, &d_perm) ||
+  if (upload(tw, &d_tw) || upload(ptw, &d_ptw) || upload(rtw, &d_rtw) || upload(chirp, &d_chirp) || upload(bhat, &d_bhat) || upload(perm, &d_perm) ||
       upload(P.fplans, &d_plans) || upload(P.planid, &d_planid))
     return EMI_ERR_RUNTIME;
-  for (void *p : {(void *)d_tw, (void *)d_rtw, (void *)d_chirp, (void *)d_bhat, (void *)d_perm, (void *)d_plans, (void *)d_planid})
+  for (void *p : {(void *)d_tw, (void *)d_ptw, (void *)d_rtw, (void *)d_chirp, (void *)d_bhat, (void *)d_perm, (void *)d_plans, (void *)d_planid})
     P.dev_allocs.push_back(p);
   P.ftab.tw = d_tw;
+  P.ftab.ptw = d_ptw;
   P.ftab.rtw = d_rtw;
   P.ftab.chirp = d_chirp;
   P.ftab.bhat = d_bhat;

@@ -62,11 +62,13 @@ struct FftPlanDev {
   int nfac;
   int fac[14];
   int tw_off, perm_off, rtw_off, chirp_off, bhat_off;
+  int ptw_off[14];  // per pass (DIT order): table [(t-1)*lenp + j] = exp(-2 pi i j t/(lenp*R))
   int fbk;  // fields per workgroup
   int lds_class, pad_;
 };
 struct FftTabDev {
   const d2 *tw;                // e^{-2 pi i k/S}
+  const d2 *ptw;               // per-pass twiddles, coalesced layout
   const unsigned short *perm;  // DIT input position of natural index
   const d2 *rtw;               // e^{-2 pi i k/n}, k=0..sz/2
   const d2 *chirp;             // e^{-i pi k^2/sz}
@@ -455,15 +457,18 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
 //   * radices 2,3,4,5,8,16 are hard-coded register butterflies; 7,11,13 use the DFT matrix from tw
 //   * the host orders the factors so that every pass stride (lenp) of a 2-3-5-smooth size is a power
 //     of two (odd radices last in DIT order) -> no integer divisions in those passes
-//   * logical element i lives at LDS slot FPAD(i) = i + (i >> 4): the pass whose butterflies are
-//     contiguous runs of R elements (stride R*16 B between lanes) becomes bank-conflict free
+//   * logical element i lives at LDS slot FPAD(i) = i ^ ((i >> 3) & 15) (XOR swizzle inside aligned
+//     16-element blocks): stride-1 passes stay conflict free and the pass whose butterflies are
+//     contiguous runs of 8 elements (stride 128 B between lanes) becomes conflict free too
+//   * inter-pass twiddles come from per-pass tables laid out [t][j] so that a wave reads them
+//     coalesced (the single table tw[j*t*S/len] is a 64-line gather per wave instruction)
 //   * Bluestein: DIF passes -> [last DIF pass + pointwise filter + first DIT pass fused in
 //     registers] -> DIT passes; the final DIT pass of the inverse transform multiplies by the chirp
 //     and stores the real row straight to the user's grid array (no LDS round trip)
 // ==========================================================================================
 #define FFT_MAXR 16
-#define FPAD(i) ((i) + ((i) >> 4))
-#define FFT_LDS_ELEMS(S) ((S) + ((S) >> 4) + 1)
+#define FPAD(i) ((i) ^ (((i) >> 3) & 15))
+#define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 
 EMI_DEVFN d2 tw_get(const d2 *tw, int idx, int sgn) {
   d2 t = tw[idx];
@@ -563,8 +568,8 @@ EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_cl
 // one in-place pass over nfl fields.  nvalid: logical elements >= nvalid read as zero (first DIF
 // pass of a zero-padded Bluestein input).
 template <int R, int DIF>
-EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *tw, int sgn, int nvalid) {
-  const int len = lenp * R, nb = S / R, tst = S / len, sh = log2_exact(lenp);
+EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
+  const int len = lenp * R, nb = S / R, sh = log2_exact(lenp);
   for (int fl = 0; fl < nfl; fl++) {
     d2 *af = a + (long long)fl * fstride;
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
@@ -577,14 +582,19 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
         const int i = base + t * lenp;
         v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
       }
-      if (!DIF && j > 0) {
+      d2 w[R];
+      if (lenp > 1) {
 #pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t * tst, sgn));
+        for (int t = 1; t < R; t++) w[t] = tw_get(ptw, (t - 1) * lenp + j, sgn);
+      }
+      if (!DIF && lenp > 1) {
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
       }
       butterfly<R>(v, tw, S, sgn);
-      if (DIF && j > 0) {
+      if (DIF && lenp > 1) {
 #pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t * tst, sgn));
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
       }
 #pragma unroll
       for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
@@ -612,31 +622,35 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
   }
 
 template <int R>
-EMI_DEVFN void pass_dit(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, int sgn, int nvalid) {
-  fft_pass<R, 0>(a, nfl, fs, S, lenp, tw, sgn, nvalid);
+EMI_DEVFN void pass_dit(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
+  fft_pass<R, 0>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
 }
 template <int R>
-EMI_DEVFN void pass_dif(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, int sgn, int nvalid) {
-  fft_pass<R, 1>(a, nfl, fs, S, lenp, tw, sgn, nvalid);
+EMI_DEVFN void pass_dif(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
+  fft_pass<R, 1>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
 }
 
 // DIT passes ip = first..last-1 (factor order); returns lenp after them
-EMI_DEVFN int run_dit(d2 *a, int nfl, int fs, int S, const int *fac, int first, int last, int lenp, const d2 *tw, int sgn) {
+EMI_DEVFN int run_dit(d2 *a, int nfl, int fs, int S, const FftPlanDev &pl, const FftTabDev &T, int first, int last, int lenp, int sgn) {
+  const int *fac = pl.fac;
+  const d2 *tw = T.tw + pl.tw_off;
   for (int ip = first; ip < last; ip++) {
     const int r = fac[ip];
-    FFT_DISPATCH(pass_dit, r, a, nfl, fs, S, lenp, tw, sgn, S);
+    FFT_DISPATCH(pass_dit, r, a, nfl, fs, S, lenp, tw, T.ptw + pl.ptw_off[ip], sgn, S);
     lenp *= r;
     EMI_SYNC();
   }
   return lenp;
 }
 // DIF passes over factors nfac-1 down to `stop` (inclusive); nvalid applies to the first one
-EMI_DEVFN void run_dif(d2 *a, int nfl, int fs, int S, const int *fac, int nfac, int stop, const d2 *tw, int sgn, int nvalid) {
+EMI_DEVFN void run_dif(d2 *a, int nfl, int fs, int S, const FftPlanDev &pl, const FftTabDev &T, int stop, int sgn, int nvalid) {
+  const int *fac = pl.fac;
+  const d2 *tw = T.tw + pl.tw_off;
   int lenp = S;
-  for (int ip = nfac - 1; ip >= stop; ip--) {
+  for (int ip = pl.nfac - 1; ip >= stop; ip--) {
     const int r = fac[ip];
     lenp /= r;
-    FFT_DISPATCH(pass_dif, r, a, nfl, fs, S, lenp, tw, sgn, nvalid);
+    FFT_DISPATCH(pass_dif, r, a, nfl, fs, S, lenp, tw, T.ptw + pl.ptw_off[ip], sgn, nvalid);
     nvalid = S;
     EMI_SYNC();
   }
@@ -671,13 +685,13 @@ EMI_DEVFN void blue_middle(d2 *a, int nfl, int fs, int S, const d2 *tw, const d2
 EMI_DEVFN int blue_conv(d2 *a, int nfl, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid, int defer_last) {
   const int L = pl.S;
   const d2 *tw = T.tw + pl.tw_off, *bh = T.bhat + pl.bhat_off;
-  run_dif(a, nfl, fs, L, pl.fac, pl.nfac, 1, tw, -1, nvalid);
+  run_dif(a, nfl, fs, L, pl, T, 1, -1, nvalid);
   const int r0 = pl.fac[0];
   const int nv0 = (pl.nfac == 1) ? nvalid : L;
   FFT_DISPATCH_POW2(blue_middle, r0, a, nfl, fs, L, tw, bh, conj_b, nv0);
   EMI_SYNC();
   const int last = defer_last ? pl.nfac - 1 : pl.nfac;
-  return run_dit(a, nfl, fs, L, pl.fac, 1, last < 1 ? 1 : last, r0, tw, +1);
+  return run_dit(a, nfl, fs, L, pl, T, 1, last < 1 ? 1 : last, r0, +1);
 }
 
 EMI_DEVFN long long grid_index(const GridFld &gf, long long p, int nproma) {
@@ -708,8 +722,8 @@ EMI_DEVFN int fft_find(const int *pref, int n, int b) {
 // logical output z_i (i < sz): x_{2i} = Re, x_{2i+1} = Im (or x_i = Re z_i in complex mode),
 // Bluestein: z_i = a'_i * conj(chirp_i) / L.
 template <int R>
-EMI_DEVFN void dit_last_to_grid(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const FftPlanDev &pl, const d2 *chirp,
-                                const GridFld *flds, int f0, long long gp0, int nproma) {
+EMI_DEVFN void dit_last_to_grid(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, const FftPlanDev &pl,
+                                const d2 *chirp, const GridFld *flds, int f0, long long gp0, int nproma) {
   const int nb = S / R, sh = log2_exact(lenp), sz = pl.sz;
   const double invL = pl.blue ? 1.0 / (double)S : 1.0;
   for (int fl = 0; fl < nfl; fl++) {
@@ -721,9 +735,9 @@ EMI_DEVFN void dit_last_to_grid(d2 *a, int nfl, int fs, int S, int lenp, const d
       d2 v[R];
 #pragma unroll
       for (int t = 0; t < R; t++) v[t] = af[FPAD(j + t * lenp)];
-      if (j > 0) {
+      if (lenp > 1) {
 #pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(tw, j * t, +1));
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(ptw, (t - 1) * lenp + j, +1));
       }
       butterfly<R>(v, tw, S, +1);
 #pragma unroll
@@ -851,10 +865,10 @@ EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
       }
       return;
     }
-    lenp = run_dit(a, nfl, fs, S, pl.fac, 0, pl.nfac - 1, 1, tw, +1);
+    lenp = run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac - 1, 1, +1);
   }
   const int rl = pl.fac[pl.nfac - 1];
-  FFT_DISPATCH(dit_last_to_grid, rl, a, nfl, fs, S, lenp, tw, pl, chirp, flds, f0, gp0, nproma);
+  FFT_DISPATCH(dit_last_to_grid, rl, a, nfl, fs, S, lenp, tw, T.ptw + pl.ptw_off[pl.nfac - 1], pl, chirp, flds, f0, gp0, nproma);
 }
 
 // ==========================================================================================
@@ -908,7 +922,7 @@ EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
   if (pl.blue)
     blue_conv(a, nfl, fs, pl, T, 0, sz, 0);
   else
-    run_dit(a, nfl, fs, S, pl.fac, 0, pl.nfac, 1, tw, -1);
+    run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac, 1, -1);
   // ---- stage 3: X_k, k = 0..NMEN
   const double invL = pl.blue ? 1.0 / (double)S : 1.0;
   const double base_scale = g.rw[lat] / (double)n;
