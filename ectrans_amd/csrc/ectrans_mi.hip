@@ -127,7 +127,10 @@ struct Plan {
   bool reduced = false;
   double ra = 6371229.0;
   std::vector<int> nloen, nmen, ndglu, gpoff, nasm0, fbase, wbase, wrows, ldp, lattile_pref, ktile_pref;
-  std::vector<long long> offS, offA;
+  std::vector<long long> offS, offA, offTS, offTA;
+  std::vector<int> ldk;
+  long long pt_elems = 0;
+  double *d_PT = nullptr;
   std::vector<double> rmu, rw, racthe, cos2;
   long long frows = 0, wrows_total = 0, p_elems = 0;
   // device
@@ -397,13 +400,16 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   P.ldp.assign(N + 1, 0);
   P.offS.assign(N + 1, 0);
   P.offA.assign(N + 1, 0);
+  P.offTS.assign(N + 1, 0);
+  P.offTA.assign(N + 1, 0);
+  P.ldk.assign(N + 1, 0);
   P.lattile_pref.assign(N + 2, 0);
   P.ktile_pref.assign(N + 2, 0);
   std::vector<int> ebase(N + 1, 0);
   std::vector<double> eps;
   {
     int ipos = 0;
-    long long poff = 0;
+    long long poff = 0, ptoff = 0;
     for (int m = 0; m <= N; m++) {
       P.nasm0[m] = ipos;  // 0-based (D%NASM0 - 1, suwavedi_mod.F90:128-133)
       ipos += (N - m + 1) * 2;
@@ -415,6 +421,11 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
       P.offS[m] = poff;
       P.offA[m] = poff + pan;
       poff += 2 * pan;
+      P.ldk[m] = roundup(P.wrows[m] / 2, 64);
+      long long pant = (long long)roundup(std::max(nd, 1), 8) * P.ldk[m];
+      P.offTS[m] = ptoff;
+      P.offTA[m] = ptoff + pant;
+      ptoff += 2 * pant;
       P.lattile_pref[m + 1] = P.lattile_pref[m] + (nd + 63) / 64;
       P.ktile_pref[m + 1] = P.ktile_pref[m] + (P.wrows[m] / 2 + 63) / 64;
       ebase[m] = (int)eps.size();
@@ -422,6 +433,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
         eps.push_back(std::sqrt((double)(n * n - m * m) / (double)(4 * n * n - 1)));
     }
     P.p_elems = poff;
+    P.pt_elems = ptoff;
     P.wrows_total = P.wbase[N + 1];
   }
   std::vector<int> rowm(P.wrows_total);
@@ -441,6 +453,13 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   }
   P.d_P = (double *)dP;
   P.dev_allocs.push_back(dP);
+  void *dPT = nullptr;
+  if (emi_dev_malloc(&dPT, (size_t)P.pt_elems * 8)) {
+    delete pp;
+    EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB for the transposed Legendre panels", P.pt_elems * 8.0 / (1 << 30));
+  }
+  P.d_PT = (double *)dPT;
+  P.dev_allocs.push_back(dPT);
   {
     std::atomic<int> bad{0};
     emi::parallel_for(N + 1, [&](int m) {
@@ -459,6 +478,13 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
         }
       }
       if (emi_h2d(P.d_P + P.offS[m], pan.data(), pan.size() * 8, 0)) bad = 1;
+      // transposed copy for the direct transform: [par][j][k], k fastest, zero padded
+      const int ldk = P.ldk[m], ndp = roundup(std::max(nd, 1), 8);
+      std::vector<double> pt((size_t)2 * ndp * ldk, 0.0);
+      for (int par = 0; par < 2; par++)
+        for (int k = 0; k < nk; k++)
+          for (int j = 0; j < nd; j++) pt[((size_t)par * ndp + j) * ldk + k] = pan[((size_t)par * nk + k) * ld + j];
+      if (emi_h2d(P.d_PT + P.offTS[m], pt.data(), pt.size() * 8, 0)) bad = 1;
       emi_stream_sync(0);
     });
     if (bad) {
@@ -467,20 +493,22 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
     }
   }
   // device tables
-  int *d_nloen, *d_nmen, *d_ndglu, *d_gpoff, *d_nasm0, *d_fbase, *d_wbase, *d_wrows, *d_rowm, *d_ebase, *d_ldp, *d_ltp, *d_ktp;
+  int *d_nloen, *d_nmen, *d_ndglu, *d_gpoff, *d_nasm0, *d_fbase, *d_wbase, *d_wrows, *d_rowm, *d_ebase, *d_ldp, *d_ltp, *d_ktp, *d_ldk;
   double *d_eps, *d_lapin, *d_rw, *d_racthe;
-  long long *d_offS, *d_offA;
+  long long *d_offS, *d_offA, *d_offTS, *d_offTA;
   if (upload(P.nloen, &d_nloen) || upload(P.nmen, &d_nmen) || upload(P.ndglu, &d_ndglu) || upload(P.gpoff, &d_gpoff) ||
       upload(P.nasm0, &d_nasm0) || upload(P.fbase, &d_fbase) || upload(P.wbase, &d_wbase) || upload(P.wrows, &d_wrows) ||
       upload(rowm, &d_rowm) || upload(ebase, &d_ebase) || upload(P.ldp, &d_ldp) || upload(P.lattile_pref, &d_ltp) ||
       upload(P.ktile_pref, &d_ktp) || upload(eps, &d_eps) || upload(lapin, &d_lapin) || upload(P.rw, &d_rw) ||
-      upload(P.racthe, &d_racthe) || upload(P.offS, &d_offS) || upload(P.offA, &d_offA)) {
+      upload(P.racthe, &d_racthe) || upload(P.offS, &d_offS) || upload(P.offA, &d_offA) || upload(P.offTS, &d_offTS) ||
+      upload(P.offTA, &d_offTA) || upload(P.ldk, &d_ldk)) {
     delete pp;
     return EMI_ERR_RUNTIME;
   }
   for (void *p : {(void *)d_nloen, (void *)d_nmen, (void *)d_ndglu, (void *)d_gpoff, (void *)d_nasm0, (void *)d_fbase, (void *)d_wbase,
                   (void *)d_wrows, (void *)d_rowm, (void *)d_ebase, (void *)d_ldp, (void *)d_ltp, (void *)d_ktp, (void *)d_eps,
-                  (void *)d_lapin, (void *)d_rw, (void *)d_racthe, (void *)d_offS, (void *)d_offA})
+                  (void *)d_lapin, (void *)d_rw, (void *)d_racthe, (void *)d_offS, (void *)d_offA, (void *)d_offTS, (void *)d_offTA,
+                  (void *)d_ldk})
     P.dev_allocs.push_back(p);
   EmiGeomDev &g = P.g;
   g.nsmax = N;
@@ -505,6 +533,10 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   g.offS = d_offS;
   g.offA = d_offA;
   g.ldp = d_ldp;
+  g.PT = P.d_PT;
+  g.offTS = d_offTS;
+  g.offTA = d_offTA;
+  g.ldk = d_ldk;
   g.lattile_pref = d_ltp;
   g.ktile_pref = d_ktp;
   int rc = build_fft_plans(P);

@@ -30,6 +30,9 @@ struct EmiGeomDev {
   const double *P;             // Legendre panels
   const long long *offS, *offA;  // [nsmax+1] element offsets of the even/odd (n-m) panels
   const int *ldp;              // [nsmax+1] padded latitude count (multiple of 64)
+  const double *PT;            // transposed panels for the direct transform: [par][lat j][k], k fastest
+  const long long *offTS, *offTA;  // [nsmax+1]
+  const int *ldk;              // [nsmax+1] padded k count (multiple of 64)
   const int *lattile_pref;     // [nsmax+2] prefix of ceil(ndglu/64)
   const int *ktile_pref;       // [nsmax+2] prefix of ceil((wrows/2)/64)
 };
@@ -356,7 +359,6 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
   int t2 = (int)(tile / ncoltiles);
   const int m = upper_m(g.ktile_pref, g.nsmax, t2);
   const int kt = t2 - g.ktile_pref[m];
-  const int ld = g.ldp[m];
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int ndglu = g.ndglu[m] < g.ndgnh ? g.ndglu[m] : g.ndgnh;
@@ -370,15 +372,19 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  const int arow = tid >> 2, ac2 = tid & 3;
-  const bool aok = (k0 + arow) < nkpad;
-  const double *pS = g.P + g.offS[m] + (long long)(k0 + arow) * ld + 2 * ac2;
-  const double *pA = g.P + g.offA[m] + (long long)(k0 + arow) * ld + 2 * ac2;
+  // P^T tile: 8 latitudes x 64 k per parity, k contiguous in HBM (coalesced 512-B rows) and in LDS
+  const int arow = tid >> 5, ac2 = tid & 31;
+  const int ldk = g.ldk[m];
+  const double *pS = g.PT + g.offTS[m] + (long long)arow * ldk + k0 + 2 * ac2;
+  const double *pA = g.PT + g.offTA[m] + (long long)arow * ldk + k0 + 2 * ac2;
+  const long long stepA = 8LL * ldk;
   const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow and brow+4 of each 8-row stage
   const double *FBc = FB + col0 + 2 * bc2;
-  d2 ra0, ra1, rn0, rn1, rs0, rs1;
-  // FB row numbers (fbase[lat]+m) are fetched one stage ahead of the FB loads that use them, so
-  // the two dependent global loads never sit in the same prefetch window.
+  d2 ra0, ra1, rn0, rn1, rs0, rs1;     // stage s+1 (written to LDS at the top of the next iteration)
+  d2 qn0, qn1, qs0, qs1;               // stage s+2 (FB rows only: their latency is the long one)
+  // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
+  // kernels), so each stage touches 16 far-apart rows: they are prefetched TWO stages ahead and
+  // their row numbers (fbase[lat]+m) one stage earlier still.
   long long in0, in1, is0, is1;
 #define LEGDIR_ROWS(s_)                                                            \
   {                                                                                \
@@ -393,33 +399,38 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
       is1 = (long long)g.fbase[g.ndgl - 1 - isl0 - j1_] + m;                       \
     }                                                                              \
   }
-#define LEGDIR_LOAD(s_)                                                            \
+#define LEGDIR_LOADB(n0_, s0_, n1_, s1_)                                           \
   {                                                                                \
-    ra0 = aok ? *(const d2 *)(pS + 8 * (s_)) : mk2(0, 0);                          \
-    ra1 = aok ? *(const d2 *)(pA + 8 * (s_)) : mk2(0, 0);                          \
-    rn0 = in0 >= 0 ? *(const d2 *)(FBc + in0 * ldf) : mk2(0, 0);                   \
-    rs0 = is0 >= 0 ? *(const d2 *)(FBc + is0 * ldf) : mk2(0, 0);                   \
-    rn1 = in1 >= 0 ? *(const d2 *)(FBc + in1 * ldf) : mk2(0, 0);                   \
-    rs1 = is1 >= 0 ? *(const d2 *)(FBc + is1 * ldf) : mk2(0, 0);                   \
+    n0_ = in0 >= 0 ? *(const d2 *)(FBc + in0 * ldf) : mk2(0, 0);                   \
+    s0_ = is0 >= 0 ? *(const d2 *)(FBc + is0 * ldf) : mk2(0, 0);                   \
+    n1_ = in1 >= 0 ? *(const d2 *)(FBc + in1 * ldf) : mk2(0, 0);                   \
+    s1_ = is1 >= 0 ? *(const d2 *)(FBc + is1 * ldf) : mk2(0, 0);                   \
   }
   LEGDIR_ROWS(0);
-  LEGDIR_LOAD(0);
+  LEGDIR_LOADB(rn0, rs0, rn1, rs1);
+  ra0 = *(const d2 *)pS;
+  ra1 = *(const d2 *)pA;
   LEGDIR_ROWS(1);
+  LEGDIR_LOADB(qn0, qs0, qn1, qs1);
+  LEGDIR_ROWS(2);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
-    // transpose the P tile: As[par][kk = latitude in stage][k index]
-    As[(0 * 8 + 2 * ac2) * LG_LDA + arow] = ra0.x;
-    As[(0 * 8 + 2 * ac2 + 1) * LG_LDA + arow] = ra0.y;
-    As[(1 * 8 + 2 * ac2) * LG_LDA + arow] = ra1.x;
-    As[(1 * 8 + 2 * ac2 + 1) * LG_LDA + arow] = ra1.y;
+    *(d2 *)(As + (0 * 8 + arow) * LG_LDA + 2 * ac2) = ra0;  // As[par][kk = latitude in stage][k index]
+    *(d2 *)(As + (1 * 8 + arow) * LG_LDA + 2 * ac2) = ra1;
     *(d2 *)(Bs + (0 * 8 + brow) * LG_LDB + 2 * bc2) = cadd(rn0, rs0);      // symmetric part
     *(d2 *)(Bs + (1 * 8 + brow) * LG_LDB + 2 * bc2) = csub(rn0, rs0);      // antisymmetric part
     *(d2 *)(Bs + (0 * 8 + brow + 4) * LG_LDB + 2 * bc2) = cadd(rn1, rs1);
     *(d2 *)(Bs + (1 * 8 + brow + 4) * LG_LDB + 2 * bc2) = csub(rn1, rs1);
     EMI_SYNC();
+    // rotate: stage s+1 <- stage s+2 registers, then issue stage s+3's... (s+2 already in flight)
+    rn0 = qn0; rs0 = qs0; rn1 = qn1; rs1 = qs1;
     if (s + 1 < nst) {
-      LEGDIR_LOAD(s + 1);
-      LEGDIR_ROWS(s + 2);
+      ra0 = *(const d2 *)(pS + (s + 1) * stepA);
+      ra1 = *(const d2 *)(pA + (s + 1) * stepA);
+    }
+    if (s + 2 < nst) {
+      LEGDIR_LOADB(qn0, qs0, qn1, qs1);  // rows of stage s+2 (numbers fetched last iteration)
+      LEGDIR_ROWS(s + 3);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -435,8 +446,8 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
         for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
     }
   }
+#undef LEGDIR_LOADB
 #undef LEGDIR_ROWS
-#undef LEGDIR_LOAD
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll

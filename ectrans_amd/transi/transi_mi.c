@@ -1,0 +1,236 @@
+/* transi_mi.c -- see transi_mi.h.  Thin marshalling onto include/ectrans_mi.h. */
+#include "transi_mi.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/ectrans_mi.h"
+
+static int g_limit = 100;
+static double g_radius = 6371.22e3;
+static int g_init = 0;
+static char g_msg[1200];
+
+const char *trans_error_msg(int errcode) {
+  switch (errcode) {
+    case TRANS_SUCCESS: return "Trans: No error";
+    case TRANS_NOTIMPL: return "Trans: Not (yet) implemented";
+    case TRANS_MISSING_ARG: return "Trans: Required member of the argument structure is missing or not allocated";
+    case TRANS_UNRECOGNIZED_ARG: return "Trans: Unrecognized argument";
+    case TRANS_STALE_ARG: return "Trans: Passed argument was already used in a previous call";
+    default:
+      strcpy(g_msg, "Trans: ");
+      strncat(g_msg, emi_last_error(), sizeof(g_msg) - 16);
+      return g_msg;
+  }
+}
+
+int trans_use_mpi(_bool b) { return b ? TRANS_NOTIMPL : TRANS_SUCCESS; }
+int trans_set_handles_limit(int n) {
+  if (g_init) return TRANS_ERROR;
+  g_limit = n;
+  return TRANS_SUCCESS;
+}
+int trans_set_radius(double r) {
+  if (g_init) return TRANS_ERROR;
+  g_radius = r;
+  return TRANS_SUCCESS;
+}
+
+int trans_init(void) {
+  if (g_init) return TRANS_SUCCESS;
+  emi_init_t cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.kmax_resol = g_limit;
+  cfg.prad = g_radius;
+  cfg.nproc = 1;
+  cfg.myproc = 1;
+  cfg.device = -1;
+  if (emi_init(&cfg) != 0) return TRANS_ERROR;
+  g_init = 1;
+  return TRANS_SUCCESS;
+}
+
+int trans_new(struct Trans_t *t) {
+  memset(t, 0, sizeof(*t));
+  t->nsmax = -1;
+  t->lsplit = 1;
+  t->flt = -1;
+  return TRANS_SUCCESS;
+}
+
+int trans_set_resol(struct Trans_t *t, int ndgl, const int *nloen) {
+  t->ndgl = ndgl;
+  free(t->nloen);
+  t->nloen = (int *)malloc(sizeof(int) * (size_t)ndgl);
+  if (!t->nloen) return TRANS_ERROR;
+  memcpy(t->nloen, nloen, sizeof(int) * (size_t)ndgl);
+  return TRANS_SUCCESS;
+}
+
+int trans_set_trunc(struct Trans_t *t, int nsmax) {
+  t->nsmax = nsmax;
+  return TRANS_SUCCESS;
+}
+
+int trans_setup(struct Trans_t *t) {
+  int rc = trans_init();
+  if (rc) return rc;
+  if (t->ndgl <= 0 || (!t->nloen && t->nlon <= 0)) return TRANS_MISSING_ARG;
+  if (t->llatlon || t->flt > 0) return TRANS_NOTIMPL;
+  if (t->nsmax < 0) t->nsmax = t->ndgl - 1; /* default: linear truncation on the given latitudes */
+  emi_setup_t cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.ksmax = t->nsmax;
+  cfg.kdgl = t->ndgl;
+  cfg.kloen = t->nloen;
+  cfg.kdlon = t->nlon;
+  cfg.precision = 8;
+  if (emi_setup(&cfg, &t->handle) != 0) return TRANS_ERROR;
+  t->myproc = t->nproc = 1;
+  emi_inq_int(t->handle, "nspec2", &t->nspec2);
+  t->nspec = t->nspec2 / 2;
+  t->nspec2g = t->nspec2mx = t->nspec2;
+  emi_inq_int(t->handle, "nump", &t->nump);
+  emi_inq_int(t->handle, "ngptot", &t->ngptot);
+  t->ngptotg = t->ngptotmx = t->ngptot;
+  return TRANS_SUCCESS;
+}
+
+static int inq_one(struct Trans_t *t, const char *v) {
+  const int ns = t->nsmax + 1;
+  if (!strcmp(v, "rmu") || !strcmp(v, "rgw")) {
+    double **dst = !strcmp(v, "rmu") ? &t->rmu : &t->rgw;
+    if (!*dst) *dst = (double *)malloc(sizeof(double) * (size_t)t->ndgl);
+    return emi_inq_real_array(t->handle, v, *dst, t->ndgl) ? TRANS_ERROR : TRANS_SUCCESS;
+  }
+  struct {
+    const char *name, *emi;
+    int **dst;
+    int len;
+  } ints[] = {{"nasm0", "nasm0", &t->nasm0, ns}, {"nmyms", "myms", &t->nmyms, ns}, {"ndglu", "ndglu", &t->ndglu, ns},
+              {"nnmeng", "nmen", &t->nnmeng, t->ndgl}, {"nmeng", "nmen", &t->nnmeng, t->ndgl}};
+  for (size_t i = 0; i < sizeof(ints) / sizeof(ints[0]); i++)
+    if (!strcmp(v, ints[i].name)) {
+      if (!*ints[i].dst) *ints[i].dst = (int *)malloc(sizeof(int) * (size_t)ints[i].len);
+      return emi_inq_int_array(t->handle, ints[i].emi, *ints[i].dst, ints[i].len) ? TRANS_ERROR : TRANS_SUCCESS;
+    }
+  if (!strcmp(v, "nvalue")) {
+    if (!t->nvalue) t->nvalue = (int *)malloc(sizeof(int) * (size_t)t->nspec2);
+    int k = 0;
+    for (int m = 0; m <= t->nsmax; m++)
+      for (int n = m; n <= t->nsmax; n++) {
+        t->nvalue[k++] = n;
+        t->nvalue[k++] = n;
+      }
+    return TRANS_SUCCESS;
+  }
+  if (!strcmp(v, "nloen")) return TRANS_SUCCESS; /* input, already there */
+  return TRANS_UNRECOGNIZED_ARG;
+}
+
+int trans_inquire(struct Trans_t *t, const char *varlist) {
+  if (!t || !t->handle) return TRANS_MISSING_ARG;
+  char buf[512];
+  strncpy(buf, varlist, sizeof(buf) - 1);
+  buf[sizeof(buf) - 1] = 0;
+  for (char *tok = strtok(buf, ", "); tok; tok = strtok(NULL, ", ")) {
+    int rc = inq_one(t, tok);
+    if (rc) return rc;
+  }
+  return TRANS_SUCCESS;
+}
+
+struct DirTrans_t new_dirtrans(struct Trans_t *t) {
+  struct DirTrans_t d;
+  memset(&d, 0, sizeof(d));
+  d.trans = t;
+  return d;
+}
+
+int trans_dirtrans(struct DirTrans_t *d) {
+  if (d->count++ > 0) return TRANS_STALE_ARG;
+  if (!d->trans || !d->rgp) return TRANS_MISSING_ARG;
+  if (d->nscalar > 0 && !d->rspscalar) return TRANS_MISSING_ARG;
+  if (d->nvordiv > 0 && (!d->rspvor || !d->rspdiv)) return TRANS_MISSING_ARG;
+  if (d->lglobal || d->rmeanu || d->rmeanv) return TRANS_NOTIMPL;
+  emi_dirtrans_t a;
+  memset(&a, 0, sizeof(a));
+  a.mem_space = EMI_MEM_HOST;
+  if (d->nvordiv > 0) {
+    a.spvor = d->rspvor;
+    a.spdiv = d->rspdiv;
+    a.nf_uv = d->nvordiv;
+  }
+  if (d->nscalar > 0) {
+    a.spscalar = d->rspscalar;
+    a.nf_scalar = d->nscalar;
+  }
+  a.kproma = d->nproma > 0 ? d->nproma : d->trans->ngptot;
+  a.gp = d->rgp;
+  a.gp_nfld = 2 * d->nvordiv + d->nscalar;
+  return emi_dir_trans(d->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+
+struct InvTrans_t new_invtrans(struct Trans_t *t) {
+  struct InvTrans_t v;
+  memset(&v, 0, sizeof(v));
+  v.trans = t;
+  return v;
+}
+
+int trans_invtrans(struct InvTrans_t *v) {
+  if (v->count++ > 0) return TRANS_STALE_ARG;
+  if (!v->trans || !v->rgp) return TRANS_MISSING_ARG;
+  if (v->nscalar > 0 && !v->rspscalar) return TRANS_MISSING_ARG;
+  if (v->nvordiv > 0 && (!v->rspvor || !v->rspdiv)) return TRANS_MISSING_ARG;
+  if (v->lglobal || v->rmeanu || v->rmeanv) return TRANS_NOTIMPL;
+  emi_invtrans_t a;
+  memset(&a, 0, sizeof(a));
+  a.mem_space = EMI_MEM_HOST;
+  if (v->nvordiv > 0) {
+    a.spvor = v->rspvor;
+    a.spdiv = v->rspdiv;
+    a.nf_uv = v->nvordiv;
+  }
+  if (v->nscalar > 0) {
+    a.spscalar = v->rspscalar;
+    a.nf_scalar = v->nscalar;
+  }
+  a.ldscders = v->lscalarders;
+  a.lduvder = v->luvder_EW;
+  a.ldvorgp = a.lddivgp = v->lvordivgp;
+  a.kproma = v->nproma > 0 ? v->nproma : v->trans->ngptot;
+  a.gp = v->rgp;
+  a.gp_nfld = 2 * v->nvordiv + v->nscalar + (v->lscalarders ? 2 * v->nscalar : 0) + (v->lvordivgp ? 2 * v->nvordiv : 0) +
+              (v->luvder_EW ? 2 * v->nvordiv : 0);
+  return emi_inv_trans(v->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+
+struct SpecNorm_t new_specnorm(struct Trans_t *t) {
+  struct SpecNorm_t s;
+  memset(&s, 0, sizeof(s));
+  s.trans = t;
+  s.nmaster = 1;
+  return s;
+}
+
+int trans_specnorm(struct SpecNorm_t *s) {
+  if (s->count++ > 0) return TRANS_STALE_ARG;
+  if (!s->trans || !s->rspec || !s->rnorm || s->nfld <= 0) return TRANS_MISSING_ARG;
+  if (s->rmet) return TRANS_NOTIMPL;
+  return emi_specnorm(s->trans->handle, EMI_MEM_HOST, s->rspec, s->nfld, s->rnorm) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+
+int trans_delete(struct Trans_t *t) {
+  int rc = TRANS_SUCCESS;
+  if (t->handle) rc = emi_release(t->handle) ? TRANS_ERROR : TRANS_SUCCESS;
+  free(t->nloen), free(t->nmyms), free(t->nasm0), free(t->nvalue), free(t->ndglu), free(t->nnmeng), free(t->rmu), free(t->rgw);
+  memset(t, 0, sizeof(*t));
+  return rc;
+}
+
+int trans_finalize(void) {
+  g_init = 0;
+  return emi_finalize() ? TRANS_ERROR : TRANS_SUCCESS;
+}

@@ -1,0 +1,107 @@
+/*
+ * transi_mi.h -- transi-style C API (struct Trans_t / DirTrans_t / InvTrans_t / SpecNorm_t and
+ * trans_* functions) over libectrans_mi.so, source compatible with the hot-path subset of the
+ * reference's C interface (/root/reference/src/transi/transi.h:110-685 functions, :701-1240
+ * structs).  Same names, same field names, same array layouts
+ * (rgp[ngpblks][nfld][nproma], rsp[nspec2][nfld], transi.h:908-921), same return convention
+ * (TRANS_SUCCESS = 0, negative error codes, trans_error_msg()).
+ *
+ * Not provided (outside SURVEY.md section 8): distgrid/gathgrid/distspec/gathspec, vordiv_to_UV,
+ * adjoints, LAM, lonlat, legendre-cache I/O, lglobal != 0, rmeanu/rmeanv.  They return
+ * TRANS_NOTIMPL instead of being silently ignored.
+ */
+#ifndef TRANSI_MI_H
+#define TRANSI_MI_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int _bool;
+
+#define TRANS_SUCCESS 0
+#define TRANS_ERROR (-1)
+#define TRANS_NOTIMPL (-2)
+#define TRANS_MISSING_ARG (-3)
+#define TRANS_UNRECOGNIZED_ARG (-4)
+#define TRANS_STALE_ARG (-5)
+
+struct Trans_t {
+  /* inputs */
+  int ndgl;   /* number of latitudes */
+  int *nloen; /* [ndgl] points per latitude */
+  int nlon;   /* points per latitude of a regular grid (when nloen == NULL) */
+  int nsmax;  /* spectral truncation */
+  _bool lsplit;
+  int llatlon; /* must stay 0 */
+  int flt;     /* <= 0: Fast Legendre Transform not requested (the only supported setting) */
+  /* filled by trans_setup */
+  int myproc, nproc;
+  int handle; /* KRESOL */
+  int nspec, nspec2, nspec2g, nspec2mx, nump;
+  int ngptot, ngptotg, ngptotmx;
+  /* filled on demand by trans_inquire("name,name,...") */
+  int *nmyms;   /* [nump] */
+  int *nasm0;   /* [0:nsmax], 1-based addresses as in Fortran */
+  int *nvalue;  /* [nspec2] n of every coefficient */
+  int *ndglu;   /* [0:nsmax] */
+  int *nnmeng;  /* [ndgl] NMEN per latitude */
+  double *rmu;  /* [ndgl] sin(latitude) */
+  double *rgw;  /* [ndgl] Gaussian weights (sum = 1) */
+};
+
+struct DirTrans_t {
+  const double *rgp;  /* [ngpblks][2*nvordiv+nscalar][nproma]: u, v, scalars */
+  double *rspscalar;  /* [nspec2][nscalar] */
+  double *rspvor;     /* [nspec2][nvordiv] */
+  double *rspdiv;     /* [nspec2][nvordiv] */
+  const double *rmeanu, *rmeanv; /* LAM only: must stay NULL */
+  int nproma, nscalar, nvordiv, ngpblks, lglobal;
+  struct Trans_t *trans;
+  int count; /* a DirTrans_t is single use, as in the reference (transi_module.F90:1661-1666) */
+};
+
+struct InvTrans_t {
+  const double *rspscalar, *rspvor, *rspdiv;
+  const double *rmeanu, *rmeanv;
+  double *rgp; /* [ngpblks][nfld][nproma]: [vor div] u v scalars [NS-ders] [u_EW v_EW] [sc_EW] */
+  int nproma, nscalar, nvordiv;
+  int lscalarders, luvder_EW, lvordivgp;
+  int ngpblks, lglobal;
+  struct Trans_t *trans;
+  int count;
+};
+
+struct SpecNorm_t {
+  const double *rspec; /* [nspec2][nfld] */
+  int nmaster;
+  const double *rmet; /* must stay NULL */
+  double *rnorm;      /* [nfld] */
+  int nfld;
+  struct Trans_t *trans;
+  int count;
+};
+
+const char *trans_error_msg(int errcode);
+int trans_use_mpi(_bool);          /* only false is meaningful: one task per GPU */
+int trans_set_handles_limit(int);  /* default 100 (transi_module.F90:129-136) */
+int trans_set_radius(double);      /* default 6371.22e3 (transi's own default) */
+int trans_init(void);
+int trans_new(struct Trans_t *);
+int trans_set_resol(struct Trans_t *, int ndgl, const int *nloen);
+int trans_set_trunc(struct Trans_t *, int nsmax);
+int trans_setup(struct Trans_t *);
+int trans_inquire(struct Trans_t *, const char *varlist);
+struct DirTrans_t new_dirtrans(struct Trans_t *);
+int trans_dirtrans(struct DirTrans_t *);
+struct InvTrans_t new_invtrans(struct Trans_t *);
+int trans_invtrans(struct InvTrans_t *);
+struct SpecNorm_t new_specnorm(struct Trans_t *);
+int trans_specnorm(struct SpecNorm_t *);
+int trans_delete(struct Trans_t *);
+int trans_finalize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
