@@ -1171,7 +1171,7 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     {
       const int nct = ldw / LG_BN;
       long long ntiles = (long long)P.ktile_pref[P.nsmax + 1] * nct;
-      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_FB, ldw, P.d_W, ldw, ntiles);
+      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, st, P.g, nct, (const double *)P.d_FB, ldw, P.d_W, ldw, ntiles);
     }
     g_pt.mark(1);
     {

@@ -383,36 +383,34 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
   d2 ra0, ra1, rn0, rn1, rs0, rs1;     // stage s+1 (written to LDS at the top of the next iteration)
   d2 qn0, qn1, qs0, qs1;               // stage s+2 (FB rows only: their latency is the long one)
   // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
-  // kernels), so each stage touches 16 far-apart rows: they are prefetched TWO stages ahead and
-  // their row numbers (fbase[lat]+m) one stage earlier still.
-  long long in0, in1, is0, is1;
-#define LEGDIR_ROWS(s_)                                                            \
-  {                                                                                \
-    int j0_ = 8 * (s_) + brow, j1_ = j0_ + 4;                                      \
-    in0 = in1 = is0 = is1 = -1;                                                    \
-    if (j0_ < ndglu) {                                                             \
-      in0 = (long long)g.fbase[isl0 + j0_] + m;                                    \
-      is0 = (long long)g.fbase[g.ndgl - 1 - isl0 - j0_] + m;                       \
-    }                                                                              \
-    if (j1_ < ndglu) {                                                             \
-      in1 = (long long)g.fbase[isl0 + j1_] + m;                                    \
-      is1 = (long long)g.fbase[g.ndgl - 1 - isl0 - j1_] + m;                       \
-    }                                                                              \
+  // kernels), so each stage touches 16 far-apart rows: they are prefetched TWO stages ahead.  Their
+  // row numbers (fbase[lat]+m) are staged once per tile in LDS, so that looking them up is an LDS
+  // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
+  int *rowN = (int *)(Bs + 2 * 8 * LG_LDB);
+  int *rowS = rowN + ((g.ndgnh + 8) & ~7);
+  for (int j = tid; j < 8 * nst; j += LG_THREADS) {
+    int rn_ = -1, rs_ = -1;
+    if (j < ndglu) {
+      rn_ = g.fbase[isl0 + j] + m;
+      rs_ = g.fbase[g.ndgl - 1 - isl0 - j] + m;
+    }
+    rowN[j] = rn_;
+    rowS[j] = rs_;
   }
-#define LEGDIR_LOADB(n0_, s0_, n1_, s1_)                                           \
+  EMI_SYNC();
+#define LEGDIR_LOADB(s_, n0_, s0_, n1_, s1_)                                       \
   {                                                                                \
-    n0_ = in0 >= 0 ? *(const d2 *)(FBc + in0 * ldf) : mk2(0, 0);                   \
-    s0_ = is0 >= 0 ? *(const d2 *)(FBc + is0 * ldf) : mk2(0, 0);                   \
-    n1_ = in1 >= 0 ? *(const d2 *)(FBc + in1 * ldf) : mk2(0, 0);                   \
-    s1_ = is1 >= 0 ? *(const d2 *)(FBc + is1 * ldf) : mk2(0, 0);                   \
+    const int j0_ = 8 * (s_) + brow;                                               \
+    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + 4], is1 = rowS[j0_ + 4]; \
+    n0_ = in0 >= 0 ? *(const d2 *)(FBc + (long long)in0 * ldf) : mk2(0, 0);        \
+    s0_ = is0 >= 0 ? *(const d2 *)(FBc + (long long)is0 * ldf) : mk2(0, 0);        \
+    n1_ = in1 >= 0 ? *(const d2 *)(FBc + (long long)in1 * ldf) : mk2(0, 0);        \
+    s1_ = is1 >= 0 ? *(const d2 *)(FBc + (long long)is1 * ldf) : mk2(0, 0);        \
   }
-  LEGDIR_ROWS(0);
-  LEGDIR_LOADB(rn0, rs0, rn1, rs1);
+  LEGDIR_LOADB(0, rn0, rs0, rn1, rs1);
   ra0 = *(const d2 *)pS;
   ra1 = *(const d2 *)pA;
-  LEGDIR_ROWS(1);
-  LEGDIR_LOADB(qn0, qs0, qn1, qs1);
-  LEGDIR_ROWS(2);
+  if (nst > 1) LEGDIR_LOADB(1, qn0, qs0, qn1, qs1);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
     *(d2 *)(As + (0 * 8 + arow) * LG_LDA + 2 * ac2) = ra0;  // As[par][kk = latitude in stage][k index]
@@ -422,16 +420,12 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
     *(d2 *)(Bs + (0 * 8 + brow + 4) * LG_LDB + 2 * bc2) = cadd(rn1, rs1);
     *(d2 *)(Bs + (1 * 8 + brow + 4) * LG_LDB + 2 * bc2) = csub(rn1, rs1);
     EMI_SYNC();
-    // rotate: stage s+1 <- stage s+2 registers, then issue stage s+3's... (s+2 already in flight)
-    rn0 = qn0; rs0 = qs0; rn1 = qn1; rs1 = qs1;
+    rn0 = qn0; rs0 = qs0; rn1 = qn1; rs1 = qs1;  // stage s+1 <- registers of stage s+2 (in flight)
     if (s + 1 < nst) {
       ra0 = *(const d2 *)(pS + (s + 1) * stepA);
       ra1 = *(const d2 *)(pA + (s + 1) * stepA);
     }
-    if (s + 2 < nst) {
-      LEGDIR_LOADB(qn0, qs0, qn1, qs1);  // rows of stage s+2 (numbers fetched last iteration)
-      LEGDIR_ROWS(s + 3);
-    }
+    if (s + 2 < nst) LEGDIR_LOADB(s + 2, qn0, qs0, qn1, qs1);
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const int kk = 4 * ks + (l >> 4);
@@ -447,7 +441,6 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
     }
   }
 #undef LEGDIR_LOADB
-#undef LEGDIR_ROWS
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
