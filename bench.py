@@ -10,10 +10,11 @@ over device-resident synthetic fields: nlev levels of (vor,div), nfld x nlev 3-D
 Default workload = BASELINE.json's metric config: TCo1279 (O1280), 137 levels x 10 fields
 (KF = 2*137 + 10*137 + 1 = 1645 Fourier-space fields), fp64, inputs resident in HBM.
 
-N > 1: the zonal-wavenumber/latitude sharding with the RCCL all-to-all is row 8(e) of the scope
-table and is not built yet; until then `--gpus N` runs N independent replicas of the 1-GPU
-workload (weak scaling over independent field sets, i.e. the reference's V-set decomposition,
-which needs no exchange) -- DESIGN.md section 7.
+N > 1 (one rank per GPU, launched by torch.distributed.run): the SAME global workload is sharded the
+way the reference shards it over its W-sets -- zonal wavenumbers zig-zag over ranks, latitudes in
+contiguous bands -- with one RCCL all-to-all-v of the device-resident Fourier buffer per direction
+(DESIGN.md section 7).  Total work is fixed, so "scaling" is "strong" and `value` is the pairs/s
+of the whole job.
 
 Prints ONE JSON line on rank 0.
 """
@@ -93,23 +94,25 @@ def main():
     import ectrans_amd as et
     N, nlev, nfld = args.nsmax, args.nlev, args.nfld
     kf = 2 * nlev + nfld * nlev + 1
-    et.setup_trans0(kmax_resol=2, device=local)
+    et.setup_trans0(kmax_resol=2, device=local, kprtrw=world, myproc=rank + 1)
     if args.max_batch:
         et.set_max_batch(args.max_batch)
     t0 = time.time()
     r = et.setup_trans(N, 2 * (N + 1), octahedral(N))
     t_setup = time.time() - t0
-    nspec2, ngptot = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
-    i419 = int(et.trans_inq(r, "nasm0")[4] - 1 + 2 * (19 - 4))
+    nspec2, ngptot = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")  # this rank's share
+    a4 = int(et.trans_inq(r, "nasm0")[4])
+    i419 = a4 - 1 + 2 * (19 - 4) if a4 > 0 else None  # only the rank owning m=4 holds the harmonic
 
     def z(*shape):
         return torch.zeros(shape, dtype=torch.float64, device=dev)
 
     # call mode 2 arrays of the reference harness (ectrans-benchmark.F90:450-479)
     spvor, spdiv, spsc3a, spsc2 = z(nspec2, nlev), z(nspec2, nlev), z(nfld, nspec2, nlev), z(nspec2, 1)
-    for a in (spvor, spdiv, spsc2):
-        a[i419] = 1.0
-    spsc3a[:, i419] = 1.0
+    if i419 is not None:
+        for a in (spvor, spdiv, spsc2):
+            a[i419] = 1.0
+        spsc3a[:, i419] = 1.0
     gpuv, gp3a, gp2 = z(1, 2, nlev, ngptot), z(1, nfld, nlev, ngptot), z(1, 1, ngptot)
     n0 = et.specnorm(r, spsc2)[0]
 
@@ -145,37 +148,46 @@ def main():
         leg_ms += ms[1]
         fft_ms += ms[2]
         leg_launches += ln[1]
+    wm = et.work_model(r, kf)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # whole-job Legendre rate: flops of all ranks / slowest rank's kernel time
+        red = torch.tensor([wm["legendre_flops"], wm["fourier_bytes"], float(ngptot)], dtype=torch.float64, device=dev)
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        mx = torch.tensor([leg_ms, fft_ms, pack_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        wm["legendre_flops"], wm["fourier_bytes"], ngptot = float(red[0]), float(red[1]), int(red[2].item())
+        leg_ms, fft_ms, pack_ms = (float(x) for x in mx)
     n1 = et.specnorm(r, spsc2)[0]
-    wm = et.work_model(r, kf)
 
     if rank == 0:
+        # per launch: algorithmic flops of the launch (all ranks) / average launch duration (slowest rank)
         flops_per_launch = wm["legendre_flops"] * 2 * args.steps / max(leg_launches, 1)
         ms_per_launch = leg_ms / max(leg_launches, 1)
         ach = flops_per_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
         out = {
             "metric": "dir+inv transform-pairs/sec, TCo%d %dL x %d fields; spectral-norm rel-error" % (N, nlev, nfld),
-            "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "TCo%d/O%d, %d levels x %d 3-D fields + vor/div + 1 surface field, KF=%d, "
                                    "device-resident call-mode-2 arrays" % (N, N + 1, nlev, nfld, kf),
-                       "parallelism": "1 GPU" if world == 1 else "%d independent replicas (no exchange)" % world,
+                       "parallelism": "1 GPU" if world == 1 else
+                       "%d GPUs: zonal wavenumbers zig-zag + latitude bands, RCCL all-to-all-v per direction" % world,
                        "setup_s": round(t_setup, 2)},
             "spectral_norm_rel_error": abs(n0 / n1 - 1.0),
             "roofline": {"bound": "mfma", "kernel": "k_leg_inv + k_leg_dir (fp64 MFMA Legendre transforms)",
-                         "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                         "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": ach / (PEAK_F64_MFMA_TFLOPS * world), "traffic": None,
                          "launches": leg_launches, "avg_launch_ms": ms_per_launch,
                          "algorithmic_flops_per_launch": flops_per_launch},
             "phase_ms_per_step": {"spectral_pack_unpack": pack_ms / args.steps, "legendre_mfma": leg_ms / args.steps,
                                   "fft": fft_ms / args.steps},
             "fft_hbm": {"algorithmic_GB_per_step": 2 * (wm["fourier_bytes"] + kf * ngptot * 8.0) / 1e9,
                         "achieved_GBps": 2 * (wm["fourier_bytes"] + kf * ngptot * 8.0) / 1e9 / max(fft_ms / args.steps * 1e-3, 1e-9),
-                        "peak_GBps": 8000.0},
+                        "peak_GBps": 8000.0 * world},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, kf)

@@ -93,6 +93,8 @@ def _bind(L):
     L.emi_work_model.argtypes = [C.c_int, C.c_int, dp, dp, dp]
     L.emi_last_phase_ms.argtypes = [dp]
     L.emi_set_max_batch.argtypes = [C.c_int]
+    L.emi_specnorm_partial.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, dp]
+    L.emi_set_alltoallv.argtypes = [C.c_void_p, C.c_void_p]
     L.emi_set_profile.argtypes = [C.c_int]
     L.emi_last_phase_launches.argtypes = [ip]
     return L
@@ -146,12 +148,28 @@ def _ptr(a, space):
     return a.ctypes.data, a
 
 
-def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, **unsupported):
-    """SETUP_TRANS0 (setup_trans0.h:12-89).  LDMPOFF-style single-task setup."""
+_DIST = {"nproc": 1, "group": None, "device": None}
+
+
+def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, myproc=1, group=None, alltoallv=None,
+                 **unsupported):
+    """SETUP_TRANS0 (setup_trans0.h:12-89).
+
+    kprtrw > 1: this process is task `myproc` (1-based) of a W-set of `kprtrw` tasks, one per GPU
+    (NPRTRV = NPRGPEW = 1); the all-to-all-v between them defaults to torch.distributed on `group`
+    (RCCL for CUDA devices, gloo on the CPU test tier) -- see ectrans_amd.dist."""
     for k, v in unsupported.items():
-        if k.lower() in ("kprgpns", "kprgpew", "kprtrw") and v not in (None, 1):
-            raise TransError("SETUP_TRANS0: %s=%r -- multi-task runs go through ectrans_amd.dist" % (k, v))
-    cfg = _Init(kmax_resol, kprintlev, prad if prad else 0.0, 1, 1, device)
+        if k.lower() in ("kprgpns", "kprgpew") and v not in (None, 1, kprtrw):
+            raise TransError("SETUP_TRANS0: %s=%r: only the W-set decomposition (KPRTRW tasks) is supported" % (k, v))
+    if kprtrw > 1:
+        from . import dist as _dist
+        dev = ("cuda:%d" % device) if device is not None and device >= 0 else "cpu"
+        hook = alltoallv if alltoallv is not None else _dist.make_alltoallv_hook(group, dev)
+        _chk(lib().emi_set_alltoallv(C.cast(hook, C.c_void_p), None))
+        _DIST.update(nproc=kprtrw, group=group, device=dev)
+    else:
+        _DIST.update(nproc=1, group=None, device=None)
+    cfg = _Init(kmax_resol, kprintlev, prad if prad else 0.0, kprtrw, myproc, device if device is not None else -1)
     _chk(lib().emi_init(C.byref(cfg)))
 
 
@@ -172,8 +190,10 @@ def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, ps
     return kresol.value
 
 
-_INT_SCALARS = ("nspec2", "nspec2g", "nspec", "ngptot", "ngptotg", "nump", "ndgl", "nsmax", "ndlon")
-_INT_ARRAYS = {"nloen": "ndgl", "nmen": "ndgl", "ndglu": "nsmax+1", "nasm0": "nsmax+1", "myms": "nsmax+1"}
+_INT_SCALARS = ("nspec2", "nspec2g", "nspec2mx", "nspec", "nspecg", "ngptot", "ngptotg", "ngptotmx", "nump", "ndgl",
+                "nsmax", "ndlon", "nproc", "myproc", "nfrstlat", "nlstlat")
+_INT_ARRAYS = {"nloen": "ndgl", "nmen": "ndgl", "ndglu": "nsmax+1", "nasm0": "nsmax+1", "myms": "nump",
+               "procm": "nsmax+1", "latlo": "nproc+1"}
 _REAL_ARRAYS = {"rmu": "ndgl", "pmu": "ndgl", "rgw": "ndgl", "pgw": "ndgl", "racthe": "ndgl"}
 
 
@@ -185,7 +205,8 @@ def trans_inq(kresol, name):
         v = C.c_int(0)
         _chk(L.emi_inq_int(kresol, name.encode(), C.byref(v)))
         return v.value
-    dims = {"ndgl": trans_inq(kresol, "ndgl"), "nsmax+1": trans_inq(kresol, "nsmax") + 1}
+    dims = {"ndgl": trans_inq(kresol, "ndgl"), "nsmax+1": trans_inq(kresol, "nsmax") + 1,
+            "nump": trans_inq(kresol, "nump"), "nproc+1": trans_inq(kresol, "nproc") + 1}
     if name in _INT_ARRAYS:
         out = np.zeros(dims[_INT_ARRAYS[name]], dtype=np.int32)
         _chk(L.emi_inq_int_array(kresol, name.encode(), out.ctypes.data_as(C.POINTER(C.c_int)), out.size))
@@ -278,12 +299,17 @@ def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
 
 
 def specnorm(kresol, pspec):
-    """SPECNORM (specnorm.h:12): per-field spectral L2 norm, returned as a numpy array."""
+    """SPECNORM (specnorm.h:12): per-field spectral L2 norm, returned as a numpy array (on every
+    task; the reference returns it on the master only)."""
     space = [None]
     p, keep = _ptr(pspec, space)
     out = np.zeros(pspec.shape[1])
-    _chk(lib().emi_specnorm(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
-    return out
+    if _DIST["nproc"] == 1:
+        _chk(lib().emi_specnorm(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+    from . import dist as _dist
+    _chk(lib().emi_specnorm_partial(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
+    return np.sqrt(_dist.all_reduce_sum(out, _DIST["group"], _DIST["device"]))
 
 
 def trans_release(kresol):
@@ -292,6 +318,7 @@ def trans_release(kresol):
 
 def trans_end():
     _chk(lib().emi_finalize())
+    _DIST.update(nproc=1, group=None, device=None)
 
 
 def work_model(kresol, nfields):

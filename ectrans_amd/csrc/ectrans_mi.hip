@@ -123,28 +123,38 @@ struct FftClass {
 
 struct Plan {
   bool active = false;
-  int nsmax = 0, ndgl = 0, ndgnh = 0, ngptot = 0, nspec2 = 0;
+  int nsmax = 0, ndgl = 0, ndgnh = 0;
   bool reduced = false;
   double ra = 6371229.0;
-  std::vector<int> nloen, nmen, ndglu, gpoff, nasm0, fbase, wbase, wrows, ldp, lattile_pref, ktile_pref;
-  std::vector<long long> offS, offA, offTS, offTA;
-  std::vector<int> ldk;
-  long long pt_elems = 0;
-  double *d_PT = nullptr;
+  // ---- global geometry (identical on every task)
+  std::vector<int> nloen, nmen, ndglu, procm;  // procm[m]: owning task (0-based) of wavenumber m
+  std::vector<int> latlo;                      // [nproc+1] latitude band of every task
   std::vector<double> rmu, rw, racthe, cos2;
-  long long frows = 0, wrows_total = 0, p_elems = 0;
+  int ngptotg = 0, nspec2g = 0;
+  // ---- this task's share
+  int nproc = 1, me = 0;
+  int nump = 0, nlat = 0, lat0 = 0;
+  int ngptot = 0, nspec2 = 0;
+  std::vector<int> mval, nasm0;            // [nump]
+  std::vector<int> l_nmen, l_gpoff, l_fbase;  // [nlat]
+  std::vector<int> wbase, wrows, ldp, ldk, lattile_pref, ktile_pref, lbase;
+  std::vector<long long> offS, offA, offTS, offTA;
+  long long frows = 0, lrows = 0, wrows_total = 0, p_elems = 0, pt_elems = 0;
+  // exchange (rows of the Fourier buffers per peer); inverse sends Legendre-side -> FFT-side
+  std::vector<long long> leg_rows, leg_disp, fft_rows, fft_disp;  // [nproc]
   // device
   EmiGeomDev g{};
   std::vector<void *> dev_allocs;
-  double *d_P = nullptr;
+  double *d_P = nullptr, *d_PT = nullptr;
   // fft
   std::vector<FftPlanDev> fplans;
-  std::vector<int> planid;
+  std::vector<int> planid;  // [nlat]
   FftTabDev ftab{};
   FftClass fclass[3];
-  // work buffers (grown on demand)
-  double *d_W = nullptr, *d_FB = nullptr;
-  size_t cap_W = 0, cap_FB = 0;
+  // work buffers (grown on demand): W, Legendre-side Fourier buffer, FFT-side Fourier buffer
+  // (the same allocation when nproc == 1)
+  double *d_W = nullptr, *d_FBL = nullptr, *d_FBF = nullptr;
+  size_t cap_W = 0, cap_FBL = 0, cap_FBF = 0;
   void *d_desc = nullptr;
   size_t cap_desc = 0;
 };
@@ -156,8 +166,9 @@ static struct {
   int nproc = 1, myproc = 1;
   std::vector<Plan *> plans;
   int max_batch = 0;
-  double phase_ms[3] = {0, 0, 0};
   bool profile = false;
+  emi_alltoallv_fn a2a = nullptr;
+  void *a2a_user = nullptr;
 } G;
 
 static Plan *get_plan(int kresol) {
@@ -174,7 +185,7 @@ extern "C" int emi_init(const emi_init_t *cfg) {
   G.ra = c.prad > 0 ? c.prad : 6371229.0;
   G.nproc = c.nproc > 0 ? c.nproc : 1;
   G.myproc = c.myproc > 0 ? c.myproc : 1;
-  if (G.nproc != 1) EMI_FAIL(EMI_ERR_UNSUPPORTED, "emi_init: nproc > 1 goes through ectrans_amd.dist (row 8e), not this entry point");
+  if (G.myproc > G.nproc) EMI_FAIL(EMI_ERR_ARG, "emi_init: myproc %d > nproc %d", G.myproc, G.nproc);
 #ifndef EMI_CPU_EMU
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -199,9 +210,9 @@ static int build_fft_plans(Plan &P) {
   std::map<int, int> idx;
   std::vector<d2> tw, rtw, chirp, bhat, ptw;
   std::vector<uint16_t> perm;
-  P.planid.assign(P.ndgl, 0);
-  for (int j = 0; j < P.ndgl; j++) {
-    int n = P.nloen[j];
+  P.planid.assign(P.nlat, 0);
+  for (int j = 0; j < P.nlat; j++) {  // local latitudes
+    int n = P.nloen[P.lat0 + j];
     auto it = idx.find(n);
     if (it != idx.end()) {
       P.planid[j] = it->second;
@@ -300,7 +311,7 @@ static int build_fft_plans(Plan &P) {
     P.fclass[c].lats.clear();
     P.fclass[c].lds = 0;
   }
-  for (int j = 0; j < P.ndgl; j++) {
+  for (int j = 0; j < P.nlat; j++) {
     const FftPlanDev &pl = P.fplans[P.planid[j]];
     FftClass &fc = P.fclass[pl.lds_class];
     fc.lats.push_back(j);
@@ -352,7 +363,17 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   P.ndgl = cfg->kdgl;
   P.ndgnh = (P.ndgl + 1) / 2;
   P.ra = G.ra;
-  const int N = P.nsmax, L = P.ndgl;
+  P.nproc = G.nproc;
+  P.me = G.myproc - 1;
+  const int N = P.nsmax, L = P.ndgl, NP = P.nproc, me = P.me;
+  if (NP > 1 && !G.a2a) {
+    delete pp;
+    EMI_FAIL(EMI_ERR_STATE, "SETUP_TRANS: %d tasks but no all-to-all-v hook registered (emi_set_alltoallv)", NP);
+  }
+  if (NP > L / 2 || NP > N + 1) {
+    delete pp;
+    EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: too many tasks (%d) for NDGL=%d, NSMAX=%d", NP, L, N);
+  }
   int ndlon = cfg->kdlon > 0 ? cfg->kdlon : 2 * L;
   P.nloen.assign(L, ndlon);
   if (cfg->kloen) {
@@ -369,20 +390,14 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
       if (cfg->kloen[j] != ndlon) P.reduced = true;
     }
   }
-  P.nspec2 = (N + 1) * (N + 2);
-  P.gpoff.assign(L, 0);
-  {
-    long long off = 0;
-    for (int j = 0; j < L; j++) {
-      P.gpoff[j] = (int)off;
-      off += P.nloen[j];
-    }
-    if (off > 2000000000LL) {
-      delete pp;
-      EMI_FAIL(EMI_ERR_UNSUPPORTED, "grid too large for 32-bit point offsets");
-    }
-    P.ngptot = (int)off;
+  P.nspec2g = (N + 1) * (N + 2);
+  std::vector<long long> cum(L + 1, 0);
+  for (int j = 0; j < L; j++) cum[j + 1] = cum[j] + P.nloen[j];
+  if (cum[L] > 2000000000LL) {
+    delete pp;
+    EMI_FAIL(EMI_ERR_UNSUPPORTED, "grid too large for 32-bit point offsets");
   }
+  P.ngptotg = (int)cum[L];
   // Gaussian latitudes / weights, cos^2, 1/(a cos)  (suleg_mod.F90:264-293, 386-394)
   emi::gauss_latitudes(L, P.rmu, P.rw);
   P.cos2.assign(L, 0.0);
@@ -393,78 +408,192 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
     P.racthe[j] = 1.0 / c / P.ra;
   }
   emi::wavenumber_cutoffs(N, L, P.nloen, P.reduced, P.cos2, P.nmen, P.ndglu);
-  // index tables
-  P.nasm0.assign(N + 1, 0);
-  P.wbase.assign(N + 2, 0);
-  P.wrows.assign(N + 1, 0);
-  P.ldp.assign(N + 1, 0);
-  P.offS.assign(N + 1, 0);
-  P.offA.assign(N + 1, 0);
-  P.offTS.assign(N + 1, 0);
-  P.offTA.assign(N + 1, 0);
-  P.ldk.assign(N + 1, 0);
-  P.lattile_pref.assign(N + 2, 0);
-  P.ktile_pref.assign(N + 2, 0);
-  std::vector<int> ebase(N + 1, 0);
-  std::vector<double> eps;
+
+  // ---- distribution over tasks
+  // wavenumbers: the reference's zig-zag W-set assignment (suwavedi_mod.F90:118-137)
+  P.procm.assign(N + 1, 0);
+  {
+    int ik = 0, ind = 1;
+    for (int m = 0; m <= N; m++) {
+      ik += ind;
+      if (ik > NP) {
+        ik = NP;
+        ind = -1;
+      } else if (ik < 1) {
+        ik = 1;
+        ind = 1;
+      }
+      P.procm[m] = ik - 1;
+    }
+  }
+  // latitudes: contiguous bands holding ~equal numbers of grid points (whole latitudes, as the
+  // Fourier-space distribution of sumplatb_mod.F90 with LDSPLIT=.FALSE.); the grid-point
+  // distribution is chosen identical, so TRGTOL/TRLTOG stay local copies.
+  P.latlo.assign(NP + 1, 0);
+  for (int r = 1; r < NP; r++) {
+    long long target = cum[L] * r / NP;
+    int j = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+    j = std::max(j, P.latlo[r - 1] + 1);
+    j = std::min(j, L - (NP - r));
+    P.latlo[r] = j;
+  }
+  P.latlo[NP] = L;
+  P.lat0 = P.latlo[me];
+  P.nlat = P.latlo[me + 1] - P.lat0;
+  P.ngptot = (int)(cum[P.latlo[me + 1]] - cum[P.lat0]);
+  for (int m = 0; m <= N; m++)
+    if (P.procm[m] == me) P.mval.push_back(m);
+  P.nump = (int)P.mval.size();
+  const int NU = P.nump, NL = P.nlat;
+  auto band_of = [&](int lat) { return (int)(std::upper_bound(P.latlo.begin(), P.latlo.end(), lat) - P.latlo.begin()) - 1; };
+
+  // ---- local index tables
+  P.nasm0.assign(NU, 0);
+  P.wbase.assign(NU + 1, 0);
+  P.wrows.assign(NU, 0);
+  P.ldp.assign(NU, 0);
+  P.ldk.assign(NU, 0);
+  P.offS.assign(NU, 0);
+  P.offA.assign(NU, 0);
+  P.offTS.assign(NU, 0);
+  P.offTA.assign(NU, 0);
+  P.lattile_pref.assign(NU + 1, 0);
+  P.ktile_pref.assign(NU + 1, 0);
+  P.lbase.assign(NU + 1, 0);
+  std::vector<int> ebase(NU, 0);
+  std::vector<double> eps, specw;
   {
     int ipos = 0;
     long long poff = 0, ptoff = 0;
-    for (int m = 0; m <= N; m++) {
-      P.nasm0[m] = ipos;  // 0-based (D%NASM0 - 1, suwavedi_mod.F90:128-133)
+    for (int ml = 0; ml < NU; ml++) {
+      const int m = P.mval[ml];
+      P.nasm0[ml] = ipos;  // 0-based (D%NASM0 - 1, suwavedi_mod.F90:128-133)
       ipos += (N - m + 1) * 2;
-      P.wrows[m] = roundup(N + 2 - m, 16);
-      P.wbase[m + 1] = P.wbase[m] + P.wrows[m];
+      for (int n = m; n <= N; n++) {  // SPNORMD weights (spnormd_mod.F90:40-57)
+        specw.push_back(m == 0 ? 1.0 : 2.0);
+        specw.push_back(m == 0 ? 0.0 : 2.0);
+      }
+      P.wrows[ml] = roundup(N + 2 - m, 16);
+      P.wbase[ml + 1] = P.wbase[ml] + P.wrows[ml];
       int nd = std::min(P.ndgnh, P.ndglu[m]);
-      P.ldp[m] = roundup(std::max(nd, 1), 64);
-      long long pan = (long long)(P.wrows[m] / 2) * P.ldp[m];
-      P.offS[m] = poff;
-      P.offA[m] = poff + pan;
+      P.lbase[ml + 1] = P.lbase[ml] + nd;
+      P.ldp[ml] = roundup(std::max(nd, 1), 64);
+      long long pan = (long long)(P.wrows[ml] / 2) * P.ldp[ml];
+      P.offS[ml] = poff;
+      P.offA[ml] = poff + pan;
       poff += 2 * pan;
-      P.ldk[m] = roundup(P.wrows[m] / 2, 64);
-      long long pant = (long long)roundup(std::max(nd, 1), 8) * P.ldk[m];
-      P.offTS[m] = ptoff;
-      P.offTA[m] = ptoff + pant;
+      P.ldk[ml] = roundup(P.wrows[ml] / 2, 64);
+      long long pant = (long long)roundup(std::max(nd, 1), 8) * P.ldk[ml];
+      P.offTS[ml] = ptoff;
+      P.offTA[ml] = ptoff + pant;
       ptoff += 2 * pant;
-      P.lattile_pref[m + 1] = P.lattile_pref[m] + (nd + 63) / 64;
-      P.ktile_pref[m + 1] = P.ktile_pref[m] + (P.wrows[m] / 2 + 63) / 64;
-      ebase[m] = (int)eps.size();
+      P.lattile_pref[ml + 1] = P.lattile_pref[ml] + (nd + 63) / 64;
+      P.ktile_pref[ml + 1] = P.ktile_pref[ml] + (P.wrows[ml] / 2 + 63) / 64;
+      ebase[ml] = (int)eps.size();
       for (int n = m; n <= N + 2; n++)  // REPSNM (pre_suleg_mod.F90:55-63)
         eps.push_back(std::sqrt((double)(n * n - m * m) / (double)(4 * n * n - 1)));
     }
+    P.nspec2 = ipos;
     P.p_elems = poff;
     P.pt_elems = ptoff;
-    P.wrows_total = P.wbase[N + 1];
+    P.wrows_total = P.wbase[NU];
   }
   std::vector<int> rowm(P.wrows_total);
-  for (int m = 0; m <= N; m++)
-    for (int r = 0; r < P.wrows[m]; r++) rowm[P.wbase[m] + r] = m;
-  P.fbase.assign(L + 1, 0);
-  for (int j = 0; j < L; j++) P.fbase[j + 1] = P.fbase[j] + P.nmen[j] + 1;
-  P.frows = P.fbase[L];
+  for (int ml = 0; ml < NU; ml++)
+    for (int r = 0; r < P.wrows[ml]; r++) rowm[P.wbase[ml] + r] = ml;
+  P.l_nmen.assign(NL, 0);
+  P.l_gpoff.assign(NL, 0);
+  P.l_fbase.assign(NL + 1, 0);
+  std::vector<double> l_rw(NL), l_racthe(NL);
+  for (int jl = 0; jl < NL; jl++) {
+    const int j = P.lat0 + jl;
+    P.l_nmen[jl] = P.nmen[j];
+    P.l_gpoff[jl] = (int)(cum[j] - cum[P.lat0]);
+    P.l_fbase[jl + 1] = P.l_fbase[jl] + P.nmen[j] + 1;
+    l_rw[jl] = P.rw[j];
+    l_racthe[jl] = P.racthe[j];
+  }
+  P.frows = P.l_fbase[NL];
+  P.lrows = 2LL * P.lbase[NU];
+
+  // ---- Fourier-buffer row tables.  One task: both sides share one latitude-major buffer
+  // (row = fbase[lat] + m).  Several tasks: the Legendre-side buffer is cut into one block per
+  // destination task (rows ordered wavenumber-major, then latitude), the FFT-side buffer into one
+  // block per source task with exactly the same row order, so the all-to-all-v moves whole blocks.
+  std::vector<int> legN(P.lbase[NU]), legS(P.lbase[NU]), fftrow(P.frows);
+  P.leg_rows.assign(NP, 0);
+  P.leg_disp.assign(NP, 0);
+  P.fft_rows.assign(NP, 0);
+  P.fft_disp.assign(NP, 0);
+  if (NP == 1) {
+    for (int ml = 0; ml < NU; ml++) {
+      const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
+      for (int j = 0; j < nd; j++) {
+        legN[P.lbase[ml] + j] = P.l_fbase[isl0 + j] + m;
+        legS[P.lbase[ml] + j] = P.l_fbase[L - 1 - isl0 - j] + m;
+      }
+    }
+    for (long long i = 0; i < P.frows; i++) fftrow[i] = (int)i;
+    P.leg_rows[0] = P.fft_rows[0] = P.frows;
+  } else {
+    // Legendre side: block d holds (ml ascending, lat in band d ascending with NMEN(lat) >= m)
+    for (int ml = 0; ml < NU; ml++) {
+      const int m = P.mval[ml];
+      for (int lat = 0; lat < L; lat++)
+        if (P.nmen[lat] >= m) P.leg_rows[band_of(lat)]++;
+    }
+    for (int d = 1; d < NP; d++) P.leg_disp[d] = P.leg_disp[d - 1] + P.leg_rows[d - 1];
+    {
+      std::vector<long long> pos(P.leg_disp);
+      std::vector<int> rowof(L);
+      for (int ml = 0; ml < NU; ml++) {
+        const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
+        for (int lat = 0; lat < L; lat++)
+          if (P.nmen[lat] >= m) rowof[lat] = (int)pos[band_of(lat)]++;
+        for (int j = 0; j < nd; j++) {
+          legN[P.lbase[ml] + j] = rowof[isl0 + j];
+          legS[P.lbase[ml] + j] = rowof[L - 1 - isl0 - j];
+        }
+      }
+    }
+    // FFT side: block s holds (wavenumbers of task s ascending, local lat ascending with NMEN >= m)
+    for (int m = 0; m <= N; m++)
+      for (int jl = 0; jl < NL; jl++)
+        if (P.l_nmen[jl] >= m) P.fft_rows[P.procm[m]]++;
+    for (int sr = 1; sr < NP; sr++) P.fft_disp[sr] = P.fft_disp[sr - 1] + P.fft_rows[sr - 1];
+    {
+      std::vector<long long> pos(P.fft_disp);
+      for (int m = 0; m <= N; m++)
+        for (int jl = 0; jl < NL; jl++)
+          if (P.l_nmen[jl] >= m) fftrow[P.l_fbase[jl] + m] = (int)pos[P.procm[m]]++;
+    }
+    long long tl = 0, tf = 0;
+    for (int r = 0; r < NP; r++) tl += P.leg_rows[r], tf += P.fft_rows[r];
+    if (tl != P.lrows || tf != P.frows) {
+      delete pp;
+      EMI_FAIL(EMI_ERR_RUNTIME, "internal: exchange tables inconsistent (%lld/%lld, %lld/%lld)", tl, P.lrows, tf, P.frows);
+    }
+  }
   std::vector<double> lapin(N + 4, 0.0);  // RLAPIN(-1:N+2) (pre_suleg_mod.F90:64-69)
   for (int n = 1; n <= N + 2; n++) lapin[n + 1] = -(P.ra * P.ra / (double)(n * (n + 1)));
 
-  // Legendre panels: PS[k][j] = P_{m+2k}^m(mu_{isl0+j}), PA[k][j] = P_{m+2k+1}^m, zero padded
-  void *dP = nullptr;
-  if (emi_dev_malloc(&dP, (size_t)P.p_elems * 8)) {
+  // ---- Legendre panels of the local wavenumbers: PS[k][j] = P_{m+2k}^m(mu_{isl0+j}),
+  // PA[k][j] = P_{m+2k+1}^m, zero padded; plus the [j][k] transposed copy for the direct transform
+  void *dP = nullptr, *dPT = nullptr;
+  if (emi_dev_malloc(&dP, (size_t)P.p_elems * 8) || emi_dev_malloc(&dPT, (size_t)P.pt_elems * 8)) {
     delete pp;
-    EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB for the Legendre panels", P.p_elems * 8.0 / (1 << 30));
+    EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB for the Legendre panels", (P.p_elems + P.pt_elems) * 8.0 / (1 << 30));
   }
   P.d_P = (double *)dP;
-  P.dev_allocs.push_back(dP);
-  void *dPT = nullptr;
-  if (emi_dev_malloc(&dPT, (size_t)P.pt_elems * 8)) {
-    delete pp;
-    EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB for the transposed Legendre panels", P.pt_elems * 8.0 / (1 << 30));
-  }
   P.d_PT = (double *)dPT;
+  P.dev_allocs.push_back(dP);
   P.dev_allocs.push_back(dPT);
   {
     std::atomic<int> bad{0};
-    emi::parallel_for(N + 1, [&](int m) {
-      const int nd = std::min(P.ndgnh, P.ndglu[m]), isl0 = P.ndgnh - nd;
-      const int ld = P.ldp[m], nk = P.wrows[m] / 2;
+    emi::parallel_for(NU, [&](int ml) {
+      const int m = P.mval[ml];
+      const int nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
+      const int ld = P.ldp[ml], nk = P.wrows[ml] / 2;
       const int nmax = N + 2;
       std::vector<double> pan((size_t)2 * nk * ld, 0.0), col(nmax + 1);
       std::vector<int> corr(nmax + 1);
@@ -477,14 +606,13 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
           for (int k = 0; m + 2 * k + par <= N + 1; k++) dst[(size_t)k * ld + j] = col[m + 2 * k + par];
         }
       }
-      if (emi_h2d(P.d_P + P.offS[m], pan.data(), pan.size() * 8, 0)) bad = 1;
-      // transposed copy for the direct transform: [par][j][k], k fastest, zero padded
-      const int ldk = P.ldk[m], ndp = roundup(std::max(nd, 1), 8);
+      if (emi_h2d(P.d_P + P.offS[ml], pan.data(), pan.size() * 8, 0)) bad = 1;
+      const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), 8);
       std::vector<double> pt((size_t)2 * ndp * ldk, 0.0);
       for (int par = 0; par < 2; par++)
         for (int k = 0; k < nk; k++)
           for (int j = 0; j < nd; j++) pt[((size_t)par * ndp + j) * ldk + k] = pan[((size_t)par * nk + k) * ld + j];
-      if (emi_h2d(P.d_PT + P.offTS[m], pt.data(), pt.size() * 8, 0)) bad = 1;
+      if (emi_h2d(P.d_PT + P.offTS[ml], pt.data(), pt.size() * 8, 0)) bad = 1;
       emi_stream_sync(0);
     });
     if (bad) {
@@ -492,35 +620,40 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
       return EMI_ERR_RUNTIME;
     }
   }
-  // device tables
-  int *d_nloen, *d_nmen, *d_ndglu, *d_gpoff, *d_nasm0, *d_fbase, *d_wbase, *d_wrows, *d_rowm, *d_ebase, *d_ldp, *d_ltp, *d_ktp, *d_ldk;
-  double *d_eps, *d_lapin, *d_rw, *d_racthe;
+  // ---- device tables
+  int *d_mval, *d_nmen, *d_gpoff, *d_nasm0, *d_fbase, *d_fftrow, *d_lbase, *d_legN, *d_legS, *d_wbase, *d_wrows, *d_rowm, *d_ebase,
+      *d_ldp, *d_ldk, *d_ltp, *d_ktp;
+  double *d_eps, *d_lapin, *d_rw, *d_racthe, *d_specw;
   long long *d_offS, *d_offA, *d_offTS, *d_offTA;
-  if (upload(P.nloen, &d_nloen) || upload(P.nmen, &d_nmen) || upload(P.ndglu, &d_ndglu) || upload(P.gpoff, &d_gpoff) ||
-      upload(P.nasm0, &d_nasm0) || upload(P.fbase, &d_fbase) || upload(P.wbase, &d_wbase) || upload(P.wrows, &d_wrows) ||
-      upload(rowm, &d_rowm) || upload(ebase, &d_ebase) || upload(P.ldp, &d_ldp) || upload(P.lattile_pref, &d_ltp) ||
-      upload(P.ktile_pref, &d_ktp) || upload(eps, &d_eps) || upload(lapin, &d_lapin) || upload(P.rw, &d_rw) ||
-      upload(P.racthe, &d_racthe) || upload(P.offS, &d_offS) || upload(P.offA, &d_offA) || upload(P.offTS, &d_offTS) ||
-      upload(P.offTA, &d_offTA) || upload(P.ldk, &d_ldk)) {
+  if (upload(P.mval, &d_mval) || upload(P.l_nmen, &d_nmen) || upload(P.l_gpoff, &d_gpoff) || upload(P.nasm0, &d_nasm0) ||
+      upload(P.l_fbase, &d_fbase) || upload(fftrow, &d_fftrow) || upload(P.lbase, &d_lbase) || upload(legN, &d_legN) ||
+      upload(legS, &d_legS) || upload(P.wbase, &d_wbase) || upload(P.wrows, &d_wrows) || upload(rowm, &d_rowm) ||
+      upload(ebase, &d_ebase) || upload(P.ldp, &d_ldp) || upload(P.ldk, &d_ldk) || upload(P.lattile_pref, &d_ltp) ||
+      upload(P.ktile_pref, &d_ktp) || upload(eps, &d_eps) || upload(lapin, &d_lapin) || upload(l_rw, &d_rw) ||
+      upload(l_racthe, &d_racthe) || upload(specw, &d_specw) || upload(P.offS, &d_offS) || upload(P.offA, &d_offA) ||
+      upload(P.offTS, &d_offTS) || upload(P.offTA, &d_offTA)) {
     delete pp;
     return EMI_ERR_RUNTIME;
   }
-  for (void *p : {(void *)d_nloen, (void *)d_nmen, (void *)d_ndglu, (void *)d_gpoff, (void *)d_nasm0, (void *)d_fbase, (void *)d_wbase,
-                  (void *)d_wrows, (void *)d_rowm, (void *)d_ebase, (void *)d_ldp, (void *)d_ltp, (void *)d_ktp, (void *)d_eps,
-                  (void *)d_lapin, (void *)d_rw, (void *)d_racthe, (void *)d_offS, (void *)d_offA, (void *)d_offTS, (void *)d_offTA,
-                  (void *)d_ldk})
+  for (void *p : {(void *)d_mval, (void *)d_nmen, (void *)d_gpoff, (void *)d_nasm0, (void *)d_fbase, (void *)d_fftrow, (void *)d_lbase,
+                  (void *)d_legN, (void *)d_legS, (void *)d_wbase, (void *)d_wrows, (void *)d_rowm, (void *)d_ebase, (void *)d_ldp,
+                  (void *)d_ldk, (void *)d_ltp, (void *)d_ktp, (void *)d_eps, (void *)d_lapin, (void *)d_rw, (void *)d_racthe,
+                  (void *)d_specw, (void *)d_offS, (void *)d_offA, (void *)d_offTS, (void *)d_offTA})
     P.dev_allocs.push_back(p);
   EmiGeomDev &g = P.g;
   g.nsmax = N;
-  g.ndgl = L;
-  g.ndgnh = P.ndgnh;
+  g.nump = NU;
+  g.nlat = NL;
   g.ngptot = P.ngptot;
-  g.nloen = d_nloen;
+  g.mval = d_mval;
   g.nmen = d_nmen;
-  g.ndglu = d_ndglu;
   g.gpoff = d_gpoff;
   g.nasm0 = d_nasm0;
   g.fbase = d_fbase;
+  g.fftrow = d_fftrow;
+  g.lbase = d_lbase;
+  g.legN = d_legN;
+  g.legS = d_legS;
   g.wbase = d_wbase;
   g.wrows = d_wrows;
   g.rowm = d_rowm;
@@ -539,6 +672,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   g.ldk = d_ldk;
   g.lattile_pref = d_ltp;
   g.ktile_pref = d_ktp;
+  g.specw = d_specw;
   int rc = build_fft_plans(P);
   if (rc) {
     delete pp;
@@ -552,6 +686,12 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   return EMI_SUCCESS;
 }
 
+extern "C" int emi_set_alltoallv(emi_alltoallv_fn fn, void *user) {
+  G.a2a = fn;
+  G.a2a_user = user;
+  return EMI_SUCCESS;
+}
+
 extern "C" int emi_release(int kresol) {
   Plan *P = get_plan(kresol);
   if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_RELEASE: unknown resolution %d", kresol);
@@ -559,7 +699,8 @@ extern "C" int emi_release(int kresol) {
   for (void *p : P->dev_allocs) emi_dev_free(p);
   for (int c = 0; c < 3; c++) emi_dev_free(P->fclass[c].d_pref);
   emi_dev_free(P->d_W);
-  emi_dev_free(P->d_FB);
+  emi_dev_free(P->d_FBL);
+  if (P->d_FBF != P->d_FBL) emi_dev_free(P->d_FBF);
   emi_dev_free(P->d_desc);
   P->active = false;
   delete P;
@@ -583,20 +724,48 @@ extern "C" int emi_inq_int(int kresol, const char *name, int *value) {
   Plan *P = get_plan(kresol);
   if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_INQ: unknown resolution %d", kresol);
   std::string s(name ? name : "");
-  if (s == "nspec2" || s == "nspec2g" || s == "nspec2mx")
+  if (s == "nspec2")
     *value = P->nspec2;
-  else if (s == "nspec" || s == "nspecg")
+  else if (s == "nspec2g")
+    *value = P->nspec2g;
+  else if (s == "nspec2mx") {
+    int mx = 0;
+    std::vector<int> cnt(P->nproc, 0);
+    for (int m = 0; m <= P->nsmax; m++) cnt[P->procm[m]] += 2 * (P->nsmax - m + 1);
+    for (int c : cnt) mx = std::max(mx, c);
+    *value = mx;
+  } else if (s == "nspec")
     *value = P->nspec2 / 2;
-  else if (s == "ngptot" || s == "ngptotg" || s == "ngptotmx")
+  else if (s == "nspecg")
+    *value = P->nspec2g / 2;
+  else if (s == "ngptot")
     *value = P->ngptot;
-  else if (s == "nump")
-    *value = P->nsmax + 1;
+  else if (s == "ngptotg")
+    *value = P->ngptotg;
+  else if (s == "ngptotmx") {
+    long long mx = 0;
+    for (int r = 0; r < P->nproc; r++) {
+      long long c = 0;
+      for (int j = P->latlo[r]; j < P->latlo[r + 1]; j++) c += P->nloen[j];
+      mx = std::max(mx, c);
+    }
+    *value = (int)mx;
+  } else if (s == "nump")
+    *value = P->nump;
   else if (s == "ndgl")
     *value = P->ndgl;
   else if (s == "nsmax")
     *value = P->nsmax;
   else if (s == "ndlon")
     *value = *std::max_element(P->nloen.begin(), P->nloen.end());
+  else if (s == "nproc" || s == "nprtrw")
+    *value = P->nproc;
+  else if (s == "myproc" || s == "mysetw")
+    *value = P->me + 1;
+  else if (s == "nfrstlat")  // first (1-based, global) latitude of this task's band
+    *value = P->lat0 + 1;
+  else if (s == "nlstlat")
+    *value = P->lat0 + P->nlat;
   else
     EMI_FAIL(EMI_ERR_ARG, "emi_inq_int: unknown name '%s'", s.c_str());
   return EMI_SUCCESS;
@@ -614,14 +783,18 @@ extern "C" int emi_inq_int_array(int kresol, const char *name, int *out, int len
     v = &P->nmen;
   else if (s == "ndglu")
     v = &P->ndglu;
-  else if (s == "nasm0") {
-    tmp = P->nasm0;
-    for (auto &x : tmp) x += 1;  // Fortran 1-based D%NASM0
+  else if (s == "nasm0") {  // D%NASM0(0:NSMAX): 1-based address of (m, n=m), -99 for foreign m
+    tmp.assign(P->nsmax + 1, -99);
+    for (int ml = 0; ml < P->nump; ml++) tmp[P->mval[ml]] = P->nasm0[ml] + 1;
     v = &tmp;
-  } else if (s == "myms") {
-    tmp.resize(P->nsmax + 1);
-    for (int m = 0; m <= P->nsmax; m++) tmp[m] = m;
+  } else if (s == "myms")
+    v = &P->mval;
+  else if (s == "procm") {  // D%NPROCM: owning W-set (1-based) of every wavenumber
+    tmp = P->procm;
+    for (auto &x : tmp) x += 1;
     v = &tmp;
+  } else if (s == "latlo") {  // [nproc+1] 0-based first latitude of every task's band
+    v = &P->latlo;
   } else
     EMI_FAIL(EMI_ERR_ARG, "emi_inq_int_array: unknown name '%s'", s.c_str());
   if (len < (int)v->size()) EMI_FAIL(EMI_ERR_ARG, "TRANS_INQ: %s TOO SMALL (%d < %zu)", s.c_str(), len, v->size());
@@ -651,14 +824,16 @@ extern "C" int emi_inq_legendre(int kresol, int m, int symmetric, double *out, i
   Plan *P = get_plan(kresol);
   if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_INQ: unknown resolution %d", kresol);
   if (m < 0 || m > P->nsmax) EMI_FAIL(EMI_ERR_ARG, "emi_inq_legendre: m out of range");
+  if (P->procm[m] != P->me) EMI_FAIL(EMI_ERR_ARG, "emi_inq_legendre: wavenumber %d belongs to task %d", m, P->procm[m] + 1);
+  const int ml = (int)(std::lower_bound(P->mval.begin(), P->mval.end(), m) - P->mval.begin());
   const int N = P->nsmax, nd = std::min(P->ndgnh, P->ndglu[m]);
   const int nc = symmetric ? (N - m + 3) / 2 : (N - m + 2) / 2;
   if (nrows) *nrows = nd;
   if (ncols) *ncols = nc;
   if (!out) return EMI_SUCCESS;
-  const int ld = P->ldp[m], nk = P->wrows[m] / 2;
+  const int ld = P->ldp[ml], nk = P->wrows[ml] / 2;
   std::vector<double> pan((size_t)nk * ld);
-  if (emi_d2h(pan.data(), P->d_P + (symmetric ? P->offS[m] : P->offA[m]), pan.size() * 8, 0)) return EMI_ERR_RUNTIME;
+  if (emi_d2h(pan.data(), P->d_P + (symmetric ? P->offS[ml] : P->offA[ml]), pan.size() * 8, 0)) return EMI_ERR_RUNTIME;
   emi_stream_sync(0);
   // reference column c (0-based) holds n descending: k = nc-1-c
   for (int c = 0; c < nc; c++)
@@ -697,30 +872,52 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
   }
 };
 
+static int grow(double **p, size_t *cap, size_t need, const char *what) {
+  if (need <= *cap) return 0;
+  emi_stream_sync(0);
+  emi_dev_free(*p);
+  *p = nullptr;
+  *cap = 0;
+  void *q;
+  if (emi_dev_malloc(&q, need)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB %s", need / 1073741824.0, what);
+  *p = (double *)q;
+  *cap = need;
+  emi_dev_memset(q, 0, need, 0);
+  return 0;
+}
+
 static int ensure_work(Plan &P, int bfpad) {
-  size_t needW = (size_t)P.wrows_total * 2 * bfpad * 8, needF = (size_t)P.frows * 2 * bfpad * 8;
-  if (needW > P.cap_W) {
-    emi_stream_sync(0);
-    emi_dev_free(P.d_W);
-    P.d_W = nullptr;
-    P.cap_W = 0;
-    void *p;
-    if (emi_dev_malloc(&p, needW)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB packed-spectral work buffer", needW / 1073741824.0);
-    P.d_W = (double *)p;
-    P.cap_W = needW;
-    emi_dev_memset(p, 0, needW, 0);
+  const size_t rowb = (size_t)2 * bfpad * 8;
+  if (grow(&P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer")) return -1;
+  if (P.nproc == 1) {
+    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)P.frows * rowb, "Fourier work buffer")) return -1;
+    P.d_FBF = P.d_FBL;
+    P.cap_FBF = P.cap_FBL;
+  } else {
+    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)P.lrows * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
+    if (grow(&P.d_FBF, &P.cap_FBF, (size_t)P.frows * rowb, "Fourier (FFT-side) exchange buffer")) return -1;
   }
-  if (needF > P.cap_FB) {
-    emi_stream_sync(0);
-    emi_dev_free(P.d_FB);
-    P.d_FB = nullptr;
-    P.cap_FB = 0;
-    void *p;
-    if (emi_dev_malloc(&p, needF)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB Fourier work buffer", needF / 1073741824.0);
-    P.d_FB = (double *)p;
-    P.cap_FB = needF;
-    emi_dev_memset(p, 0, needF, 0);
+  return 0;
+}
+
+// TRLTOM / TRMTOL (trltom_mod.F90:96-136, trmtol_mod.F90:101-141): one all-to-all-v of whole
+// row blocks of the Fourier buffers.  to_fft: Legendre-side -> FFT-side (inverse transform).
+static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st) {
+  if (P.nproc == 1) return 0;
+  const int NP = P.nproc;
+  std::vector<long long> sc(NP), sd(NP), rc(NP), rd(NP);
+  const long long rowb = (long long)ldf * 8;
+  for (int r = 0; r < NP; r++) {
+    const long long lr = P.leg_rows[r] * rowb, ld = P.leg_disp[r] * rowb, fr = P.fft_rows[r] * rowb, fd = P.fft_disp[r] * rowb;
+    sc[r] = to_fft ? lr : fr;
+    sd[r] = to_fft ? ld : fd;
+    rc[r] = to_fft ? fr : lr;
+    rd[r] = to_fft ? fd : ld;
   }
+  const void *sb = to_fft ? P.d_FBL : P.d_FBF;
+  void *rb = to_fft ? P.d_FBF : P.d_FBL;
+  if (G.a2a(G.a2a_user, sb, sc.data(), sd.data(), rb, rc.data(), rd.data(), NP, (void *)st) != 0)
+    EMI_FAIL(EMI_ERR_RUNTIME, "all-to-all-v hook failed");
   return 0;
 }
 
@@ -758,8 +955,8 @@ static int pick_batch(Plan &P, int nfields) {
   // fields per batch: bounded by free HBM (W + FB rows x 16 B per field) and EMI_MAX_BATCH
   size_t fr = 0, tot = 0;
   emi_mem_info(&fr, &tot);
-  size_t have = fr + P.cap_W + P.cap_FB;
-  double per_field = (double)(P.wrows_total + P.frows) * 16.0;
+  size_t have = fr + P.cap_W + P.cap_FBL + (P.nproc > 1 ? P.cap_FBF : 0);
+  double per_field = (double)(P.wrows_total + P.frows + (P.nproc > 1 ? P.lrows : 0)) * 16.0;
   long long cap = (long long)((double)have * 0.85 / per_field);
   cap = cap / 64 * 64;
   if (cap < 64) cap = 64;
@@ -1026,11 +1223,13 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     g_pt.mark(0);
     {
       const int nct = ldw / LG_BN;
-      long long ntiles = (long long)P.lattile_pref[P.nsmax + 1] * nct;
-      EMI_LAUNCH(k_leg_inv, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_W, ldw, P.d_FB, ldw, ntiles);
+      long long ntiles = (long long)P.lattile_pref[P.nump] * nct;
+      EMI_LAUNCH(k_leg_inv, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_W, ldw, P.d_FBL, ldw, ntiles);
     }
     g_pt.mark(1);
-    launch_fft(P, true, d_bg, (int)bg.size(), P.d_FB, ldw, nproma, st);
+    if (exchange(P, true, ldw, st)) return EMI_ERR_RUNTIME;  // TRMTOL
+    if (P.nproc > 1) g_pt.mark(-1);
+    launch_fft(P, true, d_bg, (int)bg.size(), P.d_FBF, ldw, nproma, st);
     g_pt.mark(2);
   }
   if (host) hs.flush(st);
@@ -1166,12 +1365,14 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     const GridFld *d_bg = (const GridFld *)P.d_desc;
     const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + off_o);
     g_pt.mark(-1);
-    launch_fft(P, false, d_bg, (int)bg.size(), P.d_FB, ldw, nproma, st);
+    launch_fft(P, false, d_bg, (int)bg.size(), P.d_FBF, ldw, nproma, st);
     g_pt.mark(2);
+    if (exchange(P, false, ldw, st)) return EMI_ERR_RUNTIME;  // TRLTOM
+    if (P.nproc > 1) g_pt.mark(-1);
     {
       const int nct = ldw / LG_BN;
-      long long ntiles = (long long)P.ktile_pref[P.nsmax + 1] * nct;
-      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, st, P.g, nct, (const double *)P.d_FB, ldw, P.d_W, ldw, ntiles);
+      long long ntiles = (long long)P.ktile_pref[P.nump] * nct;
+      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, st, P.g, nct, (const double *)P.d_FBL, ldw, P.d_W, ldw, ntiles);
     }
     g_pt.mark(1);
     {
@@ -1188,33 +1389,51 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   return EMI_SUCCESS;
 }
 
-extern "C" int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms) {
-  Plan *Pp = get_plan(kresol);
-  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: unknown resolution %d", kresol);
-  if (!spec || nfld <= 0 || !norms) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
-  Plan &P = *Pp;
+static int specnorm_sumsq(Plan &P, int mem_space, const void *spec, int nfld, double *sumsq) {
   HostStage hs;
   const double *d_sp = hs.in(spec, (size_t)P.nspec2 * nfld, mem_space == EMI_MEM_HOST, 0);
   void *d_out = nullptr;
   if (emi_dev_malloc(&d_out, (size_t)nfld * 8)) return EMI_ERR_RUNTIME;
-  EMI_LAUNCH(k_specnorm, nfld, 256, 256 * 8, (emi_stream_t)0, P.g, d_sp, nfld, (double *)d_out);
-  emi_d2h(norms, d_out, (size_t)nfld * 8, 0);
+  EMI_LAUNCH(k_specnorm, nfld, 256, 256 * 8, (emi_stream_t)0, P.g, (long long)P.nspec2, d_sp, nfld, (double *)d_out);
+  emi_d2h(sumsq, d_out, (size_t)nfld * 8, 0);
   emi_stream_sync(0);
   emi_dev_free(d_out);
   return EMI_SUCCESS;
+}
+
+extern "C" int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: unknown resolution %d", kresol);
+  if (!spec || nfld <= 0 || !norms) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
+  if (Pp->nproc > 1) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: with several tasks use emi_specnorm_partial and sum over tasks");
+  if (specnorm_sumsq(*Pp, mem_space, spec, nfld, norms)) return EMI_ERR_RUNTIME;
+  for (int i = 0; i < nfld; i++) norms[i] = std::sqrt(norms[i]);
+  return EMI_SUCCESS;
+}
+
+// this task's contribution (sum over its wavenumbers of the weighted squares, spnormd_mod.F90);
+// the caller sums over tasks and takes the square root (spnormc_mod.F90 gathers to the master)
+extern "C" int emi_specnorm_partial(int kresol, int mem_space, const void *spec, int nfld, double *sumsq) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: unknown resolution %d", kresol);
+  if (!spec || nfld <= 0 || !sumsq) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
+  return specnorm_sumsq(*Pp, mem_space, spec, nfld, sumsq);
 }
 
 extern "C" int emi_work_model(int kresol, int nfields, double *leg, double *fft, double *fbytes) {
   Plan *Pp = get_plan(kresol);
   if (!Pp) EMI_FAIL(EMI_ERR_STATE, "emi_work_model: unknown resolution %d", kresol);
   Plan &P = *Pp;
-  // LT flops/direction = KF * sum_m 2*NDGLU(m)*(N-m+2)*c_m, c_0=1, c_{m>0}=2
+  // LT flops/direction = KF * sum_m 2*NDGLU(m)*(N-m+2)*c_m, c_0=1, c_{m>0}=2 (this
+  // task's wavenumbers); FFT ~ 2.5 n log2 n per row; Fourier bytes of this task's latitudes
   double s = 0.0;
-  for (int m = 0; m <= P.nsmax; m++)
+  for (int ml = 0; ml < P.nump; ml++) {
+    const int m = P.mval[ml];
     s += 2.0 * std::min(P.ndgnh, P.ndglu[m]) * (double)(P.nsmax - m + 2) * (m == 0 ? 1.0 : 2.0);
+  }
   if (leg) *leg = s * nfields;
   double f = 0.0;
-  for (int j = 0; j < P.ndgl; j++) f += 2.5 * P.nloen[j] * std::log2((double)std::max(2, P.nloen[j]));
+  for (int j = P.lat0; j < P.lat0 + P.nlat; j++) f += 2.5 * P.nloen[j] * std::log2((double)std::max(2, P.nloen[j]));
   if (fft) *fft = f * nfields;
   if (fbytes) *fbytes = (double)P.frows * 16.0 * nfields;
   return EMI_SUCCESS;

@@ -16,25 +16,35 @@
 // device-visible descriptors
 // ------------------------------------------------------------------------------------------
 struct EmiGeomDev {
-  int nsmax, ndgl, ndgnh, ngptot;
-  const int *nloen, *nmen, *ndglu, *gpoff;
-  const int *nasm0;   // [nsmax+1] 0-based index of Re(m, n=m) in the user spectral dimension
-  const int *fbase;   // [ndgl+1]  Fourier rows (lat,m<=NMEN) before latitude
-  const int *wbase;   // [nsmax+2] packed-spectral rows before m (padded to 16)
-  const int *wrows;   // [nsmax+1] padded row count of m (multiple of 16)
-  const int *rowm;    // [wbase[nsmax+1]] row -> m
-  const int *ebase;   // [nsmax+1] index of eps(n=m) in eps[] (n = m..N+2)
+  // Everything is indexed by LOCAL zonal-wavenumber number ml (0..nump-1, actual wavenumber
+  // mval[ml]) and LOCAL latitude number (0..nlat-1): with one task local == global; with several
+  // tasks each task owns the wavenumbers of its W-set (suwavedi_mod.F90:118-137) and a contiguous
+  // latitude band.
+  int nsmax, nump, nlat, ngptot;
+  const int *mval;    // [nump] actual zonal wavenumber
+  const int *nmen, *gpoff;  // [nlat]
+  const int *nasm0;   // [nump] 0-based index of Re(m, n=m) in the (local) user spectral dimension
+  const int *fbase;   // [nlat+1]  Fourier rows (lat, m<=NMEN) before the local latitude
+  const int *fftrow;  // [fbase[nlat]] row of (lat, m) in the FFT-side Fourier buffer
+  const int *lbase;   // [nump+1] start of wavenumber ml in legN/legS
+  const int *legN, *legS;  // row of (ml, j-th northern latitude with m<=NMEN) / its southern mirror
+                           // in the Legendre-side Fourier buffer
+  const int *wbase;   // [nump+1] packed-spectral rows before ml (padded to 16)
+  const int *wrows;   // [nump] padded row count (multiple of 16)
+  const int *rowm;    // [wbase[nump]] row -> ml
+  const int *ebase;   // [nump] index of eps(n=m) in eps[] (n = m..N+2)
   const double *eps;  // REPSNM
   const double *lapin;  // RLAPIN(n) at [n+1], n=-1..N+2
-  const double *rw, *racthe;
+  const double *rw, *racthe;   // [nlat]
   const double *P;             // Legendre panels
-  const long long *offS, *offA;  // [nsmax+1] element offsets of the even/odd (n-m) panels
-  const int *ldp;              // [nsmax+1] padded latitude count (multiple of 64)
+  const long long *offS, *offA;  // [nump] element offsets of the even/odd (n-m) panels
+  const int *ldp;              // [nump] padded latitude count (multiple of 64)
   const double *PT;            // transposed panels for the direct transform: [par][lat j][k], k fastest
-  const long long *offTS, *offTA;  // [nsmax+1]
-  const int *ldk;              // [nsmax+1] padded k count (multiple of 64)
-  const int *lattile_pref;     // [nsmax+2] prefix of ceil(ndglu/64)
-  const int *ktile_pref;       // [nsmax+2] prefix of ceil((wrows/2)/64)
+  const long long *offTS, *offTA;  // [nump]
+  const int *ldk;              // [nump] padded k count (multiple of 64)
+  const int *lattile_pref;     // [nump+1] prefix of ceil(ndglu/64)
+  const int *ktile_pref;       // [nump+1] prefix of ceil((wrows/2)/64)
+  const double *specw;         // [nspec2 local] SPECNORM weight of every spectral entry (0, 1 or 2)
 };
 
 enum { SPK_COPY = 0, SPK_U = 1, SPK_V = 2, SPK_NSD = 3 };
@@ -97,9 +107,9 @@ EMI_DEVFN d2 cconj(d2 a) { return mk2(a.x, -a.y); }
 EMI_DEVFN d2 cscale(d2 a, double s) { return mk2(a.x * s, a.y * s); }
 EMI_DEVFN d2 cmuli(d2 a) { return mk2(-a.y, a.x); }  // i*a
 
-EMI_DEVFN int upper_m(const int *pref, int nsmax, int t) {
-  // largest m in [0,nsmax] with pref[m] <= t  (pref non-decreasing, pref[nsmax+1] > t)
-  int lo = 0, hi = nsmax;
+EMI_DEVFN int upper_m(const int *pref, int nump, int t) {
+  // largest ml in [0,nump) with pref[ml] <= t  (pref non-decreasing, pref[nump] > t)
+  int lo = 0, hi = nump - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
     if (pref[mid] <= t)
@@ -146,16 +156,17 @@ EMI_KERNEL_LB(256) void k_prepack_inv(EmiGeomDev g, const SpecSrc *flds, int nfl
     int f = (int)(idx - row * nfld_pad);
     d2 out = mk2(0.0, 0.0);
     if (f < nfld) {
-      int m = g.rowm[row];
-      int r = (int)(row - g.wbase[m]);
+      const int ml = g.rowm[row];
+      const int m = g.mval[ml];
+      int r = (int)(row - g.wbase[ml]);
       int n = m + r;
       if (n <= N + 1) {
         SpecSrc s = flds[f];
-        long long isp = g.nasm0[m] + 2LL * r;  // Re(m,n)
+        long long isp = g.nasm0[ml] + 2LL * r;  // Re(m,n)
         if (s.kind == SPK_COPY) {
           if (n <= N) out = spec_get(s.a, s.sa, s.ia, isp, m);
         } else {
-          const double *eps = g.eps + g.ebase[m] - m;  // eps[n], n=m..N+2
+          const double *eps = g.eps + g.ebase[ml] - m;  // eps[n], n=m..N+2
           double zn_m1 = (double)(n - 1), zn_p2 = (double)(n + 2);
           double e_n = eps[n], e_np1 = eps[n + 1];
           if (s.kind == SPK_NSD) {
@@ -201,8 +212,9 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
     if (idx >= total) return;
     long long row = idx / nfld;
     int f = (int)(idx - row * nfld);
-    int m = g.rowm[row];
-    int r = (int)(row - g.wbase[m]);
+    const int ml = g.rowm[row];
+    const int m = g.mval[ml];
+    int r = (int)(row - g.wbase[ml]);
     int n = m + r;
     if (n > N) return;
     SpecDst s = flds[f];
@@ -210,7 +222,7 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
     if (s.kind == SPO_COPY) {
       out = *(const d2 *)(W + row * ldw + 2 * s.src0);
     } else {
-      const double *eps = g.eps + g.ebase[m] - m;
+      const double *eps = g.eps + g.ebase[ml] - m;
       // vor: x=V (i m term), y=U ; div: x=U, y=V with opposite sign on the n-terms
       int fx = (s.kind == SPO_VOR) ? s.src1 : s.src0;
       int fy = (s.kind == SPO_VOR) ? s.src0 : s.src1;
@@ -226,7 +238,7 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
       if (m == 0 && n == 0) out = mk2(0, 0);  // updsp_mod.F90:113-126
     }
     if (m == 0) out.y = 0.0;  // updspb_mod.F90:106,117
-    long long isp = g.nasm0[m] + 2LL * r;
+    long long isp = g.nasm0[ml] + 2LL * r;
     s.dst[isp * s.stride + s.idx] = out.x;
     s.dst[(isp + 1) * s.stride + s.idx] = out.y;
   }
@@ -256,7 +268,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, int ncoltiles, const double 
   long long tile = xcd_swizzle(EMI_BID, ntiles, ncoltiles);
   int ct = (int)(tile % ncoltiles);
   int t2 = (int)(tile / ncoltiles);
-  const int m = upper_m(g.lattile_pref, g.nsmax, t2);
+  const int m = upper_m(g.lattile_pref, g.nump, t2);  // local wavenumber number
   const int lt = t2 - g.lattile_pref[m];
   const int ld = g.ldp[m];
   const int lat0 = lt * 64, col0 = ct * LG_BN;
@@ -323,17 +335,15 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, int ncoltiles, const double 
       }
   }
   // epilogue (ASRE1B): rows = latitudes
-  const int ndglu = g.ndglu[m] < g.ndgnh ? g.ndglu[m] : g.ndgnh;
-  const int isl0 = g.ndgnh - ndglu;  // 0-based first northern latitude with m <= NMEN
+  const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       int j = lat0 + wm * 32 + i * 16 + (l >> 4) + 4 * q;
       if (j < ndglu) {
-        int latn = isl0 + j, lats = g.ndgl - 1 - latn;
-        double *pn = FB + ((long long)g.fbase[latn] + m) * ldf + col0 + wn * 64 + (l & 15);
-        double *ps = FB + ((long long)g.fbase[lats] + m) * ldf + col0 + wn * 64 + (l & 15);
+        double *pn = FB + (long long)g.legN[lb + j] * ldf + col0 + wn * 64 + (l & 15);
+        double *ps = FB + (long long)g.legS[lb + j] * ldf + col0 + wn * 64 + (l & 15);
 #pragma unroll
         for (int jn = 0; jn < 4; jn++) {
           double sv = acc[0][i][jn][q], av = acc[1][i][jn][q];
@@ -357,12 +367,11 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
   long long tile = xcd_swizzle(EMI_BID, ntiles, ncoltiles);
   int ct = (int)(tile % ncoltiles);
   int t2 = (int)(tile / ncoltiles);
-  const int m = upper_m(g.ktile_pref, g.nsmax, t2);
+  const int m = upper_m(g.ktile_pref, g.nump, t2);  // local wavenumber number
   const int kt = t2 - g.ktile_pref[m];
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
-  const int ndglu = g.ndglu[m] < g.ndgnh ? g.ndglu[m] : g.ndgnh;
-  const int isl0 = g.ndgnh - ndglu;
+  const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
   const int nst = (ndglu + 7) >> 3;
   const long long wb = g.wbase[m];
 
@@ -387,12 +396,12 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
   // row numbers (fbase[lat]+m) are staged once per tile in LDS, so that looking them up is an LDS
   // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
   int *rowN = (int *)(Bs + 2 * 8 * LG_LDB);
-  int *rowS = rowN + ((g.ndgnh + 8) & ~7);
+  int *rowS = rowN + 8 * nst;
   for (int j = tid; j < 8 * nst; j += LG_THREADS) {
     int rn_ = -1, rs_ = -1;
     if (j < ndglu) {
-      rn_ = g.fbase[isl0 + j] + m;
-      rs_ = g.fbase[g.ndgl - 1 - isl0 - j] + m;
+      rn_ = g.legN[lb + j];
+      rs_ = g.legS[lb + j];
     }
     rowN[j] = rn_;
     rowS[j] = rs_;
@@ -796,7 +805,7 @@ EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
   const int fs = FFT_LDS_ELEMS(S);
   const double racthe = g.racthe[lat];
-  const long long frow = g.fbase[lat];
+  const int *frow = g.fftrow + g.fbase[lat];  // frow[k]: row of (lat, m=k) in the FFT-side buffer
   const d2 *tw = T.tw + pl.tw_off;
   const unsigned short *perm = T.perm + pl.perm_off;
   const d2 *rtw = T.rtw + pl.rtw_off;
@@ -810,8 +819,8 @@ EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
       const int npair = sz / 2 + 1;  // k = 0..sz/2 pairs with sz-k
       for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
         const int k2 = sz - k;
-        d2 xa = (k <= nmen) ? fsc_load(FB, frow + k, ldf, gf, k, racthe) : mk2(0, 0);
-        d2 xb = (k2 <= nmen) ? fsc_load(FB, frow + k2, ldf, gf, k2, racthe) : mk2(0, 0);
+        d2 xa = (k <= nmen) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
+        d2 xb = (k2 <= nmen) ? fsc_load(FB, frow[k2], ldf, gf, k2, racthe) : mk2(0, 0);
         // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
         d2 wk = cconj(rtw[k]);
         d2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
@@ -829,10 +838,10 @@ EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
       for (int k = EMI_TID; k < sz; k += EMI_NTHREADS) {
         d2 z;
         if (2 * k <= n) {
-          z = (k <= nmen) ? fsc_load(FB, frow + k, ldf, gf, k, racthe) : mk2(0, 0);
+          z = (k <= nmen) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
           if (k == 0) z.y = 0.0;
         } else {
-          z = (n - k <= nmen) ? cconj(fsc_load(FB, frow + n - k, ldf, gf, n - k, racthe)) : mk2(0, 0);
+          z = (n - k <= nmen) ? cconj(fsc_load(FB, frow[n - k], ldf, gf, n - k, racthe)) : mk2(0, 0);
         }
         af[FPAD(pl.blue ? k : (int)perm[k])] = pl.blue ? cmulc(z, chirp[k]) : z;
       }
@@ -893,7 +902,7 @@ EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
   const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
   const int fs = FFT_LDS_ELEMS(S);
-  const long long frow = g.fbase[lat];
+  const int *frow = g.fftrow + g.fbase[lat];
   const long long gp0 = g.gpoff[lat];
   const d2 *tw = T.tw + pl.tw_off;
   const unsigned short *perm = T.perm + pl.perm_off;
@@ -951,7 +960,7 @@ EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
         x = af[FPAD(k)];
         if (pl.blue) x = cscale(cmul(x, chirp[k]), invL);
       }
-      *(d2 *)(FB + (frow + k) * ldf + 2 * (f0 + fl)) = cscale(x, sc);
+      *(d2 *)(FB + (long long)frow[k] * ldf + 2 * (f0 + fl)) = cscale(x, sc);
     }
   }
 }
@@ -959,19 +968,14 @@ EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
 // ==========================================================================================
 // k_specnorm: SPNORMD (spnormd_mod.F90:40-57).  One block per field; deterministic order.
 // ==========================================================================================
-EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, const double *sp, int stride, double *out) {
+EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, long long nspec2, const double *sp, int stride, double *out) {
   EMI_LDS_DECL;
   double *red = (double *)EMI_LDS_PTR;
-  const int f = EMI_BID, N = g.nsmax;
-  const long long nspec2 = (long long)(N + 1) * (N + 2);
+  const int f = EMI_BID;
   double s = 0.0;
   for (long long i = EMI_TID; i < nspec2; i += EMI_NTHREADS) {
     double v = sp[i * stride + f];
-    // m = 0 block is the first 2(N+1) entries: real parts only, weight 1; others weight 2
-    if (i < 2LL * (N + 1))
-      s += (i & 1) ? 0.0 : v * v;
-    else
-      s += 2.0 * v * v;
+    s += g.specw[i] * v * v;  // m = 0: real parts weight 1, imaginary 0; m > 0: weight 2
   }
   red[EMI_TID] = s;
   EMI_SYNC();
@@ -979,5 +983,5 @@ EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, const double *sp, int stride, d
     if (EMI_TID < st) red[EMI_TID] += red[EMI_TID + st];
     EMI_SYNC();
   }
-  if (EMI_TID == 0) out[f] = sqrt(red[0]);
+  if (EMI_TID == 0) out[f] = red[0];  // sum of squares; the host takes the root (after the task sum)
 }

@@ -1,0 +1,80 @@
+"""Multi-GPU (one task per GPU) support: the all-to-all-v hook of the C-ABI over torch.distributed.
+
+The library shards one transform over tasks the way the reference does over its W-sets: zonal
+wavenumbers zig-zag over tasks (suwavedi_mod.F90:118-137), latitudes in contiguous bands, and ONE
+all-to-all-v per direction (TRLTOM/TRMTOL, trltom_mod.F90:96-136, trmtol_mod.F90:101-141) of whole
+blocks of the device-resident Fourier buffer.  Here that exchange is RCCL (`backend="nccl"` on
+ROCm) over xGMI; on the CPU test tier the same hook runs over gloo against the emulator build.
+
+    import torch.distributed as dist, ectrans_amd as et
+    dist.init_process_group("nccl", ...)
+    et.setup_trans0(kprtrw=dist.get_world_size(), myproc=dist.get_rank() + 1, device=local_rank)
+    r = et.setup_trans(nsmax, ndgl, nloen)      # local sizes: trans_inq(r, "nspec2"/"ngptot"/"myms"/...)
+"""
+import ctypes as C
+import sys
+import traceback
+
+import numpy as np
+
+_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p,
+                   C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int, C.c_void_p)
+_keep = []
+
+
+class _DeviceBuffer:
+    """Zero-copy view of raw device memory for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, nelem):
+        self.__cuda_array_interface__ = {"shape": (nelem,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def _as_tensor(ptr, nbytes, device):
+    import torch
+    n = int(nbytes) // 8
+    if n == 0:
+        return torch.empty(0, dtype=torch.float64, device=device)
+    if device.type == "cuda":
+        return torch.as_tensor(_DeviceBuffer(ptr, n), device=device)
+    arr = np.ctypeslib.as_array((C.c_double * n).from_address(int(ptr)))
+    return torch.from_numpy(arr)
+
+
+def make_alltoallv_hook(group=None, device=None):
+    """C callback implementing emi_alltoallv_fn with torch.distributed.all_to_all_single.
+
+    The collective is queued behind the transform kernels already on the current torch stream and the
+    kernels launched afterwards wait for it (torch.distributed stream semantics) -- no host sync."""
+    import torch
+    import torch.distributed as dist
+    device = torch.device(device) if device is not None else torch.device("cpu")
+
+    def hook(user, sb, sc, sd, rb, rc, rd, nproc, stream):
+        try:
+            scl, sdl = [int(sc[i]) for i in range(nproc)], [int(sd[i]) for i in range(nproc)]
+            rcl, rdl = [int(rc[i]) for i in range(nproc)], [int(rd[i]) for i in range(nproc)]
+            # blocks are dense and ordered by task: the buffers are exactly sum(counts) long
+            assert all(sdl[i] == sum(scl[:i]) for i in range(nproc)) and all(rdl[i] == sum(rcl[:i]) for i in range(nproc))
+            send = _as_tensor(sb, sum(scl), device)
+            recv = _as_tensor(rb, sum(rcl), device)
+            dist.all_to_all_single(recv, send, output_split_sizes=[c // 8 for c in rcl],
+                                   input_split_sizes=[c // 8 for c in scl], group=group)
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            traceback.print_exc(file=sys.stderr)
+            return -1
+
+    cb = _A2A(hook)
+    _keep.append(cb)
+    return cb
+
+
+def all_reduce_sum(values, group=None, device=None):
+    """Sum a small numpy vector over tasks (SPECNORM's gather, spnormc_mod.F90:49-85)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64))
+    if device is not None and torch.device(device).type == "cuda":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()

@@ -66,10 +66,11 @@ typedef struct {
 int emi_setup(const emi_setup_t *cfg, int *kresol);
 
 /* ---- TRANS_INQ (trans/cpu/external/trans_inq.F90:11-529), subset used by callers ----- */
-/* integer scalars: "nspec2" "nspec2g" "ngptot" "ngptotg" "nump" "ndgl" "nsmax" "ndglu"...  */
+/* integer scalars: "nspec2" "nspec2g" "nspec2mx" "ngptot" "ngptotg" "ngptotmx" "nump" "ndgl" "nsmax"
+ * "ndlon" "nproc" "myproc" "nfrstlat" "nlstlat"                                           */
 int emi_inq_int(int kresol, const char *name, int *value);
 /* integer arrays: "nloen"(ndgl) "nmen"(ndgl) "ndglu"(nsmax+1) "nasm0"(nsmax+1, 1-based as
- * D%NASM0) "myms"(nump)                                                                   */
+ * D%NASM0, -99 for wavenumbers of other tasks) "myms"(nump) "procm"(nsmax+1) "latlo"(nproc+1) */
 int emi_inq_int_array(int kresol, const char *name, int *out, int len);
 /* real arrays: "rmu"/"pmu"(ndgl) "rgw"/"pgw"(ndgl)                                        */
 int emi_inq_real_array(int kresol, const char *name, double *out, int len);
@@ -128,6 +129,19 @@ int emi_dir_trans(int kresol, const emi_dirtrans_t *args);
 
 /* ---- SPECNORM (trans/include/ectrans/specnorm.h:12) --------------------------------- */
 int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms /* host */);
+
+/* ---- TRLTOM / TRMTOL (trans/cpu/internal/trltom_mod.F90:96-136, trmtol_mod.F90:101-141) ---------
+ * With nproc > 1 every task owns the zonal wavenumbers of its W-set (zig-zag, suwavedi_mod.F90:118-137)
+ * and a contiguous latitude band; each transform needs ONE all-to-all-v of whole blocks of the
+ * device-resident Fourier buffer.  The host supplies it as a hook (RCCL through torch.distributed,
+ * an MPI_Alltoallv on GPU-aware MPI, ...): counts and displacements are in BYTES, one entry per
+ * task; buffers are device pointers; the call must be ordered after the work already queued on
+ * `stream` and must complete (or be stream-ordered) before work queued on it afterwards.         */
+typedef int (*emi_alltoallv_fn)(void *user, const void *sendbuf, const long long *sendcounts, const long long *sdispls,
+                                void *recvbuf, const long long *recvcounts, const long long *rdispls, int nproc, void *stream);
+int emi_set_alltoallv(emi_alltoallv_fn fn, void *user);
+/* This task's share of the SPECNORM sums (spnormd_mod.F90); sum over tasks, then sqrt.          */
+int emi_specnorm_partial(int kresol, int mem_space, const void *spec, int nfld, double *sumsq /* host */);
 
 /* ---- TRANS_RELEASE / TRANS_END (trans/cpu/external/trans_release.F90, trans_end.F90) -- */
 int emi_release(int kresol);

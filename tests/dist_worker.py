@@ -1,0 +1,67 @@
+"""One task of the world_size-2 gloo test (launched by tests/test_dist_gloo.py).
+
+Runs the real host logic + kernels (CPU functional emulator build) with the W-set sharding and the
+all-to-all-v hook over gloo, and checks every local piece against the oracle's global result."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch.distributed as dist  # noqa: E402
+
+import ectrans_amd as et  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+from tests.common import octahedral, random_spectrum, rel_err  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    et._use_library_for_tests(os.path.join(ROOT, "tests", "emu", "libectrans_mi_emu.so"))
+    et.setup_trans0(kmax_resol=2, kprtrw=world, myproc=rank + 1, device=None)
+    N = int(os.environ.get("EMI_TEST_NSMAX", "10"))
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    o = Oracle(N, nloen)
+    rng = np.random.default_rng(11)  # same global fields on every task
+    nuv, nsc = 1, 2
+    vor = random_spectrum(rng, o.nasm0, N, o.nspec2, nuv, True)
+    div = random_spectrum(rng, o.nasm0, N, o.nspec2, nuv, True)
+    sc = random_spectrum(rng, o.nasm0, N, o.nspec2, nsc, False)
+    gref = o.inv_trans(spvor=vor, spdiv=div, spsc=sc, scders=True, uvder=True)
+    # ---- local pieces
+    myms = et.trans_inq(r, "myms")
+    nasm0 = et.trans_inq(r, "nasm0")
+    procm = et.trans_inq(r, "procm")
+    assert all(procm[m] == rank + 1 for m in myms) and sorted(np.flatnonzero(procm == rank + 1)) == sorted(myms)
+    ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+    assert ns2 == sum(2 * (N - m + 1) for m in myms)
+    gidx = np.concatenate([np.arange(o.nasm0[m] - 1, o.nasm0[m] - 1 + 2 * (N - m + 1)) for m in myms])
+    assert all(nasm0[m] >= 1 for m in myms) and all(nasm0[m] == -99 for m in range(N + 1) if m not in set(myms))
+    lat0, lat1 = et.trans_inq(r, "nfrstlat") - 1, et.trans_inq(r, "nlstlat")
+    gp0 = int(nloen[:lat0].sum())
+    assert ng == int(nloen[lat0:lat1].sum())
+    loc = lambda a: np.ascontiguousarray(a[gidx])
+    gp = np.zeros((1, gref.shape[0], ng))
+    et.inv_trans(r, pspvor=loc(vor), pspdiv=loc(div), pspscalar=loc(sc), pgp=gp, ldscders=True, lduvder=True)
+    e_inv = rel_err(gp[0], gref[:, gp0:gp0 + ng], axis=1)
+    gdir = gref[:2 * nuv + nsc]
+    v2, d2, s2 = np.zeros((ns2, nuv)), np.zeros((ns2, nuv)), np.zeros((ns2, nsc))
+    et.dir_trans(r, pspvor=v2, pspdiv=d2, pspscalar=s2, pgp=np.ascontiguousarray(gdir[None, :, gp0:gp0 + ng]))
+    vr, dr, sr = o.dir_trans(gdir, nuv=nuv, nsc=nsc)
+    e_dir = max(rel_err(a, b[gidx]) for a, b in ((v2, vr), (d2, dr), (s2, sr)))
+    e_norm = np.abs(et.specnorm(r, loc(sc)) / o.specnorm(sc) - 1.0).max()
+    print("rank %d/%d: nump %d nlat %d e_inv %.2e e_dir %.2e e_norm %.2e" % (rank, world, len(myms), lat1 - lat0, e_inv, e_dir, e_norm),
+          flush=True)
+    assert e_inv < 1e-12 and e_dir < 1e-12 and e_norm < 1e-13, (e_inv, e_dir, e_norm)
+    et.trans_release(r)
+    et.trans_end()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("DIST OK rank %d" % rank, flush=True)
+
+
+if __name__ == "__main__":
+    main()

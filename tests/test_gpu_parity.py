@@ -229,3 +229,25 @@ def test_errors_on_gpu(et, dev):
     with pytest.raises(et.TransError, match="same memory space"):
         et.inv_trans(r, pspscalar=np.zeros((ns2, 1)), pgp=to(np.zeros((1, 1, ng))))
     et.trans_release(r)
+
+
+def test_alltoallv_hook_over_rccl_single_rank(dev):
+    """The torch.distributed hook the multi-GPU path uses (ectrans_amd/dist.py), exercised on this
+    one-GPU box with a 1-rank RCCL group: raw device pointers -> tensors -> all_to_all_single."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from ectrans_amd import dist as edist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    hook = edist.make_alltoallv_hook(None, "cuda:0")
+    src = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+    dst = torch.zeros_like(src)
+    cnt = (C.c_longlong * 1)(src.numel() * 8)
+    dsp = (C.c_longlong * 1)(0)
+    rc = hook(None, src.data_ptr(), cnt, dsp, dst.data_ptr(), cnt, dsp, 1, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(src, dst)
+    dist.destroy_process_group()
