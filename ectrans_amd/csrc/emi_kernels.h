@@ -480,6 +480,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
 //     and stores the real row straight to the user's grid array (no LDS round trip)
 // ==========================================================================================
 #define FFT_MAXR 16
+#define FFT_TWPOW_MIN (1 << 30)  // chained twiddle powers measured no faster than table reads: off
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 
@@ -548,6 +549,41 @@ EMI_DEVFN void butterfly(d2 *v, const d2 *tw, int S, int sgn) {
       v[2 * k2] = t0[k2];
       v[2 * k2 + 1] = t1[k2];
     }
+  } else if (R == 16) {
+    // n = 4 n1 + n2, k = k1 + 4 k2, computed in place: after step 1 register 4*k1+n2 holds
+    // t[n2][k1]; after step 3 register 4*k1+k2 holds X[k1 + 4*k2] (un-permuted by the caller-side
+    // index map OUT16 below, which is static)
+    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+      d2 a0 = v[n2], a1 = v[4 + n2], a2 = v[8 + n2], a3 = v[12 + n2];
+      bf4(a0, a1, a2, a3, sgn);
+      v[n2] = a0;       // k1 = 0
+      v[4 + n2] = a1;   // k1 = 1
+      v[8 + n2] = a2;   // k1 = 2
+      v[12 + n2] = a3;  // k1 = 3
+    }
+    const double wc[10] = {1.0, c1, h, s1, 0.0, -s1, -h, -c1, -1.0, -c1};
+    const double ws[10] = {0.0, s1, h, c1, 1.0, c1, h, s1, 0.0, -s1};
+#pragma unroll
+    for (int k1 = 1; k1 < 4; k1++)
+#pragma unroll
+      for (int n2 = 1; n2 < 4; n2++) {
+        const int e = n2 * k1;
+        v[4 * k1 + n2] = cmul(v[4 * k1 + n2], mk2(wc[e], (sgn < 0) ? -ws[e] : ws[e]));
+      }
+    d2 y[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+      d2 a0 = v[4 * k1], a1 = v[4 * k1 + 1], a2 = v[4 * k1 + 2], a3 = v[4 * k1 + 3];
+      bf4(a0, a1, a2, a3, sgn);
+      y[k1] = a0;
+      y[k1 + 4] = a1;
+      y[k1 + 8] = a2;
+      y[k1 + 12] = a3;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = y[u];
   } else {
     // generic small prime (7): DFT matrix rows from the twiddle table, fully unrolled
     d2 y[R], w[R];
@@ -595,20 +631,25 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
         const int i = base + t * lenp;
         v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
       }
-      d2 w[R];
-      if (lenp > 1) {
-#pragma unroll
-        for (int t = 1; t < R; t++) w[t] = tw_get(ptw, (t - 1) * lenp + j, sgn);
-      }
-      if (!DIF && lenp > 1) {
-#pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
-      }
+      // inter-pass twiddles W_len^{j t}.  Small strides: coalesced reads of the per-pass table (it
+      // stays in L1/L2).  Large strides: the table would be streamed from L2 once per butterfly, so
+      // only W^j is fetched and the powers are built by a product chain (<= R-2 products, error of a
+      // few ulp), without keeping a twiddle array alive (register pressure).
+#define FFT_APPLY_TW()                                                              \
+  if (lenp >= FFT_TWPOW_MIN && R > 2) {                                             \
+    const d2 w1 = tw_get(ptw, j, sgn);                                              \
+    d2 wt = w1;                                                                     \
+    v[1] = cmul(v[1], wt);                                                          \
+    _Pragma("unroll") for (int t = 2; t < R; t++) {                                 \
+      wt = cmul(wt, w1);                                                            \
+      v[t] = cmul(v[t], wt);                                                        \
+    }                                                                               \
+  } else if (lenp > 1) {                                                            \
+    _Pragma("unroll") for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(ptw, (t - 1) * lenp + j, sgn)); \
+  }
+      if (!DIF) FFT_APPLY_TW();
       butterfly<R>(v, tw, S, sgn);
-      if (DIF && lenp > 1) {
-#pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
-      }
+      if (DIF) FFT_APPLY_TW();
 #pragma unroll
       for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
     }
@@ -748,9 +789,9 @@ EMI_DEVFN void dit_last_to_grid(d2 *a, int nfl, int fs, int S, int lenp, const d
       d2 v[R];
 #pragma unroll
       for (int t = 0; t < R; t++) v[t] = af[FPAD(j + t * lenp)];
-      if (lenp > 1) {
-#pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(ptw, (t - 1) * lenp + j, +1));
+      {
+        const int sgn = +1;
+        FFT_APPLY_TW();
       }
       butterfly<R>(v, tw, S, +1);
 #pragma unroll
