@@ -480,7 +480,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double 
 //     and stores the real row straight to the user's grid array (no LDS round trip)
 // ==========================================================================================
 #define FFT_MAXR 16
-#define FFT_TWPOW_MIN (1 << 30)  // chained twiddle powers measured no faster than table reads: off
+#define FFT_TWPOW_MIN (1 << 30)  // chained twiddle powers (1 load + R-2 products) measured no faster than the coalesced table reads: off
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 
@@ -647,9 +647,13 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
   } else if (lenp > 1) {                                                            \
     _Pragma("unroll") for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(ptw, (t - 1) * lenp + j, sgn)); \
   }
-      if (!DIF) FFT_APPLY_TW();
+      if (!DIF) {
+        FFT_APPLY_TW();
+      }
       butterfly<R>(v, tw, S, sgn);
-      if (DIF) FFT_APPLY_TW();
+      if (DIF) {
+        FFT_APPLY_TW();
+      }
 #pragma unroll
       for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
     }
