@@ -115,10 +115,11 @@ static int upload(const std::vector<T> &h, T **d) {
 struct FftClass {
   std::vector<int> lats;
   int *d_lats = nullptr;
-  int *d_pref = nullptr;    // rebuilt when the field count changes
-  int pref_nfld = -1;
-  long long nblocks = 0;
   size_t lds = 0;
+};
+struct FftPref {  // block -> (latitude, field chunk) prefix tables of the three LDS classes for one field count
+  int *d_pref[3] = {nullptr, nullptr, nullptr};
+  long long nblocks[3] = {0, 0, 0};
 };
 
 struct Plan {
@@ -151,6 +152,7 @@ struct Plan {
   std::vector<int> planid;  // [nlat]
   FftTabDev ftab{};
   FftClass fclass[3];
+  std::map<int, FftPref> prefs;  // by field count
   // work buffers (grown on demand): W, Legendre-side Fourier buffer, FFT-side Fourier buffer
   // (the same allocation when nproc == 1)
   double *d_W = nullptr, *d_FBL = nullptr, *d_FBF = nullptr;
@@ -697,7 +699,8 @@ extern "C" int emi_release(int kresol) {
   if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_RELEASE: unknown resolution %d", kresol);
   emi_stream_sync(0);
   for (void *p : P->dev_allocs) emi_dev_free(p);
-  for (int c = 0; c < 3; c++) emi_dev_free(P->fclass[c].d_pref);
+  for (auto &kv : P->prefs)
+    for (int c = 0; c < 3; c++) emi_dev_free(kv.second.d_pref[c]);
   emi_dev_free(P->d_W);
   emi_dev_free(P->d_FBL);
   if (P->d_FBF != P->d_FBL) emi_dev_free(P->d_FBF);
@@ -886,11 +889,11 @@ static int grow(double **p, size_t *cap, size_t need, const char *what) {
   return 0;
 }
 
-static int ensure_work(Plan &P, int bfpad) {
+static int ensure_work(Plan &P, int bfpad, int nfb) {
   const size_t rowb = (size_t)2 * bfpad * 8;
   if (grow(&P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer")) return -1;
   if (P.nproc == 1) {
-    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)P.frows * rowb, "Fourier work buffer")) return -1;
+    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * P.frows * rowb, "Fourier work buffer")) return -1;
     P.d_FBF = P.d_FBL;
     P.cap_FBF = P.cap_FBL;
   } else {
@@ -932,81 +935,93 @@ static int ensure_desc(Plan &P, size_t bytes) {
   return 0;
 }
 
-static int fft_prefix(Plan &P, int nfld) {
-  for (int c = 0; c < 3; c++) {
-    FftClass &fc = P.fclass[c];
-    if (fc.pref_nfld == nfld) continue;
-    std::vector<int> pref(fc.lats.size() + 1, 0);
-    for (size_t i = 0; i < fc.lats.size(); i++) {
-      int fbk = P.fplans[P.planid[fc.lats[i]]].fbk;
-      pref[i + 1] = pref[i] + (nfld + fbk - 1) / fbk;
+static int fft_prefix(Plan &P, int nfld, FftPref **out) {
+  auto it = P.prefs.find(nfld);
+  if (it == P.prefs.end()) {
+    if (P.prefs.size() > 64) {  // bounded cache
+      emi_stream_sync(0);
+      for (auto &kv : P.prefs)
+        for (int c = 0; c < 3; c++) emi_dev_free(kv.second.d_pref[c]);
+      P.prefs.clear();
     }
-    fc.nblocks = pref.back();
-    emi_stream_sync(0);
-    emi_dev_free(fc.d_pref);
-    fc.d_pref = nullptr;
-    if (upload(pref, &fc.d_pref)) return EMI_ERR_RUNTIME;
-    fc.pref_nfld = nfld;
+    FftPref fp;
+    for (int c = 0; c < 3; c++) {
+      FftClass &fc = P.fclass[c];
+      std::vector<int> pref(fc.lats.size() + 1, 0);
+      for (size_t i = 0; i < fc.lats.size(); i++) {
+        int fbk = P.fplans[P.planid[fc.lats[i]]].fbk;
+        pref[i + 1] = pref[i] + (nfld + fbk - 1) / fbk;
+      }
+      fp.nblocks[c] = pref.back();
+      if (upload(pref, &fp.d_pref[c])) return EMI_ERR_RUNTIME;
+    }
+    it = P.prefs.emplace(nfld, fp).first;
   }
+  *out = &it->second;
   return 0;
 }
 
-static int pick_batch(Plan &P, int nfields) {
-  // fields per batch: bounded by free HBM (W + FB rows x 16 B per field) and EMI_MAX_BATCH
+static int pick_batch(Plan &P, int nfields, int depth) {
+  // fields per batch: bounded by free HBM (W + FB rows x 16 B per field; FB twice when batches are
+  // pipelined) and EMI_MAX_BATCH; multiples of 64 fields so the 128-column tiles are full
   size_t fr = 0, tot = 0;
   emi_mem_info(&fr, &tot);
   size_t have = fr + P.cap_W + P.cap_FBL + (P.nproc > 1 ? P.cap_FBF : 0);
-  double per_field = (double)(P.wrows_total + P.frows + (P.nproc > 1 ? P.lrows : 0)) * 16.0;
+  const int nfb = depth > 1 ? 2 : 1;
+  double per_field = (double)(P.wrows_total + nfb * P.frows + (P.nproc > 1 ? P.lrows : 0)) * 16.0;
   long long cap = (long long)((double)have * 0.85 / per_field);
   cap = cap / 64 * 64;
   if (cap < 64) cap = 64;
   if (G.max_batch > 0) cap = std::min<long long>(cap, std::max(64, roundup(G.max_batch, 64)));
-  int nb = (int)((nfields + cap - 1) / cap);
-  if (nb < 1) nb = 1;
-  return (nfields + nb - 1) / nb;
+  long long want = roundup((nfields + depth - 1) / depth, 64);
+  return (int)std::min(cap, std::max(64LL, want));
 }
 
-// Per-phase device timing with HIP events recorded on the call's stream.  Nothing is
-// synchronised inside a transform call; emi_last_phase_ms() resolves the events lazily.
+// Per-phase device timing with HIP event pairs recorded on the stream each kernel runs on.
+// Nothing is synchronised inside a transform call; emi_last_phase_ms() resolves the events lazily.
 struct PhaseTimer {
-  static const int MAXEV = 4 * 64;
+  static const int MAXIV = 256;
   int n = 0;
   bool on = false;
-  int kinds[MAXEV];  // phase index of the interval ending at event i (-1: start marker)
+  int kinds[MAXIV];
 #ifndef EMI_CPU_EMU
-  hipEvent_t ev[MAXEV];
+  hipEvent_t e0[MAXIV], e1[MAXIV];
   bool created = false;
-  emi_stream_t s = 0;
-  void begin(bool on_, emi_stream_t s_) {
+  void begin(bool on_) {
     on = on_;
-    s = s_;
     n = 0;
     if (on && !created) {
-      for (auto &e : ev) (void)hipEventCreate(&e);
+      for (int i = 0; i < MAXIV; i++) {
+        (void)hipEventCreate(&e0[i]);
+        (void)hipEventCreate(&e1[i]);
+      }
       created = true;
     }
   }
-  void mark(int kind) {
-    if (on && n < MAXEV) {
-      kinds[n] = kind;
-      (void)hipEventRecord(ev[n++], s);
-    }
+  int start(int kind, emi_stream_t s) {
+    if (!on || n >= MAXIV) return -1;
+    kinds[n] = kind;
+    (void)hipEventRecord(e0[n], s);
+    return n++;
+  }
+  void stop(int iv, emi_stream_t s) {
+    if (iv >= 0) (void)hipEventRecord(e1[iv], s);
   }
   void resolve(double *ms3, int *launches) {
     for (int i = 0; i < 3; i++) ms3[i] = 0, launches[i] = 0;
-    if (!on || n == 0) return;
-    (void)hipEventSynchronize(ev[n - 1]);
-    for (int i = 1; i < n; i++)
-      if (kinds[i] >= 0) {
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
-        ms3[kinds[i]] += ms;
-        launches[kinds[i]]++;
-      }
+    if (!on) return;
+    for (int i = 0; i < n; i++) {
+      (void)hipEventSynchronize(e1[i]);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0[i], e1[i]);
+      ms3[kinds[i]] += ms;
+      launches[kinds[i]]++;
+    }
   }
 #else
-  void begin(bool, emi_stream_t) {}
-  void mark(int) {}
+  void begin(bool) {}
+  int start(int, emi_stream_t) { return -1; }
+  void stop(int, emi_stream_t) {}
   void resolve(double *ms3, int *launches) {
     for (int i = 0; i < 3; i++) ms3[i] = 0, launches[i] = 0;
   }
@@ -1014,17 +1029,89 @@ struct PhaseTimer {
 };
 static PhaseTimer g_pt;
 
-static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, double *FB, int ldf, int nproma, emi_stream_t st) {
+static void launch_fft(Plan &P, const FftPref &fp, bool inverse, const GridFld *d_flds, int nfld, double *FB, int ldf, int nproma,
+                       emi_stream_t st) {
   for (int c = 0; c < 3; c++) {
     FftClass &fc = P.fclass[c];
-    if (fc.lats.empty() || fc.nblocks == 0) continue;
-    FftLaunchDev lc{fc.d_lats, fc.d_pref, (int)fc.lats.size(), fc.nblocks};
+    if (fc.lats.empty() || fp.nblocks[c] == 0) continue;
+    FftLaunchDev lc{fc.d_lats, fp.d_pref[c], (int)fc.lats.size(), fp.nblocks[c]};
     const int nthr = c == 0 ? 256 : (c == 1 ? 512 : 1024);
     if (inverse)
-      EMI_LAUNCH(k_fft_inv, fc.nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma);
+      EMI_LAUNCH(k_fft_inv, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma);
     else
-      EMI_LAUNCH(k_fft_dir, fc.nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, FB, ldf, nproma);
+      EMI_LAUNCH(k_fft_dir, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, FB, ldf, nproma);
   }
+}
+
+// Two library-owned streams software-pipeline the field batches of one call: the Legendre kernels
+// (MFMA-bound) of batch b+1 run on stream A while the FFT kernels (fp64-VALU/LDS-bound) of batch b
+// run on stream B; the Fourier buffer is double-buffered.  Both are forked from / joined to the
+// caller's stream with events, so the call keeps ordinary stream semantics.
+struct Pipeline {
+#ifndef EMI_CPU_EMU
+  hipStream_t sA = nullptr, sB = nullptr;
+  std::vector<hipEvent_t> ev;
+  hipEvent_t fork = nullptr, joinA = nullptr, joinB = nullptr;
+  int init() {
+    if (sA) return 0;
+    EMI_CHECK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
+    EMI_CHECK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+    EMI_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    EMI_CHECK(hipEventCreateWithFlags(&joinA, hipEventDisableTiming));
+    EMI_CHECK(hipEventCreateWithFlags(&joinB, hipEventDisableTiming));
+    return 0;
+  }
+  hipEvent_t event(size_t i) {
+    while (ev.size() <= i) {
+      hipEvent_t e;
+      (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      ev.push_back(e);
+    }
+    return ev[i];
+  }
+  void begin(emi_stream_t user) {
+    (void)hipEventRecord(fork, user);
+    (void)hipStreamWaitEvent(sA, fork, 0);
+    (void)hipStreamWaitEvent(sB, fork, 0);
+  }
+  void end(emi_stream_t user) {
+    (void)hipEventRecord(joinA, sA);
+    (void)hipEventRecord(joinB, sB);
+    (void)hipStreamWaitEvent(user, joinA, 0);
+    (void)hipStreamWaitEvent(user, joinB, 0);
+  }
+  void signal(size_t i, emi_stream_t s) { (void)hipEventRecord(event(i), s); }
+  void wait(size_t i, emi_stream_t s) { (void)hipStreamWaitEvent(s, event(i), 0); }
+#else
+  void *sA = nullptr, *sB = nullptr;
+  int init() { return 0; }
+  void begin(emi_stream_t) {}
+  void end(emi_stream_t) {}
+  void signal(size_t, emi_stream_t) {}
+  void wait(size_t, emi_stream_t) {}
+#endif
+};
+static Pipeline g_pipe;
+
+// number of field batches to pipeline (1 = plain sequential execution on the caller's stream)
+static int pipeline_depth(const Plan &P, int nfields) {
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char *e = getenv("EMI_PIPELINE");
+    // default 1 = sequential: on MI355X co-running the two kernel families was measured SLOWER
+    // (TCo1279/KF=1645: 555 vs 531 ms per pair with depth 4) -- the FFT kernels need all 16 waves per
+    // CU to hide latency and the Legendre kernels lose MFMA issue slots; kept as an option.
+    cfg = e ? atoi(e) : 1;
+    if (cfg < 1) cfg = 1;
+  }
+#ifdef EMI_CPU_EMU
+  (void)P;
+  (void)nfields;
+  return 1;
+#else
+  if (P.nproc > 1 || nfields < 256) return 1;  // the exchange hook is ordered on the caller's stream
+  return cfg;
+#endif
 }
 
 #ifndef EMI_CPU_EMU
@@ -1188,15 +1275,20 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
   }
   if (lscders) for (int i = 0; i < nsc; i++) push(dest_sc(i, 2), GM_EWDER, i_sc + i);
 
-  // ---- batches over Legendre-space fields
-  const int bsz = pick_batch(P, nlt);
+  // ---- batches over Legendre-space fields, software-pipelined over two streams
+  const int depth = pipeline_depth(P, nlt);
+  const int bsz = pick_batch(P, nlt, depth);
+  const int nbat = (nlt + bsz - 1) / bsz;
+  const bool piped = depth > 1 && nbat > 1;
   const int bfpad = roundup(std::min(bsz, nlt), 64);
-  if (ensure_work(P, bfpad)) return EMI_ERR_RUNTIME;
+  if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
   const int ldw = 2 * bfpad;
-  g_pt.begin(G.profile, st);
+  // all descriptors of the call in one upload
+  struct Bat { size_t off_l, off_g; int nl, ng; FftPref *fp; };
+  std::vector<Bat> bats;
+  std::vector<char> hdesc;
   for (int b0 = 0; b0 < nlt; b0 += bsz) {
     const int nb = std::min(bsz, nlt - b0);
-    std::vector<SpecSrc> bl(lt.begin() + b0, lt.begin() + b0 + nb);
     std::vector<GridFld> bg;
     for (auto &go : gout)
       if (go.lt >= b0 && go.lt < b0 + nb) {
@@ -1204,34 +1296,62 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
         g.src = go.lt - b0;
         bg.push_back(g);
       }
-    size_t off_g = (bl.size() * sizeof(SpecSrc) + 255) / 256 * 256;
-    size_t bytes = off_g + bg.size() * sizeof(GridFld);
-    if (ensure_desc(P, bytes)) return EMI_ERR_RUNTIME;
-    emi_stream_sync(st);  // descriptors of the previous batch are no longer in use
-    emi_h2d(P.d_desc, bl.data(), bl.size() * sizeof(SpecSrc), st);
-    emi_h2d((char *)P.d_desc + off_g, bg.data(), bg.size() * sizeof(GridFld), st);
-    emi_stream_sync(st);  // bl/bg are stack vectors
-    if (fft_prefix(P, (int)bg.size())) return EMI_ERR_RUNTIME;
-    const SpecSrc *d_bl = (const SpecSrc *)P.d_desc;
-    const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + off_g);
-    g_pt.mark(-1);
+    Bat bt{};
+    bt.nl = nb;
+    bt.ng = (int)bg.size();
+    bt.off_l = hdesc.size();
+    hdesc.resize(bt.off_l + ((size_t)nb * sizeof(SpecSrc) + 255) / 256 * 256);
+    memcpy(hdesc.data() + bt.off_l, lt.data() + b0, (size_t)nb * sizeof(SpecSrc));
+    bt.off_g = hdesc.size();
+    hdesc.resize(bt.off_g + (bg.size() * sizeof(GridFld) + 255) / 256 * 256);
+    memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
+    if (fft_prefix(P, bt.ng, &bt.fp)) return EMI_ERR_RUNTIME;
+    bats.push_back(bt);
+  }
+  if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
+  emi_h2d(P.d_desc, hdesc.data(), hdesc.size(), st);
+  emi_stream_sync(st);  // hdesc is a stack vector
+  emi_stream_t sA = st, sB = st;
+  if (piped) {
+    if (g_pipe.init()) return EMI_ERR_RUNTIME;
+    sA = (emi_stream_t)g_pipe.sA;
+    sB = (emi_stream_t)g_pipe.sB;
+    g_pipe.begin(st);
+  }
+  g_pt.begin(G.profile);
+  const size_t fbstride = (size_t)P.frows * ldw;
+  for (int ib = 0; ib < nbat; ib++) {
+    const Bat &bt = bats[ib];
+    const SpecSrc *d_bl = (const SpecSrc *)((char *)P.d_desc + bt.off_l);
+    const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
+    double *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride : 0);
+    double *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
+    // stream A: spectral pack + Legendre (needs FB[ib&1] released by the FFT of batch ib-2)
+    if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sA);
+    int iv = g_pt.start(0, sA);
     {
       long long total = (long long)P.wrows_total * bfpad;
       long long nblk = (total + 255) / 256;
-      EMI_LAUNCH(k_prepack_inv, nblk, 256, 0, st, P.g, d_bl, nb, bfpad, P.d_W, ldw, (long long)P.wrows_total);
+      EMI_LAUNCH(k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad, P.d_W, ldw, (long long)P.wrows_total);
     }
-    g_pt.mark(0);
+    g_pt.stop(iv, sA);
+    iv = g_pt.start(1, sA);
     {
       const int nct = ldw / LG_BN;
       long long ntiles = (long long)P.lattile_pref[P.nump] * nct;
-      EMI_LAUNCH(k_leg_inv, ntiles, LG_THREADS, LG_LDS_BYTES, st, P.g, nct, (const double *)P.d_W, ldw, P.d_FBL, ldw, ntiles);
+      EMI_LAUNCH(k_leg_inv, ntiles, LG_THREADS, LG_LDS_BYTES, sA, P.g, nct, (const double *)P.d_W, ldw, FBl, ldw, ntiles);
     }
-    g_pt.mark(1);
-    if (exchange(P, true, ldw, st)) return EMI_ERR_RUNTIME;  // TRMTOL
-    if (P.nproc > 1) g_pt.mark(-1);
-    launch_fft(P, true, d_bg, (int)bg.size(), P.d_FBF, ldw, nproma, st);
-    g_pt.mark(2);
+    g_pt.stop(iv, sA);
+    if (piped) g_pipe.signal(2 * ib, sA);
+    if (exchange(P, true, ldw, st)) return EMI_ERR_RUNTIME;  // TRMTOL (several tasks: never piped)
+    // stream B: FFTs
+    if (piped) g_pipe.wait(2 * ib, sB);
+    iv = g_pt.start(2, sB);
+    launch_fft(P, *bt.fp, true, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    g_pt.stop(iv, sB);
+    if (piped) g_pipe.signal(2 * ib + 1, sB);
   }
+  if (piped) g_pipe.end(st);
   if (host) hs.flush(st);
 #ifndef EMI_CPU_EMU
   EMI_CHECK(hipGetLastError());
@@ -1304,7 +1424,8 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   }
   // batches: atoms {u_i, v_i} and {scalar_j}
   const int natoms = nuv + nsc;
-  const int cap = pick_batch(P, 2 * nuv + nsc);
+  const int depth = pipeline_depth(P, 2 * nuv + nsc);
+  const int cap = pick_batch(P, 2 * nuv + nsc, depth);
   std::vector<std::vector<int>> batches;  // Fourier field indices
   {
     std::vector<int> cur;
@@ -1321,10 +1442,14 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   }
   int maxb = 0;
   for (auto &b : batches) maxb = std::max(maxb, (int)b.size());
+  const int nbat = (int)batches.size();
+  const bool piped = depth > 1 && nbat > 1;
   const int bfpad = roundup(maxb, 64);
-  if (ensure_work(P, bfpad)) return EMI_ERR_RUNTIME;
+  if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
   const int ldw = 2 * bfpad;
-  g_pt.begin(G.profile, st);
+  struct Bat { size_t off_g, off_o; int ng, no; FftPref *fp; };
+  std::vector<Bat> bats;
+  std::vector<char> hdesc;
   for (auto &b : batches) {
     std::vector<GridFld> bg;
     std::vector<SpecDst> bo;
@@ -1343,45 +1468,73 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
         bo.push_back(v);
       } else if (f >= 2 * nuv) {
         const ScalarRef &r = sc[f - 2 * nuv];
-        SpecDst s{};
-        s.kind = SPO_COPY; s.src0 = (int)i;
+        SpecDst sd{};
+        sd.kind = SPO_COPY; sd.src0 = (int)i;
         switch (r.arr) {
-          case 0: s.dst = d_sc[0]; s.stride = a.nf_scalar; s.idx = r.lev; break;
-          case 1: s.dst = d_sc[1]; s.stride = a.nf_sc2; s.idx = r.lev; break;
-          case 2: s.dst = d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev; s.stride = a.sc3a_nlev; s.idx = r.lev; break;
-          default: s.dst = d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev; s.stride = a.sc3b_nlev; s.idx = r.lev; break;
+          case 0: sd.dst = d_sc[0]; sd.stride = a.nf_scalar; sd.idx = r.lev; break;
+          case 1: sd.dst = d_sc[1]; sd.stride = a.nf_sc2; sd.idx = r.lev; break;
+          case 2: sd.dst = d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev; sd.stride = a.sc3a_nlev; sd.idx = r.lev; break;
+          default: sd.dst = d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev; sd.stride = a.sc3b_nlev; sd.idx = r.lev; break;
         }
-        bo.push_back(s);
+        bo.push_back(sd);
       }
     }
-    size_t off_o = (bg.size() * sizeof(GridFld) + 255) / 256 * 256;
-    size_t bytes = off_o + bo.size() * sizeof(SpecDst);
-    if (ensure_desc(P, bytes)) return EMI_ERR_RUNTIME;
-    emi_stream_sync(st);
-    emi_h2d(P.d_desc, bg.data(), bg.size() * sizeof(GridFld), st);
-    emi_h2d((char *)P.d_desc + off_o, bo.data(), bo.size() * sizeof(SpecDst), st);
-    emi_stream_sync(st);
-    if (fft_prefix(P, (int)bg.size())) return EMI_ERR_RUNTIME;
-    const GridFld *d_bg = (const GridFld *)P.d_desc;
-    const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + off_o);
-    g_pt.mark(-1);
-    launch_fft(P, false, d_bg, (int)bg.size(), P.d_FBF, ldw, nproma, st);
-    g_pt.mark(2);
-    if (exchange(P, false, ldw, st)) return EMI_ERR_RUNTIME;  // TRLTOM
-    if (P.nproc > 1) g_pt.mark(-1);
+    Bat bt{};
+    bt.ng = (int)bg.size();
+    bt.no = (int)bo.size();
+    bt.off_g = hdesc.size();
+    hdesc.resize(bt.off_g + (bg.size() * sizeof(GridFld) + 255) / 256 * 256);
+    memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
+    bt.off_o = hdesc.size();
+    hdesc.resize(bt.off_o + (bo.size() * sizeof(SpecDst) + 255) / 256 * 256);
+    memcpy(hdesc.data() + bt.off_o, bo.data(), bo.size() * sizeof(SpecDst));
+    if (fft_prefix(P, bt.ng, &bt.fp)) return EMI_ERR_RUNTIME;
+    bats.push_back(bt);
+  }
+  if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
+  emi_h2d(P.d_desc, hdesc.data(), hdesc.size(), st);
+  emi_stream_sync(st);
+  emi_stream_t sA = st, sB = st;
+  if (piped) {
+    if (g_pipe.init()) return EMI_ERR_RUNTIME;
+    sA = (emi_stream_t)g_pipe.sA;
+    sB = (emi_stream_t)g_pipe.sB;
+    g_pipe.begin(st);
+  }
+  g_pt.begin(G.profile);
+  const size_t fbstride = (size_t)P.frows * ldw;
+  for (int ib = 0; ib < nbat; ib++) {
+    const Bat &bt = bats[ib];
+    const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
+    const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + bt.off_o);
+    double *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride : 0);
+    double *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
+    // stream B: FFTs (need FB[ib&1] released by the Legendre transform of batch ib-2)
+    if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sB);
+    int iv = g_pt.start(2, sB);
+    launch_fft(P, *bt.fp, false, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    g_pt.stop(iv, sB);
+    if (piped) g_pipe.signal(2 * ib, sB);
+    if (exchange(P, false, ldw, st)) return EMI_ERR_RUNTIME;  // TRLTOM (several tasks: never piped)
+    // stream A: Legendre + spectral unpack
+    if (piped) g_pipe.wait(2 * ib, sA);
+    iv = g_pt.start(1, sA);
     {
       const int nct = ldw / LG_BN;
       long long ntiles = (long long)P.ktile_pref[P.nump] * nct;
-      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, st, P.g, nct, (const double *)P.d_FBL, ldw, P.d_W, ldw, ntiles);
+      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, sA, P.g, nct, (const double *)FBl, ldw, P.d_W, ldw, ntiles);
     }
-    g_pt.mark(1);
+    g_pt.stop(iv, sA);
+    if (piped) g_pipe.signal(2 * ib + 1, sA);
+    iv = g_pt.start(0, sA);
     {
-      long long total = (long long)P.wrows_total * (long long)bo.size();
+      long long total = (long long)P.wrows_total * (long long)bt.no;
       long long nblk = (total + 255) / 256;
-      EMI_LAUNCH(k_postpack_dir, nblk, 256, 0, st, P.g, d_bo, (int)bo.size(), (const double *)P.d_W, ldw, (long long)P.wrows_total);
+      EMI_LAUNCH(k_postpack_dir, nblk, 256, 0, sA, P.g, d_bo, bt.no, (const double *)P.d_W, ldw, (long long)P.wrows_total);
     }
-    g_pt.mark(0);
+    g_pt.stop(iv, sA);
   }
+  if (piped) g_pipe.end(st);
   if (host) hs.flush(st);
 #ifndef EMI_CPU_EMU
   EMI_CHECK(hipGetLastError());
