@@ -614,11 +614,13 @@ EMI_DEVFN void split_q(int q, int lenp, int sh, int &blk, int &j) {
 }
 EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_clz((unsigned)v)); }
 
-// one in-place pass over nfl fields.  nvalid: logical elements >= nvalid read as zero (first DIF
-// pass of a zero-padded Bluestein input).
-template <int R, int DIF>
+// one in-place pass over nfl fields.  MASK: logical elements >= nvalid read as zero (only the first
+// DIF pass of a zero-padded Bluestein input).  Index arithmetic is kept out of the per-element
+// path: for strides that are multiples of 128 the XOR swizzle commutes with the stride.
+template <int R, int DIF, int MASK>
 EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
   const int len = lenp * R, nb = S / R, sh = log2_exact(lenp);
+  const bool wide = (lenp & 127) == 0;  // FPAD(base + t*lenp) == FPAD(base) + t*lenp
   for (int fl = 0; fl < nfl; fl++) {
     d2 *af = a + (long long)fl * fstride;
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
@@ -626,15 +628,24 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
       split_q(q, lenp, sh, blk, j);
       const int base = blk * len + j;
       d2 v[R];
+      int pos[R];
+      if (wide) {
+        const int p0 = FPAD(base);
+#pragma unroll
+        for (int t = 0; t < R; t++) pos[t] = p0 + t * lenp;
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; t++) pos[t] = FPAD(base + t * lenp);
+      }
 #pragma unroll
       for (int t = 0; t < R; t++) {
-        const int i = base + t * lenp;
-        v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
+        if (MASK)
+          v[t] = (base + t * lenp < nvalid) ? af[pos[t]] : mk2(0.0, 0.0);
+        else
+          v[t] = af[pos[t]];
       }
-      // inter-pass twiddles W_len^{j t}.  Small strides: coalesced reads of the per-pass table (it
-      // stays in L1/L2).  Large strides: the table would be streamed from L2 once per butterfly, so
-      // only W^j is fetched and the powers are built by a product chain (<= R-2 products, error of a
-      // few ulp), without keeping a twiddle array alive (register pressure).
+      // inter-pass twiddles W_len^{j t}: coalesced reads of the per-pass table [t-1][j]
+      // (FFT_TWPOW_MIN: optional product chain from W^j, measured no faster)
 #define FFT_APPLY_TW()                                                              \
   if (lenp >= FFT_TWPOW_MIN && R > 2) {                                             \
     const d2 w1 = tw_get(ptw, j, sgn);                                              \
@@ -645,7 +656,8 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
       v[t] = cmul(v[t], wt);                                                        \
     }                                                                               \
   } else if (lenp > 1) {                                                            \
-    _Pragma("unroll") for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(ptw, (t - 1) * lenp + j, sgn)); \
+    const d2 *pw_ = ptw + j;                                                        \
+    _Pragma("unroll") for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(pw_, (t - 1) * lenp, sgn)); \
   }
       if (!DIF) {
         FFT_APPLY_TW();
@@ -655,7 +667,7 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
         FFT_APPLY_TW();
       }
 #pragma unroll
-      for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
+      for (int t = 0; t < R; t++) af[pos[t]] = v[t];
     }
   }
 }
@@ -681,11 +693,14 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
 
 template <int R>
 EMI_DEVFN void pass_dit(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
-  fft_pass<R, 0>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
+  fft_pass<R, 0, 0>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
 }
 template <int R>
 EMI_DEVFN void pass_dif(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
-  fft_pass<R, 1>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
+  if (nvalid < S)
+    fft_pass<R, 1, 1>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
+  else
+    fft_pass<R, 1, 0>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
 }
 
 // DIT passes ip = first..last-1 (factor order); returns lenp after them
