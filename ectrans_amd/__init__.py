@@ -309,7 +309,7 @@ def specnorm(kresol, pspec):
         return out
     from . import dist as _dist
     _chk(lib().emi_specnorm_partial(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
-    return np.sqrt(_dist.all_reduce_sum(out, _DIST["group"], _DIST["device"]))
+    return np.sqrt(_dist.all_reduce_sum(out, _DIST["group"], _DIST["device"]))  # every task gets the norms
 
 
 def trans_release(kresol):

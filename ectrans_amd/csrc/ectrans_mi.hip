@@ -117,6 +117,17 @@ struct FftClass {
   int *d_lats = nullptr;
   size_t lds = 0;
 };
+// Legendre tile maps for one column-tile count: block id -> (ml, row tile, column tile).
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).  Each XCD gets, for
+// every wavenumber, a fixed range of column tiles (and, when there are fewer column tiles than XCDs,
+// a residue class of row tiles): the ~64 tiles an XCD has in flight then share a few operand column
+// blocks and the Legendre-panel row blocks of one m in its 4 MiB L2, instead of streaming 26 different
+// column blocks per row tile (measured: 13x the algorithmic HBM bytes).  Tiles stay m-ascending
+// (longest K first) within every XCD, so all XCDs progress through m together.
+struct LegMaps {
+  int2 *d_inv = nullptr, *d_dir = nullptr;
+  long long n_inv = 0, n_dir = 0;
+};
 struct FftPref {  // block -> (latitude, field chunk) prefix tables of the three LDS classes for one field count
   int *d_pref[3] = {nullptr, nullptr, nullptr};
   long long nblocks[3] = {0, 0, 0};
@@ -153,6 +164,7 @@ struct Plan {
   FftTabDev ftab{};
   FftClass fclass[3];
   std::map<int, FftPref> prefs;  // by field count
+  std::map<int, LegMaps> legmaps;  // by column-tile count
   // work buffers (grown on demand): W, Legendre-side Fourier buffer, FFT-side Fourier buffer
   // (the same allocation when nproc == 1)
   double *d_W = nullptr, *d_FBL = nullptr, *d_FBF = nullptr;
@@ -701,6 +713,10 @@ extern "C" int emi_release(int kresol) {
   for (void *p : P->dev_allocs) emi_dev_free(p);
   for (auto &kv : P->prefs)
     for (int c = 0; c < 3; c++) emi_dev_free(kv.second.d_pref[c]);
+  for (auto &kv : P->legmaps) {
+    emi_dev_free(kv.second.d_inv);
+    emi_dev_free(kv.second.d_dir);
+  }
   emi_dev_free(P->d_W);
   emi_dev_free(P->d_FBL);
   if (P->d_FBF != P->d_FBL) emi_dev_free(P->d_FBF);
@@ -932,6 +948,44 @@ static int ensure_desc(Plan &P, size_t bytes) {
   size_t cap = std::max(bytes, (size_t)1 << 16);
   if (emi_dev_malloc(&P.d_desc, cap)) return EMI_ERR_RUNTIME;
   P.cap_desc = cap;
+  return 0;
+}
+
+static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int2 **d_map, long long *nblocks) {
+  int gx = 1;
+  while (gx * 2 <= std::min(nct, 8)) gx *= 2;
+  const int gy = 8 / gx;
+  std::vector<std::vector<int2>> per(8);
+  for (int ml = 0; ml < P.nump; ml++) {
+    const int nrt = pref[ml + 1] - pref[ml];
+    for (int x = 0; x < 8; x++) {
+      // rotate the column ranges and row residues with ml: the ranges differ by one tile, rotation
+      // evens the per-XCD totals out (a fixed assignment leaves XCDs with 4 of 26 column tiles 23 %
+      // more work than those with 3)
+      const int xc = (x + ml) % gx, xl = (x / gx + ml) % gy;
+      const int c0 = (int)((long long)xc * nct / gx), c1 = (int)((long long)(xc + 1) * nct / gx);
+      for (int rt = xl; rt < nrt; rt += gy)
+        for (int ct = c0; ct < c1; ct++) per[x].push_back(int2{ml, (rt << 16) | ct});
+    }
+  }
+  size_t mx = 0;
+  for (auto &v : per) mx = std::max(mx, v.size());
+  std::vector<int2> map(mx * 8, int2{-1, 0});
+  for (int x = 0; x < 8; x++)
+    for (size_t k = 0; k < per[x].size(); k++) map[k * 8 + x] = per[x][k];
+  *nblocks = (long long)map.size();
+  return upload(map, d_map);
+}
+
+static int leg_tilemaps(Plan &P, int nct, LegMaps **out) {
+  auto it = P.legmaps.find(nct);
+  if (it == P.legmaps.end()) {
+    LegMaps lm;
+    if (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv, &lm.n_inv) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir, &lm.n_dir))
+      return EMI_ERR_RUNTIME;
+    it = P.legmaps.emplace(nct, lm).first;
+  }
+  *out = &it->second;
   return 0;
 }
 
@@ -1318,6 +1372,8 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     sB = (emi_stream_t)g_pipe.sB;
     g_pipe.begin(st);
   }
+  LegMaps *lmaps = nullptr;
+  if (leg_tilemaps(P, ldw / LG_BN, &lmaps)) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile);
   const size_t fbstride = (size_t)P.frows * ldw;
   for (int ib = 0; ib < nbat; ib++) {
@@ -1336,11 +1392,7 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     }
     g_pt.stop(iv, sA);
     iv = g_pt.start(1, sA);
-    {
-      const int nct = ldw / LG_BN;
-      long long ntiles = (long long)P.lattile_pref[P.nump] * nct;
-      EMI_LAUNCH(k_leg_inv, ntiles, LG_THREADS, LG_LDS_BYTES, sA, P.g, nct, (const double *)P.d_W, ldw, FBl, ldw, ntiles);
-    }
+    EMI_LAUNCH(k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const double *)P.d_W, ldw, FBl, ldw);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(2 * ib, sA);
     if (exchange(P, true, ldw, st)) return EMI_ERR_RUNTIME;  // TRMTOL (several tasks: never piped)
@@ -1501,6 +1553,8 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     sB = (emi_stream_t)g_pipe.sB;
     g_pipe.begin(st);
   }
+  LegMaps *lmaps = nullptr;
+  if (leg_tilemaps(P, ldw / LG_BN, &lmaps)) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile);
   const size_t fbstride = (size_t)P.frows * ldw;
   for (int ib = 0; ib < nbat; ib++) {
@@ -1519,11 +1573,7 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     // stream A: Legendre + spectral unpack
     if (piped) g_pipe.wait(2 * ib, sA);
     iv = g_pt.start(1, sA);
-    {
-      const int nct = ldw / LG_BN;
-      long long ntiles = (long long)P.ktile_pref[P.nump] * nct;
-      EMI_LAUNCH(k_leg_dir, ntiles, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, sA, P.g, nct, (const double *)FBl, ldw, P.d_W, ldw, ntiles);
-    }
+    EMI_LAUNCH(k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const double *)FBl, ldw, P.d_W, ldw);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(2 * ib + 1, sA);
     iv = g_pt.start(0, sA);

@@ -259,17 +259,17 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
 // ---- inverse: FB[lat][m][col] = sum_n P[lat,n] W[m][n][col]; north = S+A, south = S-A
 // (leinv_mod.F90:92-186 DGEMM('N','N') x2, asre1b_mod.F90:83-102)
 // tile: 64 latitudes x 128 columns, both parities; wave (wm, wn) owns 32 lat x 64 col.
-EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, int ncoltiles, const double *W, int ldw, double *FB, int ldf, long long ntiles) {
+EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const double *W, int ldw, double *FB, int ldf) {
   EMI_LDS_DECL;
   double *As = (double *)EMI_LDS_PTR;
   double *Bs = As + 2 * 8 * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int wm = w & 1, wn = w >> 1;
-  long long tile = xcd_swizzle(EMI_BID, ntiles, ncoltiles);
-  int ct = (int)(tile % ncoltiles);
-  int t2 = (int)(tile / ncoltiles);
-  const int m = upper_m(g.lattile_pref, g.nump, t2);  // local wavenumber number
-  const int lt = t2 - g.lattile_pref[m];
+  // host-built tile map (leg_tilemap): block -> (local wavenumber, latitude tile, column tile),
+  // 2-D blocked per XCD for L2 reuse; padding entries have x < 0
+  const int2 tm = tilemap[EMI_BID];
+  if (tm.x < 0) return;
+  const int m = tm.x, lt = tm.y >> 16, ct = tm.y & 0xffff;
   const int ld = g.ldp[m];
   const int lat0 = lt * 64, col0 = ct * LG_BN;
   const int nst = g.wrows[m] >> 4;
@@ -358,17 +358,15 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, int ncoltiles, const double 
 // (prfi2b_mod.F90:82-94, ledir_mod.F90:100-267 DGEMM('T','N') x2; Gaussian weights and
 //  1/(a cos) were folded into FB by k_fft_dir)
 // tile: 64 k (n-pairs) x 2 parities x 128 columns; wave (par, wn) owns 64 k x 64 col.
-EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, int ncoltiles, const double *FB, int ldf, double *W, int ldw, long long ntiles) {
+EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const double *FB, int ldf, double *W, int ldw) {
   EMI_LDS_DECL;
   double *As = (double *)EMI_LDS_PTR;
   double *Bs = As + 2 * 8 * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int par = w & 1, wn = w >> 1;
-  long long tile = xcd_swizzle(EMI_BID, ntiles, ncoltiles);
-  int ct = (int)(tile % ncoltiles);
-  int t2 = (int)(tile / ncoltiles);
-  const int m = upper_m(g.ktile_pref, g.nump, t2);  // local wavenumber number
-  const int kt = t2 - g.ktile_pref[m];
+  const int2 tm = tilemap[EMI_BID];
+  if (tm.x < 0) return;
+  const int m = tm.x, kt = tm.y >> 16, ct = tm.y & 0xffff;
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
@@ -615,12 +613,10 @@ EMI_DEVFN void split_q(int q, int lenp, int sh, int &blk, int &j) {
 EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_clz((unsigned)v)); }
 
 // one in-place pass over nfl fields.  MASK: logical elements >= nvalid read as zero (only the first
-// DIF pass of a zero-padded Bluestein input).  Index arithmetic is kept out of the per-element
-// path: for strides that are multiples of 128 the XOR swizzle commutes with the stride.
+// DIF pass of a zero-padded Bluestein input).
 template <int R, int DIF, int MASK>
 EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
   const int len = lenp * R, nb = S / R, sh = log2_exact(lenp);
-  const bool wide = (lenp & 127) == 0;  // FPAD(base + t*lenp) == FPAD(base) + t*lenp
   for (int fl = 0; fl < nfl; fl++) {
     d2 *af = a + (long long)fl * fstride;
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
@@ -628,21 +624,13 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
       split_q(q, lenp, sh, blk, j);
       const int base = blk * len + j;
       d2 v[R];
-      int pos[R];
-      if (wide) {
-        const int p0 = FPAD(base);
-#pragma unroll
-        for (int t = 0; t < R; t++) pos[t] = p0 + t * lenp;
-      } else {
-#pragma unroll
-        for (int t = 0; t < R; t++) pos[t] = FPAD(base + t * lenp);
-      }
 #pragma unroll
       for (int t = 0; t < R; t++) {
+        const int i = base + t * lenp;
         if (MASK)
-          v[t] = (base + t * lenp < nvalid) ? af[pos[t]] : mk2(0.0, 0.0);
+          v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
         else
-          v[t] = af[pos[t]];
+          v[t] = af[FPAD(i)];
       }
       // inter-pass twiddles W_len^{j t}: coalesced reads of the per-pass table [t-1][j]
       // (FFT_TWPOW_MIN: optional product chain from W^j, measured no faster)
@@ -667,7 +655,7 @@ EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *
         FFT_APPLY_TW();
       }
 #pragma unroll
-      for (int t = 0; t < R; t++) af[pos[t]] = v[t];
+      for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
     }
   }
 }

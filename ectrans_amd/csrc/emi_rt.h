@@ -81,6 +81,9 @@ typedef double v4d __attribute__((vector_size(32)));
 struct __attribute__((aligned(16))) d2 {
   double x, y;
 };
+struct int2 {
+  int x, y;
+};
 
 inline v4d emi_mfma_f64_16x16x4(double a, double b, v4d c) {
   EmuCtx *x = emu_ctx;

@@ -49,6 +49,8 @@ def make_alltoallv_hook(group=None, device=None):
     import torch.distributed as dist
     device = torch.device(device) if device is not None else torch.device("cpu")
 
+    staged = device.type == "cuda" and dist.get_backend(group) == "gloo"
+
     def hook(user, sb, sc, sd, rb, rc, rd, nproc, stream):
         try:
             scl, sdl = [int(sc[i]) for i in range(nproc)], [int(sd[i]) for i in range(nproc)]
@@ -57,8 +59,17 @@ def make_alltoallv_hook(group=None, device=None):
             assert all(sdl[i] == sum(scl[:i]) for i in range(nproc)) and all(rdl[i] == sum(rcl[:i]) for i in range(nproc))
             send = _as_tensor(sb, sum(scl), device)
             recv = _as_tensor(rb, sum(rcl), device)
-            dist.all_to_all_single(recv, send, output_split_sizes=[c // 8 for c in rcl],
-                                   input_split_sizes=[c // 8 for c in scl], group=group)
+            osz, isz = [c // 8 for c in rcl], [c // 8 for c in scl]
+            if staged:
+                # test configuration only (several ranks sharing one GPU, gloo has no device
+                # all-to-all): stage through the host, fully synchronised
+                torch.cuda.synchronize(device)
+                hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_to_all_single(hr, hs, output_split_sizes=osz, input_split_sizes=isz, group=group)
+                recv.copy_(hr)
+                torch.cuda.synchronize(device)
+            else:
+                dist.all_to_all_single(recv, send, output_split_sizes=osz, input_split_sizes=isz, group=group)
             return 0
         except Exception:  # never let an exception cross the C boundary
             traceback.print_exc(file=sys.stderr)
@@ -74,7 +85,7 @@ def all_reduce_sum(values, group=None, device=None):
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64))
-    if device is not None and torch.device(device).type == "cuda":
+    if device is not None and torch.device(device).type == "cuda" and dist.get_backend(group) != "gloo":
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()

@@ -19,8 +19,16 @@ from tests.common import octahedral, random_spectrum, rel_err  # noqa: E402
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    et._use_library_for_tests(os.path.join(ROOT, "tests", "emu", "libectrans_mi_emu.so"))
-    et.setup_trans0(kmax_resol=2, kprtrw=world, myproc=rank + 1, device=None)
+    on_gpu = os.environ.get("EMI_TEST_DEVICE", "cpu") == "cuda"
+    if on_gpu:  # all ranks share cuda:0; the hook stages the exchange through gloo (ectrans_amd/dist.py)
+        import torch
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+        back = lambda t: t.cpu().numpy()
+        et.setup_trans0(kmax_resol=2, kprtrw=world, myproc=rank + 1, device=0)
+    else:
+        to = back = lambda a: a
+        et._use_library_for_tests(os.path.join(ROOT, "tests", "emu", "libectrans_mi_emu.so"))
+        et.setup_trans0(kmax_resol=2, kprtrw=world, myproc=rank + 1, device=None)
     N = int(os.environ.get("EMI_TEST_NSMAX", "10"))
     nloen = octahedral(N)
     r = et.setup_trans(N, len(nloen), nloen)
@@ -44,15 +52,15 @@ def main():
     gp0 = int(nloen[:lat0].sum())
     assert ng == int(nloen[lat0:lat1].sum())
     loc = lambda a: np.ascontiguousarray(a[gidx])
-    gp = np.zeros((1, gref.shape[0], ng))
-    et.inv_trans(r, pspvor=loc(vor), pspdiv=loc(div), pspscalar=loc(sc), pgp=gp, ldscders=True, lduvder=True)
-    e_inv = rel_err(gp[0], gref[:, gp0:gp0 + ng], axis=1)
+    gp = to(np.zeros((1, gref.shape[0], ng)))
+    et.inv_trans(r, pspvor=to(loc(vor)), pspdiv=to(loc(div)), pspscalar=to(loc(sc)), pgp=gp, ldscders=True, lduvder=True)
+    e_inv = rel_err(back(gp)[0], gref[:, gp0:gp0 + ng], axis=1)
     gdir = gref[:2 * nuv + nsc]
-    v2, d2, s2 = np.zeros((ns2, nuv)), np.zeros((ns2, nuv)), np.zeros((ns2, nsc))
-    et.dir_trans(r, pspvor=v2, pspdiv=d2, pspscalar=s2, pgp=np.ascontiguousarray(gdir[None, :, gp0:gp0 + ng]))
+    v2, d2, s2 = to(np.zeros((ns2, nuv))), to(np.zeros((ns2, nuv))), to(np.zeros((ns2, nsc)))
+    et.dir_trans(r, pspvor=v2, pspdiv=d2, pspscalar=s2, pgp=to(gdir[None, :, gp0:gp0 + ng]))
     vr, dr, sr = o.dir_trans(gdir, nuv=nuv, nsc=nsc)
-    e_dir = max(rel_err(a, b[gidx]) for a, b in ((v2, vr), (d2, dr), (s2, sr)))
-    e_norm = np.abs(et.specnorm(r, loc(sc)) / o.specnorm(sc) - 1.0).max()
+    e_dir = max(rel_err(back(a), b[gidx]) for a, b in ((v2, vr), (d2, dr), (s2, sr)))
+    e_norm = np.abs(et.specnorm(r, to(loc(sc))) / o.specnorm(sc) - 1.0).max()
     print("rank %d/%d: nump %d nlat %d e_inv %.2e e_dir %.2e e_norm %.2e" % (rank, world, len(myms), lat1 - lat0, e_inv, e_dir, e_norm),
           flush=True)
     assert e_inv < 1e-12 and e_dir < 1e-12 and e_norm < 1e-13, (e_inv, e_dir, e_norm)

@@ -26,3 +26,29 @@ def test_transi_c_api():
     """trans_new/trans_setup/trans_inquire/trans_dirtrans/trans_invtrans/trans_specnorm
     (tests/transi/transi_test.c, modelled on the reference's transi_test_program.c)."""
     _run("transi", "transi_test", "TRANSI API OK")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_path_on_one_gpu(world):
+    """The N > 1 path with the REAL HIP kernels: `world` ranks share cuda:0 (RCCL cannot put two
+    ranks on one device, so the hook stages the all-to-all-v through gloo -- ectrans_amd/dist.py);
+    every rank checks its wavenumber/latitude share against the oracle (tests/dist_worker.py)."""
+    import sys
+    port = 29540 + world
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   EMI_TEST_NSMAX="63", EMI_TEST_DEVICE="cuda")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("DIST OK rank %d" % rank) in out, out
