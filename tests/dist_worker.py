@@ -26,7 +26,7 @@ def main():
         back = lambda t: t.cpu().numpy()
         et.setup_trans0(kmax_resol=2, kprtrw=world, myproc=rank + 1, device=0)
     else:
-        to = back = lambda a: a
+        to, back = (lambda a: np.ascontiguousarray(a)), (lambda a: a)
         et._use_library_for_tests(os.path.join(ROOT, "tests", "emu", "libectrans_mi_emu.so"))
         et.setup_trans0(kmax_resol=2, kprtrw=world, myproc=rank + 1, device=None)
     N = int(os.environ.get("EMI_TEST_NSMAX", "10"))
