@@ -83,13 +83,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("EMI_BENCH_ONE_GPU"):
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # EMI_BENCH_BACKEND=gloo + EMI_BENCH_ONE_GPU=1: test configuration (several ranks sharing one GPU,
+    # exchange staged through the host); the driver's runs use RCCL, one GPU per rank.
+    backend = os.environ.get("EMI_BENCH_BACKEND", "nccl")
+    rdev = dev if backend == "nccl" else torch.device("cpu")  # where small reductions live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import ectrans_amd as et
     N, nlev, nfld = args.nsmax, args.nlev, args.nfld
@@ -150,13 +159,13 @@ def main():
         leg_launches += ln[1]
     wm = et.work_model(r, kf)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # whole-job Legendre rate: flops of all ranks / slowest rank's kernel time
-        red = torch.tensor([wm["legendre_flops"], wm["fourier_bytes"], float(ngptot)], dtype=torch.float64, device=dev)
+        red = torch.tensor([wm["legendre_flops"], wm["fourier_bytes"], float(ngptot)], dtype=torch.float64, device=rdev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        mx = torch.tensor([leg_ms, fft_ms, pack_ms], dtype=torch.float64, device=dev)
+        mx = torch.tensor([leg_ms, fft_ms, pack_ms], dtype=torch.float64, device=rdev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         wm["legendre_flops"], wm["fourier_bytes"], ngptot = float(red[0]), float(red[1]), int(red[2].item())
         leg_ms, fft_ms, pack_ms = (float(x) for x in mx)
