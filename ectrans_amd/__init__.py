@@ -66,7 +66,7 @@ def build(force=False):
     """Compile libectrans_mi.so for gfx950 with hipcc (in-tree)."""
     import subprocess
     src = os.path.join(_HERE, "csrc", "ectrans_mi.hip")
-    deps = [src] + [os.path.join(_HERE, "csrc", f) for f in ("emi_kernels.h", "emi_rt.h", "emi_setup.h")]
+    deps = [src] + [os.path.join(_HERE, "csrc", f) for f in ("emi_kernels.h", "emi_kernels_body.h", "emi_types.h", "emi_rt.h", "emi_setup.h")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "ectrans_mi.h"))
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(d) for d in deps):
         return _LIBPATH
@@ -132,15 +132,15 @@ def _ptr(a, space):
     if a is None:
         return None, None
     if _is_torch(a):
-        if not a.is_contiguous() or str(a.dtype) != "torch.float64":
-            raise TransError("device arrays must be contiguous float64 tensors")
+        if not a.is_contiguous() or str(a.dtype) != "torch." + space[1]:
+            raise TransError("device arrays must be contiguous %s tensors" % space[1])
         if space[0] is None:
             space[0] = EMI_MEM_DEVICE if a.is_cuda else EMI_MEM_HOST
         elif space[0] != (EMI_MEM_DEVICE if a.is_cuda else EMI_MEM_HOST):
             raise TransError("all arrays of one call must live in the same memory space")
         return a.data_ptr(), a
-    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
-        raise TransError("host arrays must be C-contiguous float64 numpy arrays")
+    if not (isinstance(a, np.ndarray) and a.dtype == np.dtype(space[1]) and a.flags.c_contiguous):
+        raise TransError("host arrays must be C-contiguous %s numpy arrays" % space[1])
     if space[0] is None:
         space[0] = EMI_MEM_HOST
     elif space[0] != EMI_MEM_HOST:
@@ -173,10 +173,19 @@ def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, mypr
     _chk(lib().emi_init(C.byref(cfg)))
 
 
-def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, pstret=None):
-    """SETUP_TRANS (setup_trans.h:12-115); returns KRESOL."""
+_PREC = {}  # kresol -> array dtype name of that resolution
+
+
+def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, pstret=None, precision=8):
+    """SETUP_TRANS (setup_trans.h:12-115); returns KRESOL.
+
+    precision: 8 = the reference's double-precision library (libtrans_dp, JPRB=JPRD), arrays are
+    float64; 4 = its single-precision library (libtrans_sp, JPRB=JPRM), arrays are float32 (setup --
+    Gaussian latitudes, Legendre recurrences -- still runs in double, as in the reference)."""
+    if precision not in (4, 8):
+        raise TransError("SETUP_TRANS: precision must be 4 or 8")
     cfg = _Setup()
-    cfg.ksmax, cfg.kdgl, cfg.kdlon, cfg.precision = int(ksmax), int(kdgl), int(kdlon), 8
+    cfg.ksmax, cfg.kdgl, cfg.kdlon, cfg.precision = int(ksmax), int(kdgl), int(kdlon), int(precision)
     keep = None
     if kloen is not None:
         keep = np.ascontiguousarray(kloen, dtype=np.int32)
@@ -187,7 +196,13 @@ def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, ps
     cfg.ldstretch = int(pstret is not None and abs(pstret - 1.0) > 100 * np.finfo(float).eps)
     kresol = C.c_int(0)
     _chk(lib().emi_setup(C.byref(cfg), C.byref(kresol)))
+    _PREC[kresol.value] = "float32" if precision == 4 else "float64"
     return kresol.value
+
+
+def real_dtype(kresol):
+    """numpy dtype name of the arrays of resolution `kresol` ("float64" or "float32")."""
+    return _PREC.get(kresol, "float64")
 
 
 _INT_SCALARS = ("nspec2", "nspec2g", "nspec2mx", "nspec", "nspecg", "ngptot", "ngptotg", "ngptotmx", "nump", "ndgl",
@@ -270,7 +285,7 @@ def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
               ldscders=False, ldvorgp=False, lddivgp=False, lduvder=False, kproma=None, pgp=None, pgpuv=None,
               pgp3a=None, pgp3b=None, pgp2=None, stream=None):
     """INV_TRANS (inv_trans.h:12-163): spectral -> grid point, results written into pgp*/..."""
-    a, space, keep = _Inv(), [None], []
+    a, space, keep = _Inv(), [None, real_dtype(kresol)], []
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
     nproma = int(kproma) if kproma else ngptot
     ngpblks = (ngptot - 1) // nproma + 1
@@ -286,7 +301,7 @@ def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
 def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
               kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
     """DIR_TRANS (dir_trans.h:12-140): grid point -> spectral, results written into psp*."""
-    a, space, keep = _Dir(), [None], []
+    a, space, keep = _Dir(), [None, real_dtype(kresol)], []
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
     nproma = int(kproma) if kproma else ngptot
     ngpblks = (ngptot - 1) // nproma + 1
@@ -301,7 +316,7 @@ def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
 def specnorm(kresol, pspec):
     """SPECNORM (specnorm.h:12): per-field spectral L2 norm, returned as a numpy array (on every
     task; the reference returns it on the master only)."""
-    space = [None]
+    space = [None, real_dtype(kresol)]
     p, keep = _ptr(pspec, space)
     out = np.zeros(pspec.shape[1])
     if _DIST["nproc"] == 1:

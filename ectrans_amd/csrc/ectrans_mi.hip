@@ -157,7 +157,8 @@ struct Plan {
   // device
   EmiGeomDev g{};
   std::vector<void *> dev_allocs;
-  double *d_P = nullptr, *d_PT = nullptr;
+  int esz = 8;  // bytes per real: 8 (fp64 library, the reference's _dp build) or 4 (fp32, _sp)
+  char *d_P = nullptr, *d_PT = nullptr;  // esz-sized reals
   // fft
   std::vector<FftPlanDev> fplans;
   std::vector<int> planid;  // [nlat]
@@ -167,7 +168,7 @@ struct Plan {
   std::map<int, LegMaps> legmaps;  // by column-tile count
   // work buffers (grown on demand): W, Legendre-side Fourier buffer, FFT-side Fourier buffer
   // (the same allocation when nproc == 1)
-  double *d_W = nullptr, *d_FBL = nullptr, *d_FBF = nullptr;
+  char *d_W = nullptr, *d_FBL = nullptr, *d_FBF = nullptr;  // esz-sized reals; capacities in reals
   size_t cap_W = 0, cap_FBL = 0, cap_FBF = 0;
   void *d_desc = nullptr;
   size_t cap_desc = 0;
@@ -309,7 +310,7 @@ static int build_fft_plans(Plan &P) {
     }
     // fields per workgroup: as many as fit ~40 KiB of LDS (power of two, <= 16); longer rows get
     // one field per workgroup and more threads (512 / 1024) to keep the CU's SIMDs busy
-    size_t per_field = (size_t)FFT_LDS_ELEMS(pl.S) * 16;
+    size_t per_field = (size_t)FFT_LDS_ELEMS(pl.S) * 2 * P.esz;
     int fbk = 16;
     while (fbk > 1 && fbk * per_field > 40960) fbk >>= 1;
     pl.fbk = fbk;
@@ -329,16 +330,23 @@ static int build_fft_plans(Plan &P) {
     const FftPlanDev &pl = P.fplans[P.planid[j]];
     FftClass &fc = P.fclass[pl.lds_class];
     fc.lats.push_back(j);
-    fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 16);
+    fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 2 * P.esz);
   }
-  d2 *d_tw, *d_rtw, *d_chirp, *d_bhat, *d_ptw;
+  void *d_tw, *d_rtw, *d_chirp, *d_bhat, *d_ptw;
   uint16_t *d_perm;
   FftPlanDev *d_plans;
   int *d_planid;
-  if (upload(tw, &d_tw) || upload(ptw, &d_ptw) || upload(rtw, &d_rtw) || upload(chirp, &d_chirp) || upload(bhat, &d_bhat) || upload(perm, &d_perm) ||
+  // the tables are computed in (long) double and rounded once for the fp32 library
+  auto upload_c = [&](const std::vector<d2> &v, void **d) {
+    if (P.esz == 8) return upload(v, (d2 **)d);
+    std::vector<f2> w(v.size());
+    for (size_t i = 0; i < v.size(); i++) w[i] = f2{(float)v[i].x, (float)v[i].y};
+    return upload(w, (f2 **)d);
+  };
+  if (upload_c(tw, &d_tw) || upload_c(ptw, &d_ptw) || upload_c(rtw, &d_rtw) || upload_c(chirp, &d_chirp) || upload_c(bhat, &d_bhat) || upload(perm, &d_perm) ||
       upload(P.fplans, &d_plans) || upload(P.planid, &d_planid))
     return EMI_ERR_RUNTIME;
-  for (void *p : {(void *)d_tw, (void *)d_ptw, (void *)d_rtw, (void *)d_chirp, (void *)d_bhat, (void *)d_perm, (void *)d_plans, (void *)d_planid})
+  for (void *p : {d_tw, d_ptw, d_rtw, d_chirp, d_bhat, (void *)d_perm, (void *)d_plans, (void *)d_planid})
     P.dev_allocs.push_back(p);
   P.ftab.tw = d_tw;
   P.ftab.ptw = d_ptw;
@@ -362,7 +370,8 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   if (cfg->lduseflt) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: LDUSEFLT not supported (as gpu/external/setup_trans.F90:442)");
   if (cfg->ldll) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: LDLL lat-lon grids not supported (as gpu/external/setup_trans.F90:309)");
   if (cfg->ldstretch) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: PSTRET stretching not supported");
-  if (cfg->precision != 0 && cfg->precision != 8) EMI_FAIL(EMI_ERR_UNSUPPORTED, "emi_setup: only the fp64 (_dp) library is built");
+  if (cfg->precision != 0 && cfg->precision != 8 && cfg->precision != 4)
+    EMI_FAIL(EMI_ERR_ARG, "emi_setup: precision must be 8 (fp64, the _dp library) or 4 (fp32, _sp), got %d", cfg->precision);
   if (cfg->ksmax < 0) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KSMAX < 0");
   int slot = -1;
   for (int i = 0; i < G.max_resol; i++)
@@ -377,6 +386,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   P.ndgl = cfg->kdgl;
   P.ndgnh = (P.ndgl + 1) / 2;
   P.ra = G.ra;
+  P.esz = cfg->precision == 4 ? 4 : 8;
   P.nproc = G.nproc;
   P.me = G.myproc - 1;
   const int N = P.nsmax, L = P.ndgl, NP = P.nproc, me = P.me;
@@ -594,12 +604,13 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   // ---- Legendre panels of the local wavenumbers: PS[k][j] = P_{m+2k}^m(mu_{isl0+j}),
   // PA[k][j] = P_{m+2k+1}^m, zero padded; plus the [j][k] transposed copy for the direct transform
   void *dP = nullptr, *dPT = nullptr;
-  if (emi_dev_malloc(&dP, (size_t)P.p_elems * 8) || emi_dev_malloc(&dPT, (size_t)P.pt_elems * 8)) {
+  const size_t esz = P.esz;
+  if (emi_dev_malloc(&dP, (size_t)P.p_elems * esz) || emi_dev_malloc(&dPT, (size_t)P.pt_elems * esz)) {
     delete pp;
-    EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB for the Legendre panels", (P.p_elems + P.pt_elems) * 8.0 / (1 << 30));
+    EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB for the Legendre panels", (P.p_elems + P.pt_elems) * (double)esz / (1 << 30));
   }
-  P.d_P = (double *)dP;
-  P.d_PT = (double *)dPT;
+  P.d_P = (char *)dP;
+  P.d_PT = (char *)dPT;
   P.dev_allocs.push_back(dP);
   P.dev_allocs.push_back(dPT);
   {
@@ -620,13 +631,24 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
           for (int k = 0; m + 2 * k + par <= N + 1; k++) dst[(size_t)k * ld + j] = col[m + 2 * k + par];
         }
       }
-      if (emi_h2d(P.d_P + P.offS[ml], pan.data(), pan.size() * 8, 0)) bad = 1;
+      // the recurrences always run in double (as the reference's _sp build does: the JPRD work arrays of suleg_mod.F90:130-162);
+      // the fp32 library rounds the finished panel once
+      std::vector<float> cvt;
+      auto put = [&](char *dst, const std::vector<double> &v) {
+        if (esz == 8) return emi_h2d(dst, v.data(), v.size() * 8, 0);
+        cvt.resize(v.size());
+        for (size_t i = 0; i < v.size(); i++) cvt[i] = (float)v[i];
+        int rc = emi_h2d(dst, cvt.data(), cvt.size() * 4, 0);
+        emi_stream_sync(0);  // cvt is reused
+        return rc;
+      };
+      if (put(P.d_P + P.offS[ml] * esz, pan)) bad = 1;
       const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), 8);
       std::vector<double> pt((size_t)2 * ndp * ldk, 0.0);
       for (int par = 0; par < 2; par++)
         for (int k = 0; k < nk; k++)
           for (int j = 0; j < nd; j++) pt[((size_t)par * ndp + j) * ldk + k] = pan[((size_t)par * nk + k) * ld + j];
-      if (emi_h2d(P.d_PT + P.offTS[ml], pt.data(), pt.size() * 8, 0)) bad = 1;
+      if (put(P.d_PT + P.offTS[ml] * esz, pt)) bad = 1;
       emi_stream_sync(0);
     });
     if (bad) {
@@ -852,8 +874,16 @@ extern "C" int emi_inq_legendre(int kresol, int m, int symmetric, double *out, i
   if (!out) return EMI_SUCCESS;
   const int ld = P->ldp[ml], nk = P->wrows[ml] / 2;
   std::vector<double> pan((size_t)nk * ld);
-  if (emi_d2h(pan.data(), P->d_P + (symmetric ? P->offS[ml] : P->offA[ml]), pan.size() * 8, 0)) return EMI_ERR_RUNTIME;
-  emi_stream_sync(0);
+  const char *src = P->d_P + (symmetric ? P->offS[ml] : P->offA[ml]) * P->esz;
+  if (P->esz == 8) {
+    if (emi_d2h(pan.data(), src, pan.size() * 8, 0)) return EMI_ERR_RUNTIME;
+    emi_stream_sync(0);
+  } else {
+    std::vector<float> pf(pan.size());
+    if (emi_d2h(pf.data(), src, pf.size() * 4, 0)) return EMI_ERR_RUNTIME;
+    emi_stream_sync(0);
+    for (size_t i = 0; i < pf.size(); i++) pan[i] = pf[i];
+  }
   // reference column c (0-based) holds n descending: k = nc-1-c
   for (int c = 0; c < nc; c++)
     for (int j = 0; j < nd; j++) out[(size_t)c * nd + j] = pan[(size_t)(nc - 1 - c) * ld + j];
@@ -864,26 +894,28 @@ extern "C" int emi_inq_legendre(int kresol, int m, int symmetric, double *out, i
 // transforms
 // ------------------------------------------------------------------------------------------
 struct HostStage {  // staging of host arrays through device memory (mem_space == HOST)
+  size_t esz;
+  explicit HostStage(int e) : esz((size_t)e) {}
   std::vector<void *> dev;
   std::vector<std::pair<void *, std::pair<void *, size_t>>> outs;  // dev -> (host, bytes)
   ~HostStage() {
     for (void *p : dev) emi_dev_free(p);
   }
-  const double *in(const void *h, size_t elems, bool host, emi_stream_t s) {
-    if (!h || !host) return (const double *)h;
+  const void *in(const void *h, size_t elems, bool host, emi_stream_t s) {
+    if (!h || !host) return h;
     void *d = nullptr;
-    if (emi_dev_malloc(&d, elems * 8)) return nullptr;
+    if (emi_dev_malloc(&d, elems * esz)) return nullptr;
     dev.push_back(d);
-    emi_h2d(d, h, elems * 8, s);
-    return (const double *)d;
+    emi_h2d(d, h, elems * esz, s);
+    return d;
   }
-  double *out(void *h, size_t elems, bool host) {
-    if (!h || !host) return (double *)h;
+  void *out(void *h, size_t elems, bool host) {
+    if (!h || !host) return h;
     void *d = nullptr;
-    if (emi_dev_malloc(&d, elems * 8)) return nullptr;
+    if (emi_dev_malloc(&d, elems * esz)) return nullptr;
     dev.push_back(d);
-    outs.push_back({d, {h, elems * 8}});
-    return (double *)d;
+    outs.push_back({d, {h, elems * esz}});
+    return d;
   }
   void flush(emi_stream_t s) {
     for (auto &o : outs) emi_d2h(o.second.first, o.first, o.second.second, s);
@@ -891,7 +923,7 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
   }
 };
 
-static int grow(double **p, size_t *cap, size_t need, const char *what) {
+static int grow(char **p, size_t *cap, size_t need, const char *what) {
   if (need <= *cap) return 0;
   emi_stream_sync(0);
   emi_dev_free(*p);
@@ -899,14 +931,14 @@ static int grow(double **p, size_t *cap, size_t need, const char *what) {
   *cap = 0;
   void *q;
   if (emi_dev_malloc(&q, need)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB %s", need / 1073741824.0, what);
-  *p = (double *)q;
+  *p = (char *)q;
   *cap = need;
   emi_dev_memset(q, 0, need, 0);
   return 0;
 }
 
 static int ensure_work(Plan &P, int bfpad, int nfb) {
-  const size_t rowb = (size_t)2 * bfpad * 8;
+  const size_t rowb = (size_t)2 * bfpad * P.esz;
   if (grow(&P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer")) return -1;
   if (P.nproc == 1) {
     if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * P.frows * rowb, "Fourier work buffer")) return -1;
@@ -925,7 +957,7 @@ static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st) {
   if (P.nproc == 1) return 0;
   const int NP = P.nproc;
   std::vector<long long> sc(NP), sd(NP), rc(NP), rd(NP);
-  const long long rowb = (long long)ldf * 8;
+  const long long rowb = (long long)ldf * P.esz;
   for (int r = 0; r < NP; r++) {
     const long long lr = P.leg_rows[r] * rowb, ld = P.leg_disp[r] * rowb, fr = P.fft_rows[r] * rowb, fd = P.fft_disp[r] * rowb;
     sc[r] = to_fft ? lr : fr;
@@ -1022,7 +1054,7 @@ static int pick_batch(Plan &P, int nfields, int depth) {
   emi_mem_info(&fr, &tot);
   size_t have = fr + P.cap_W + P.cap_FBL + (P.nproc > 1 ? P.cap_FBF : 0);
   const int nfb = depth > 1 ? 2 : 1;
-  double per_field = (double)(P.wrows_total + nfb * P.frows + (P.nproc > 1 ? P.lrows : 0)) * 16.0;
+  double per_field = (double)(P.wrows_total + nfb * P.frows + (P.nproc > 1 ? P.lrows : 0)) * 2.0 * P.esz;
   long long cap = (long long)((double)have * 0.85 / per_field);
   cap = cap / 64 * 64;
   if (cap < 64) cap = 64;
@@ -1083,7 +1115,19 @@ struct PhaseTimer {
 };
 static PhaseTimer g_pt;
 
-static void launch_fft(Plan &P, const FftPref &fp, bool inverse, const GridFld *d_flds, int nfld, double *FB, int ldf, int nproma,
+// launch the fp64 or the fp32 instantiation of a kernel; RT names the real type inside the argument list
+#define EMI_LAUNCH_P(esz, kern, grid, block, lds, st, ...)                     \
+  do {                                                                         \
+    if ((esz) == 8) {                                                          \
+      typedef double RT;                                                       \
+      EMI_LAUNCH(emi_f64::kern, grid, block, lds, st, __VA_ARGS__);            \
+    } else {                                                                   \
+      typedef float RT;                                                        \
+      EMI_LAUNCH(emi_f32::kern, grid, block, lds, st, __VA_ARGS__);            \
+    }                                                                          \
+  } while (0)
+
+static void launch_fft(Plan &P, const FftPref &fp, bool inverse, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
                        emi_stream_t st) {
   for (int c = 0; c < 3; c++) {
     FftClass &fc = P.fclass[c];
@@ -1091,9 +1135,9 @@ static void launch_fft(Plan &P, const FftPref &fp, bool inverse, const GridFld *
     FftLaunchDev lc{fc.d_lats, fp.d_pref[c], (int)fc.lats.size(), fp.nblocks[c]};
     const int nthr = c == 0 ? 256 : (c == 1 ? 512 : 1024);
     if (inverse)
-      EMI_LAUNCH(k_fft_inv, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma);
+      EMI_LAUNCH_P(P.esz, k_fft_inv, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);
     else
-      EMI_LAUNCH(k_fft_dir, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, FB, ldf, nproma);
+      EMI_LAUNCH_P(P.esz, k_fft_dir, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
   }
 }
 
@@ -1172,8 +1216,10 @@ static int pipeline_depth(const Plan &P, int nfields) {
 static int set_lds_attrs() {
   static bool done = false;
   if (done) return 0;
-  EMI_CHECK(hipFuncSetAttribute((const void *)k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  EMI_CHECK(hipFuncSetAttribute((const void *)k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done = true;
   return 0;
 }
@@ -1241,20 +1287,20 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
   if (set_lds_attrs()) return EMI_ERR_RUNTIME;
 
   // ---- stage host arrays
-  HostStage hs;
+  HostStage hs(P.esz);
   const size_t ns2 = P.nspec2;
-  const double *d_vor = hs.in(a.spvor, ns2 * a.nf_uv, host && nuv, st), *d_div = hs.in(a.spdiv, ns2 * a.nf_uv, host && nuv, st);
-  const double *d_sc[4] = {hs.in(a.spscalar, ns2 * a.nf_scalar, host, st), hs.in(a.spsc2, ns2 * a.nf_sc2, host, st),
+  const void *d_vor = hs.in(a.spvor, ns2 * a.nf_uv, host && nuv, st), *d_div = hs.in(a.spdiv, ns2 * a.nf_uv, host && nuv, st);
+  const void *d_sc[4] = {hs.in(a.spscalar, ns2 * a.nf_scalar, host, st), hs.in(a.spsc2, ns2 * a.nf_sc2, host, st),
                            hs.in(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host, st),
                            hs.in(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host, st)};
   const int nvar_uv = ((nuv && lvorgp) ? 1 : 0) + ((nuv && ldivgp) ? 1 : 0) + 2 + (luvder ? 2 : 0);
   const int dmul = lscders ? 3 : 1;
   const size_t gsz = (size_t)nproma * ngpblks;
-  double *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host);
-  double *d_gpuv = hs.out(a.gpuv, gsz * nuv * nvar_uv, host && nuv);
-  double *d_gp2 = hs.out(a.gp2, gsz * a.nf_sc2 * dmul, host);
-  double *d_gp3a = hs.out(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar * dmul, host);
-  double *d_gp3b = hs.out(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar * dmul, host);
+  void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host);
+  void *d_gpuv = hs.out(a.gpuv, gsz * nuv * nvar_uv, host && nuv);
+  void *d_gp2 = hs.out(a.gp2, gsz * a.nf_sc2 * dmul, host);
+  void *d_gp3a = hs.out(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar * dmul, host);
+  void *d_gp3b = hs.out(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar * dmul, host);
 
   // ---- Legendre-space fields (ltinv_mod.F90:166-262): [vor][div] u v scalars [nsders]
   std::vector<SpecSrc> lt;
@@ -1264,8 +1310,8 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     switch (r.arr) {
       case 0: s.a = d_sc[0]; s.sa = a.nf_scalar; s.ia = r.lev; break;
       case 1: s.a = d_sc[1]; s.sa = a.nf_sc2; s.ia = r.lev; break;
-      case 2: s.a = d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev; s.sa = a.sc3a_nlev; s.ia = r.lev; break;
-      default: s.a = d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev; s.sa = a.sc3b_nlev; s.ia = r.lev; break;
+      case 2: s.a = (const char *)d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev * P.esz; s.sa = a.sc3a_nlev; s.ia = r.lev; break;
+      default: s.a = (const char *)d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev * P.esz; s.sa = a.sc3b_nlev; s.ia = r.lev; break;
     }
     return s;
   };
@@ -1380,19 +1426,19 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     const Bat &bt = bats[ib];
     const SpecSrc *d_bl = (const SpecSrc *)((char *)P.d_desc + bt.off_l);
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
-    double *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride : 0);
-    double *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
+    char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride * P.esz : 0);
+    char *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
     // stream A: spectral pack + Legendre (needs FB[ib&1] released by the FFT of batch ib-2)
     if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sA);
     int iv = g_pt.start(0, sA);
     {
       long long total = (long long)P.wrows_total * bfpad;
       long long nblk = (total + 255) / 256;
-      EMI_LAUNCH(k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad, P.d_W, ldw, (long long)P.wrows_total);
+      EMI_LAUNCH_P(P.esz, k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad, (RT *)P.d_W, ldw, (long long)P.wrows_total);
     }
     g_pt.stop(iv, sA);
     iv = g_pt.start(1, sA);
-    EMI_LAUNCH(k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const double *)P.d_W, ldw, FBl, ldw);
+    EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(2 * ib, sA);
     if (exchange(P, true, ldw, st)) return EMI_ERR_RUNTIME;  // TRMTOL (several tasks: never piped)
@@ -1440,16 +1486,16 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   if (if_gp == 0) return EMI_SUCCESS;
   if (set_lds_attrs()) return EMI_ERR_RUNTIME;
 
-  HostStage hs;
+  HostStage hs(P.esz);
   const size_t ns2 = P.nspec2, gsz = (size_t)nproma * ngpblks;
-  double *d_vor = hs.out(a.spvor, ns2 * a.nf_uv, host && nuv), *d_div = hs.out(a.spdiv, ns2 * a.nf_uv, host && nuv);
-  double *d_sc[4] = {hs.out(a.spscalar, ns2 * a.nf_scalar, host), hs.out(a.spsc2, ns2 * a.nf_sc2, host),
+  void *d_vor = hs.out(a.spvor, ns2 * a.nf_uv, host && nuv), *d_div = hs.out(a.spdiv, ns2 * a.nf_uv, host && nuv);
+  void *d_sc[4] = {hs.out(a.spscalar, ns2 * a.nf_scalar, host), hs.out(a.spsc2, ns2 * a.nf_sc2, host),
                      hs.out(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host), hs.out(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host)};
-  const double *d_gp = hs.in(a.gp, gsz * a.gp_nfld, host, st);
-  const double *d_gpuv = hs.in(a.gpuv, gsz * nuv * 2, host && nuv, st);
-  const double *d_gp2 = hs.in(a.gp2, gsz * a.nf_sc2, host, st);
-  const double *d_gp3a = hs.in(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar, host, st);
-  const double *d_gp3b = hs.in(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar, host, st);
+  const void *d_gp = hs.in(a.gp, gsz * a.gp_nfld, host, st);
+  const void *d_gpuv = hs.in(a.gpuv, gsz * nuv * 2, host && nuv, st);
+  const void *d_gp2 = hs.in(a.gp2, gsz * a.nf_sc2, host, st);
+  const void *d_gp3a = hs.in(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar, host, st);
+  const void *d_gp3b = hs.in(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar, host, st);
 
   // Fourier-space fields: u(nuv) v(nuv) scalars (dir_trans.F90:301, ftdir_ctl_mod.F90)
   std::vector<GridFld> gin;
@@ -1457,8 +1503,8 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   for (int var = 0; var < 2 && nuv; var++)
     for (int i = 0; i < nuv; i++) {
       GridFld g{};
-      if (d_gp) { g.base = (double *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
-      else { g.base = (double *)d_gpuv; g.nf_arr = nuv * 2; g.fidx = var * nuv + i; }
+      if (d_gp) { g.base = (void *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
+      else { g.base = (void *)d_gpuv; g.nf_arr = nuv * 2; g.fidx = var * nuv + i; }
       g.mode = GM_ACOS;
       gin.push_back(g);
       gcount++;
@@ -1466,10 +1512,10 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   for (int i = 0; i < nsc; i++) {
     GridFld g{};
     const ScalarRef &r = sc[i];
-    if (d_gp) { g.base = (double *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
-    else if (r.arr == 1) { g.base = (double *)d_gp2; g.nf_arr = a.nf_sc2; g.fidx = r.lev; }
-    else if (r.arr == 2) { g.base = (double *)d_gp3a; g.nf_arr = a.sc3a_nlev * a.sc3a_nvar; g.fidx = r.var * a.sc3a_nlev + r.lev; }
-    else { g.base = (double *)d_gp3b; g.nf_arr = a.sc3b_nlev * a.sc3b_nvar; g.fidx = r.var * a.sc3b_nlev + r.lev; }
+    if (d_gp) { g.base = (void *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
+    else if (r.arr == 1) { g.base = (void *)d_gp2; g.nf_arr = a.nf_sc2; g.fidx = r.lev; }
+    else if (r.arr == 2) { g.base = (void *)d_gp3a; g.nf_arr = a.sc3a_nlev * a.sc3a_nvar; g.fidx = r.var * a.sc3a_nlev + r.lev; }
+    else { g.base = (void *)d_gp3b; g.nf_arr = a.sc3b_nlev * a.sc3b_nvar; g.fidx = r.var * a.sc3b_nlev + r.lev; }
     g.mode = GM_PLAIN;
     gin.push_back(g);
     gcount++;
@@ -1525,8 +1571,8 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
         switch (r.arr) {
           case 0: sd.dst = d_sc[0]; sd.stride = a.nf_scalar; sd.idx = r.lev; break;
           case 1: sd.dst = d_sc[1]; sd.stride = a.nf_sc2; sd.idx = r.lev; break;
-          case 2: sd.dst = d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev; sd.stride = a.sc3a_nlev; sd.idx = r.lev; break;
-          default: sd.dst = d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev; sd.stride = a.sc3b_nlev; sd.idx = r.lev; break;
+          case 2: sd.dst = (char *)d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev * P.esz; sd.stride = a.sc3a_nlev; sd.idx = r.lev; break;
+          default: sd.dst = (char *)d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev * P.esz; sd.stride = a.sc3b_nlev; sd.idx = r.lev; break;
         }
         bo.push_back(sd);
       }
@@ -1561,8 +1607,8 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     const Bat &bt = bats[ib];
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
     const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + bt.off_o);
-    double *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride : 0);
-    double *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
+    char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride * P.esz : 0);
+    char *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
     // stream B: FFTs (need FB[ib&1] released by the Legendre transform of batch ib-2)
     if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sB);
     int iv = g_pt.start(2, sB);
@@ -1573,14 +1619,14 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     // stream A: Legendre + spectral unpack
     if (piped) g_pipe.wait(2 * ib, sA);
     iv = g_pt.start(1, sA);
-    EMI_LAUNCH(k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const double *)FBl, ldw, P.d_W, ldw);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, ldw, (RT *)P.d_W, ldw);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(2 * ib + 1, sA);
     iv = g_pt.start(0, sA);
     {
       long long total = (long long)P.wrows_total * (long long)bt.no;
       long long nblk = (total + 255) / 256;
-      EMI_LAUNCH(k_postpack_dir, nblk, 256, 0, sA, P.g, d_bo, bt.no, (const double *)P.d_W, ldw, (long long)P.wrows_total);
+      EMI_LAUNCH_P(P.esz, k_postpack_dir, nblk, 256, 0, sA, P.g, d_bo, bt.no, (const RT *)P.d_W, ldw, (long long)P.wrows_total);
     }
     g_pt.stop(iv, sA);
   }
@@ -1593,11 +1639,11 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
 }
 
 static int specnorm_sumsq(Plan &P, int mem_space, const void *spec, int nfld, double *sumsq) {
-  HostStage hs;
-  const double *d_sp = hs.in(spec, (size_t)P.nspec2 * nfld, mem_space == EMI_MEM_HOST, 0);
+  HostStage hs(P.esz);
+  const void *d_sp = hs.in(spec, (size_t)P.nspec2 * nfld, mem_space == EMI_MEM_HOST, 0);
   void *d_out = nullptr;
   if (emi_dev_malloc(&d_out, (size_t)nfld * 8)) return EMI_ERR_RUNTIME;
-  EMI_LAUNCH(k_specnorm, nfld, 256, 256 * 8, (emi_stream_t)0, P.g, (long long)P.nspec2, d_sp, nfld, (double *)d_out);
+  EMI_LAUNCH_P(P.esz, k_specnorm, nfld, 256, 256 * 8, (emi_stream_t)0, P.g, (long long)P.nspec2, (const RT *)d_sp, nfld, (double *)d_out);
   emi_d2h(sumsq, d_out, (size_t)nfld * 8, 0);
   emi_stream_sync(0);
   emi_dev_free(d_out);
@@ -1638,7 +1684,7 @@ extern "C" int emi_work_model(int kresol, int nfields, double *leg, double *fft,
   double f = 0.0;
   for (int j = P.lat0; j < P.lat0 + P.nlat; j++) f += 2.5 * P.nloen[j] * std::log2((double)std::max(2, P.nloen[j]));
   if (fft) *fft = f * nfields;
-  if (fbytes) *fbytes = (double)P.frows * 16.0 * nfields;
+  if (fbytes) *fbytes = (double)P.frows * 2.0 * P.esz * nfields;
   return EMI_SUCCESS;
 }
 

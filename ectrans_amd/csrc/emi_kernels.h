@@ -12,1024 +12,35 @@
 #pragma once
 #include "emi_rt.h"
 
-// ------------------------------------------------------------------------------------------
-// device-visible descriptors
-// ------------------------------------------------------------------------------------------
-struct EmiGeomDev {
-  // Everything is indexed by LOCAL zonal-wavenumber number ml (0..nump-1, actual wavenumber
-  // mval[ml]) and LOCAL latitude number (0..nlat-1): with one task local == global; with several
-  // tasks each task owns the wavenumbers of its W-set (suwavedi_mod.F90:118-137) and a contiguous
-  // latitude band.
-  int nsmax, nump, nlat, ngptot;
-  const int *mval;    // [nump] actual zonal wavenumber
-  const int *nmen, *gpoff;  // [nlat]
-  const int *nasm0;   // [nump] 0-based index of Re(m, n=m) in the (local) user spectral dimension
-  const int *fbase;   // [nlat+1]  Fourier rows (lat, m<=NMEN) before the local latitude
-  const int *fftrow;  // [fbase[nlat]] row of (lat, m) in the FFT-side Fourier buffer
-  const int *lbase;   // [nump+1] start of wavenumber ml in legN/legS
-  const int *legN, *legS;  // row of (ml, j-th northern latitude with m<=NMEN) / its southern mirror
-                           // in the Legendre-side Fourier buffer
-  const int *wbase;   // [nump+1] packed-spectral rows before ml (padded to 16)
-  const int *wrows;   // [nump] padded row count (multiple of 16)
-  const int *rowm;    // [wbase[nump]] row -> ml
-  const int *ebase;   // [nump] index of eps(n=m) in eps[] (n = m..N+2)
-  const double *eps;  // REPSNM
-  const double *lapin;  // RLAPIN(n) at [n+1], n=-1..N+2
-  const double *rw, *racthe;   // [nlat]
-  const double *P;             // Legendre panels
-  const long long *offS, *offA;  // [nump] element offsets of the even/odd (n-m) panels
-  const int *ldp;              // [nump] padded latitude count (multiple of 64)
-  const double *PT;            // transposed panels for the direct transform: [par][lat j][k], k fastest
-  const long long *offTS, *offTA;  // [nump]
-  const int *ldk;              // [nump] padded k count (multiple of 64)
-  const int *lattile_pref;     // [nump+1] prefix of ceil(ndglu/64)
-  const int *ktile_pref;       // [nump+1] prefix of ceil((wrows/2)/64)
-  const double *specw;         // [nspec2 local] SPECNORM weight of every spectral entry (0, 1 or 2)
-};
+#include "emi_types.h"
 
-enum { SPK_COPY = 0, SPK_U = 1, SPK_V = 2, SPK_NSD = 3 };
-struct SpecSrc {  // one Legendre-space input field of the inverse transform
-  const double *a, *b;  // element (ispec) of field = a[ispec*sa + ia]
-  int sa, ia, sb, ib;
-  int kind, pad_;
-};
-enum { SPO_COPY = 0, SPO_VOR = 1, SPO_DIV = 2 };
-struct SpecDst {  // one spectral output field of the direct transform
-  double *dst;
-  int stride, idx;
-  int kind, src0, src1, pad_;  // src*: field index in W (U and V for vor/div)
-};
-enum { GM_PLAIN = 0, GM_ACOS = 1, GM_EWDER = 2, GM_EWDER_UV = 3 };
-struct GridFld {  // one Fourier-space field <-> one user grid field
-  double *base;   // array base; element (p) = base[((p/nproma)*nf_arr + fidx)*nproma + p%nproma]
-  int nf_arr, fidx;
-  int mode, src;  // src: field index inside FB (inverse only)
-};
+// fp64 library (the _dp build of the reference) and fp32 library (_sp): same kernel source, the
+// matrix-core instruction and the accumulator row map differ
+// (v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*i ; v_mfma_f32_16x16x4_f32: row = 4*(lane>>4) + i).
+namespace emi_f64 {
+#define EMI_REAL double
+#define EMI_REAL2 d2
+#define EMI_ACC4 v4d
+#define EMI_MFMA emi_mfma_f64
+#define EMI_ACC_ROW(l, i) (((l) >> 4) + 4 * (i))
+#include "emi_kernels_body.h"
+#undef EMI_REAL
+#undef EMI_REAL2
+#undef EMI_ACC4
+#undef EMI_MFMA
+#undef EMI_ACC_ROW
+}  // namespace emi_f64
 
-struct FftPlanDev {
-  int n;      // row length (NLOEN)
-  int sz;     // logical complex transform size: n/2 (n even) or n (cmode)
-  int S;      // LDS work size per field (complex): sz, or Bluestein length L
-  int cmode;  // 1: odd n, complex transform of the real row
-  int blue;   // 1: Bluestein
-  int nfac;
-  int fac[14];
-  int tw_off, perm_off, rtw_off, chirp_off, bhat_off;
-  int ptw_off[14];  // per pass (DIT order): table [(t-1)*lenp + j] = exp(-2 pi i j t/(lenp*R))
-  int fbk;  // fields per workgroup
-  int lds_class, pad_;
-};
-struct FftTabDev {
-  const d2 *tw;                // e^{-2 pi i k/S}
-  const d2 *ptw;               // per-pass twiddles, coalesced layout
-  const unsigned short *perm;  // DIT input position of natural index
-  const d2 *rtw;               // e^{-2 pi i k/n}, k=0..sz/2
-  const d2 *chirp;             // e^{-i pi k^2/sz}
-  const d2 *bhat;              // DFT_L of the chirp filter, at perm positions
-  const FftPlanDev *plans;
-  const int *planid;           // [ndgl]
-};
-
-// ------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------
-EMI_DEVFN d2 mk2(double x, double y) {
-  d2 r;
-  r.x = x;
-  r.y = y;
-  return r;
-}
-EMI_DEVFN d2 cmul(d2 a, d2 b) { return mk2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-EMI_DEVFN d2 cmulc(d2 a, d2 b) { return mk2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
-EMI_DEVFN d2 cadd(d2 a, d2 b) { return mk2(a.x + b.x, a.y + b.y); }
-EMI_DEVFN d2 csub(d2 a, d2 b) { return mk2(a.x - b.x, a.y - b.y); }
-EMI_DEVFN d2 cconj(d2 a) { return mk2(a.x, -a.y); }
-EMI_DEVFN d2 cscale(d2 a, double s) { return mk2(a.x * s, a.y * s); }
-EMI_DEVFN d2 cmuli(d2 a) { return mk2(-a.y, a.x); }  // i*a
-
-EMI_DEVFN int upper_m(const int *pref, int nump, int t) {
-  // largest ml in [0,nump) with pref[ml] <= t  (pref non-decreasing, pref[nump] > t)
-  int lo = 0, hi = nump - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (pref[mid] <= t)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  return lo;
-}
-
-// XCD-aware remap.  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels the XCD).
-// Logical tiles are cut into groups of G consecutive tiles (same Legendre panel / operand rows,
-// different column tiles); group g*8+x goes to XCD x, so (i) the tiles of a group share one L2 and
-// (ii) all XCDs walk through the m-ascending (longest-K-first) tile list at the same pace --
-// chunking the list contiguously per XCD would hand XCD 0 all the expensive low-m tiles.
-// Bijective for any grid size (the tail that does not fill 8 groups is mapped 1:1).
-EMI_DEVFN long long xcd_swizzle(long long bid, long long nwg, int G) {
-  const long long super = 8LL * G, nfull = (nwg / super) * super;
-  if (bid >= nfull) return bid;
-  const long long x = bid & 7, k = bid >> 3;
-  return ((k / G) * 8 + x) * G + (k % G);
-}
-
-// ==========================================================================================
-// k_prepack_inv: PRFI1B (prfi1b_mod.F90:81-115) + VDTUV (vdtuv_mod.F90:97-143) + SPNSDE
-// (spnsde_mod.F90:95-114).  One thread per (packed row, field); fields fastest.
-//   W[(wbase[m]+r)*ldw + 2f + c],  r = n-m in [0, wrows[m])  (rows n > N+1 are zero)
-// ==========================================================================================
-EMI_DEVFN d2 spec_get(const double *a, int sa, int ia, long long isp, int m) {
-  d2 v;
-  v.x = a[isp * sa + ia];
-  v.y = (m == 0) ? 0.0 : a[(isp + 1) * sa + ia];
-  return v;
-}
-
-EMI_KERNEL_LB(256) void k_prepack_inv(EmiGeomDev g, const SpecSrc *flds, int nfld, int nfld_pad, double *W, int ldw,
-                              long long nrows) {
-  const int N = g.nsmax;
-  long long total = nrows * nfld_pad;
-  {
-    const long long idx = (long long)EMI_BID * EMI_NTHREADS + EMI_TID;
-    if (idx >= total) return;
-    long long row = idx / nfld_pad;
-    int f = (int)(idx - row * nfld_pad);
-    d2 out = mk2(0.0, 0.0);
-    if (f < nfld) {
-      const int ml = g.rowm[row];
-      const int m = g.mval[ml];
-      int r = (int)(row - g.wbase[ml]);
-      int n = m + r;
-      if (n <= N + 1) {
-        SpecSrc s = flds[f];
-        long long isp = g.nasm0[ml] + 2LL * r;  // Re(m,n)
-        if (s.kind == SPK_COPY) {
-          if (n <= N) out = spec_get(s.a, s.sa, s.ia, isp, m);
-        } else {
-          const double *eps = g.eps + g.ebase[ml] - m;  // eps[n], n=m..N+2
-          double zn_m1 = (double)(n - 1), zn_p2 = (double)(n + 2);
-          double e_n = eps[n], e_np1 = eps[n + 1];
-          if (s.kind == SPK_NSD) {
-            d2 fm = (n - 1 >= m) ? spec_get(s.a, s.sa, s.ia, isp - 2, m) : mk2(0, 0);
-            d2 fp = (n + 1 <= N) ? spec_get(s.a, s.sa, s.ia, isp + 2, m) : mk2(0, 0);
-            out.x = -zn_m1 * e_n * fm.x + zn_p2 * e_np1 * fp.x;
-            out.y = -zn_m1 * e_n * fm.y + zn_p2 * e_np1 * fp.y;
-          } else {
-            // a = vorticity, b = divergence
-            const double *pa = (s.kind == SPK_U) ? s.a : s.b;  // the field entering the +-(n-1),(n+2) terms
-            const double *pb = (s.kind == SPK_U) ? s.b : s.a;  // the field entering the i*m term
-            int sa = (s.kind == SPK_U) ? s.sa : s.sb, ia = (s.kind == SPK_U) ? s.ia : s.ib;
-            int sb = (s.kind == SPK_U) ? s.sb : s.sa, ib = (s.kind == SPK_U) ? s.ib : s.ia;
-            double l_n = g.lapin[n + 1], l_nm1 = g.lapin[n], l_np1 = g.lapin[n + 2];
-            d2 xm = (n - 1 >= m) ? spec_get(pa, sa, ia, isp - 2, m) : mk2(0, 0);
-            d2 xp = (n + 1 <= N) ? spec_get(pa, sa, ia, isp + 2, m) : mk2(0, 0);
-            d2 y0 = (n <= N) ? spec_get(pb, sb, ib, isp, m) : mk2(0, 0);
-            double zkm = (double)m;
-            double c1 = zn_m1 * e_n * l_nm1, c2 = zn_p2 * e_np1 * l_np1;
-            double sg = (s.kind == SPK_U) ? 1.0 : -1.0;
-            // U = i m L_n D_n + c1 vor_{n-1} - c2 vor_{n+1};  V = i m L_n vor_n - c1 D_{n-1} + c2 D_{n+1}
-            out.x = -zkm * l_n * y0.y + sg * (c1 * xm.x - c2 * xp.x);
-            out.y = zkm * l_n * y0.x + sg * (c1 * xm.y - c2 * xp.y);
-            if (m == 0) out.y = 0.0;
-          }
-        }
-      }
-    }
-    *(d2 *)(W + row * ldw + 2 * f) = out;
-  }
-}
-
-// ==========================================================================================
-// k_postpack_dir: UVTVD (uvtvd_mod.F90:91-139) + UPDSP/UPDSPB (updsp_mod.F90:100-161,
-// updspb_mod.F90:92-149).  One thread per (packed row with n<=N, output field).
-// ==========================================================================================
-EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nfld, const double *W, int ldw,
-                               long long nrows) {
-  const int N = g.nsmax;
-  long long total = nrows * nfld;
-  {
-    const long long idx = (long long)EMI_BID * EMI_NTHREADS + EMI_TID;
-    if (idx >= total) return;
-    long long row = idx / nfld;
-    int f = (int)(idx - row * nfld);
-    const int ml = g.rowm[row];
-    const int m = g.mval[ml];
-    int r = (int)(row - g.wbase[ml]);
-    int n = m + r;
-    if (n > N) return;
-    SpecDst s = flds[f];
-    d2 out;
-    if (s.kind == SPO_COPY) {
-      out = *(const d2 *)(W + row * ldw + 2 * s.src0);
-    } else {
-      const double *eps = g.eps + g.ebase[ml] - m;
-      // vor: x=V (i m term), y=U ; div: x=U, y=V with opposite sign on the n-terms
-      int fx = (s.kind == SPO_VOR) ? s.src1 : s.src0;
-      int fy = (s.kind == SPO_VOR) ? s.src0 : s.src1;
-      double sg = (s.kind == SPO_VOR) ? 1.0 : -1.0;
-      d2 x0 = *(const d2 *)(W + row * ldw + 2 * fx);
-      d2 yp = *(const d2 *)(W + (row + 1) * ldw + 2 * fy);                        // n+1 (<= N+1 stored)
-      d2 ym = (n - 1 >= m) ? *(const d2 *)(W + (row - 1) * ldw + 2 * fy) : mk2(0, 0);  // n-1
-      double zkm = (double)m, c1 = (double)n * eps[n + 1], c2 = (double)(n + 1) * eps[n];
-      // vor_n = i m V_n - n e_{n+1} U_{n+1} + (n+1) e_n U_{n-1}
-      // div_n = i m U_n + n e_{n+1} V_{n+1} - (n+1) e_n V_{n-1}
-      out.x = -zkm * x0.y + sg * (-c1 * yp.x + c2 * ym.x);
-      out.y = zkm * x0.x + sg * (-c1 * yp.y + c2 * ym.y);
-      if (m == 0 && n == 0) out = mk2(0, 0);  // updsp_mod.F90:113-126
-    }
-    if (m == 0) out.y = 0.0;  // updspb_mod.F90:106,117
-    long long isp = g.nasm0[ml] + 2LL * r;
-    s.dst[isp * s.stride + s.idx] = out.x;
-    s.dst[(isp + 1) * s.stride + s.idx] = out.y;
-  }
-}
-
-// ==========================================================================================
-// Legendre transforms on the fp64 matrix cores.
-//   workgroup = 256 threads = 4 waves; MFMA v_mfma_f64_16x16x4_f64.
-//   LDS tiles: As[2 parities][8 k][LG_LDA], Bs[2][8 k][LG_LDB]; the paddings (16 doubles) put
-//   the two k-rows a half-wave reads with one ds_read_b64 on disjoint bank halves.
-// ==========================================================================================
-#define LG_THREADS 256
-#define LG_BN 128
-#define LG_LDA 80
-#define LG_LDB 144
-#define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)
-
-// ---- inverse: FB[lat][m][col] = sum_n P[lat,n] W[m][n][col]; north = S+A, south = S-A
-// (leinv_mod.F90:92-186 DGEMM('N','N') x2, asre1b_mod.F90:83-102)
-// tile: 64 latitudes x 128 columns, both parities; wave (wm, wn) owns 32 lat x 64 col.
-EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const double *W, int ldw, double *FB, int ldf) {
-  EMI_LDS_DECL;
-  double *As = (double *)EMI_LDS_PTR;
-  double *Bs = As + 2 * 8 * LG_LDA;
-  const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
-  const int wm = w & 1, wn = w >> 1;
-  // host-built tile map (leg_tilemap): block -> (local wavenumber, latitude tile, column tile),
-  // 2-D blocked per XCD for L2 reuse; padding entries have x < 0
-  const int2 tm = tilemap[EMI_BID];
-  if (tm.x < 0) return;
-  const int m = tm.x, lt = tm.y >> 16, ct = tm.y & 0xffff;
-  const int ld = g.ldp[m];
-  const int lat0 = lt * 64, col0 = ct * LG_BN;
-  const int nst = g.wrows[m] >> 4;
-
-  v4d acc[2][2][4];
-#pragma unroll
-  for (int p = 0; p < 2; p++)
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[p][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-  // global -> register prefetch pointers (advance by one stage per iteration)
-  const int arow = tid >> 5, ac2 = tid & 31;
-  const double *pS = g.P + g.offS[m] + (long long)arow * ld + lat0 + 2 * ac2;
-  const double *pA = g.P + g.offA[m] + (long long)arow * ld + lat0 + 2 * ac2;
-  const int brow = tid >> 6, bc2 = tid & 63;  // rows brow, brow+4, brow+8, brow+12 of the stage
-  const double *pW = W + ((long long)g.wbase[m] + brow) * ldw + col0 + 2 * bc2;
-  const long long stepA = 8LL * ld, stepW = 16LL * ldw, rowW4 = 4LL * ldw;
-  double *sA0 = As + (0 * 8 + arow) * LG_LDA + 2 * ac2;
-  double *sA1 = As + (1 * 8 + arow) * LG_LDA + 2 * ac2;
-  // W row r of the stage -> parity r&1, k = r>>1 ; r = brow + 4*i
-  double *sB0 = Bs + (((brow + 0) & 1) * 8 + ((brow + 0) >> 1)) * LG_LDB + 2 * bc2;
-  double *sB1 = Bs + (((brow + 4) & 1) * 8 + ((brow + 4) >> 1)) * LG_LDB + 2 * bc2;
-  double *sB2 = Bs + (((brow + 8) & 1) * 8 + ((brow + 8) >> 1)) * LG_LDB + 2 * bc2;
-  double *sB3 = Bs + (((brow + 12) & 1) * 8 + ((brow + 12) >> 1)) * LG_LDB + 2 * bc2;
-  d2 ra0 = *(const d2 *)pS, ra1 = *(const d2 *)pA;
-  d2 rb0 = *(const d2 *)pW, rb1 = *(const d2 *)(pW + rowW4), rb2 = *(const d2 *)(pW + 2 * rowW4), rb3 = *(const d2 *)(pW + 3 * rowW4);
-  for (int s = 0; s < nst; s++) {
-    if (s > 0) EMI_SYNC();
-    *(d2 *)sA0 = ra0;
-    *(d2 *)sA1 = ra1;
-    *(d2 *)sB0 = rb0;
-    *(d2 *)sB1 = rb1;
-    *(d2 *)sB2 = rb2;
-    *(d2 *)sB3 = rb3;
-    EMI_SYNC();
-    if (s + 1 < nst) {
-      pS += stepA;
-      pA += stepA;
-      pW += stepW;
-      ra0 = *(const d2 *)pS;
-      ra1 = *(const d2 *)pA;
-      rb0 = *(const d2 *)pW;
-      rb1 = *(const d2 *)(pW + rowW4);
-      rb2 = *(const d2 *)(pW + 2 * rowW4);
-      rb3 = *(const d2 *)(pW + 3 * rowW4);
-    }
-#pragma unroll
-    for (int p = 0; p < 2; p++)
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        const int kk = 4 * ks + (l >> 4);
-        double a[2], b[4];
-#pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = As[(p * 8 + kk) * LG_LDA + wm * 32 + i * 16 + (l & 15)];
-#pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = Bs[(p * 8 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[p][i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[p][i][j]);
-      }
-  }
-  // epilogue (ASRE1B): rows = latitudes
-  const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int j = lat0 + wm * 32 + i * 16 + (l >> 4) + 4 * q;
-      if (j < ndglu) {
-        double *pn = FB + (long long)g.legN[lb + j] * ldf + col0 + wn * 64 + (l & 15);
-        double *ps = FB + (long long)g.legS[lb + j] * ldf + col0 + wn * 64 + (l & 15);
-#pragma unroll
-        for (int jn = 0; jn < 4; jn++) {
-          double sv = acc[0][i][jn][q], av = acc[1][i][jn][q];
-          pn[jn * 16] = sv + av;
-          ps[jn * 16] = sv - av;
-        }
-      }
-    }
-}
-
-// ---- direct: W[m][n][col] = sum_lat P[lat,n] * (FB_north +- FB_south)[lat][col]
-// (prfi2b_mod.F90:82-94, ledir_mod.F90:100-267 DGEMM('T','N') x2; Gaussian weights and
-//  1/(a cos) were folded into FB by k_fft_dir)
-// tile: 64 k (n-pairs) x 2 parities x 128 columns; wave (par, wn) owns 64 k x 64 col.
-EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const double *FB, int ldf, double *W, int ldw) {
-  EMI_LDS_DECL;
-  double *As = (double *)EMI_LDS_PTR;
-  double *Bs = As + 2 * 8 * LG_LDA;
-  const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
-  const int par = w & 1, wn = w >> 1;
-  const int2 tm = tilemap[EMI_BID];
-  if (tm.x < 0) return;
-  const int m = tm.x, kt = tm.y >> 16, ct = tm.y & 0xffff;
-  const int k0 = kt * 64, col0 = ct * LG_BN;
-  const int nkpad = g.wrows[m] >> 1;
-  const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
-  const int nst = (ndglu + 7) >> 3;
-  const long long wb = g.wbase[m];
-
-  v4d acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-  // P^T tile: 8 latitudes x 64 k per parity, k contiguous in HBM (coalesced 512-B rows) and in LDS
-  const int arow = tid >> 5, ac2 = tid & 31;
-  const int ldk = g.ldk[m];
-  const double *pS = g.PT + g.offTS[m] + (long long)arow * ldk + k0 + 2 * ac2;
-  const double *pA = g.PT + g.offTA[m] + (long long)arow * ldk + k0 + 2 * ac2;
-  const long long stepA = 8LL * ldk;
-  const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow and brow+4 of each 8-row stage
-  const double *FBc = FB + col0 + 2 * bc2;
-  d2 ra0, ra1, rn0, rn1, rs0, rs1;     // stage s+1 (written to LDS at the top of the next iteration)
-  d2 qn0, qn1, qs0, qs1;               // stage s+2 (FB rows only: their latency is the long one)
-  // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
-  // kernels), so each stage touches 16 far-apart rows: they are prefetched TWO stages ahead.  Their
-  // row numbers (fbase[lat]+m) are staged once per tile in LDS, so that looking them up is an LDS
-  // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
-  int *rowN = (int *)(Bs + 2 * 8 * LG_LDB);
-  int *rowS = rowN + 8 * nst;
-  for (int j = tid; j < 8 * nst; j += LG_THREADS) {
-    int rn_ = -1, rs_ = -1;
-    if (j < ndglu) {
-      rn_ = g.legN[lb + j];
-      rs_ = g.legS[lb + j];
-    }
-    rowN[j] = rn_;
-    rowS[j] = rs_;
-  }
-  EMI_SYNC();
-#define LEGDIR_LOADB(s_, n0_, s0_, n1_, s1_)                                       \
-  {                                                                                \
-    const int j0_ = 8 * (s_) + brow;                                               \
-    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + 4], is1 = rowS[j0_ + 4]; \
-    n0_ = in0 >= 0 ? *(const d2 *)(FBc + (long long)in0 * ldf) : mk2(0, 0);        \
-    s0_ = is0 >= 0 ? *(const d2 *)(FBc + (long long)is0 * ldf) : mk2(0, 0);        \
-    n1_ = in1 >= 0 ? *(const d2 *)(FBc + (long long)in1 * ldf) : mk2(0, 0);        \
-    s1_ = is1 >= 0 ? *(const d2 *)(FBc + (long long)is1 * ldf) : mk2(0, 0);        \
-  }
-  LEGDIR_LOADB(0, rn0, rs0, rn1, rs1);
-  ra0 = *(const d2 *)pS;
-  ra1 = *(const d2 *)pA;
-  if (nst > 1) LEGDIR_LOADB(1, qn0, qs0, qn1, qs1);
-  for (int s = 0; s < nst; s++) {
-    if (s > 0) EMI_SYNC();
-    *(d2 *)(As + (0 * 8 + arow) * LG_LDA + 2 * ac2) = ra0;  // As[par][kk = latitude in stage][k index]
-    *(d2 *)(As + (1 * 8 + arow) * LG_LDA + 2 * ac2) = ra1;
-    *(d2 *)(Bs + (0 * 8 + brow) * LG_LDB + 2 * bc2) = cadd(rn0, rs0);      // symmetric part
-    *(d2 *)(Bs + (1 * 8 + brow) * LG_LDB + 2 * bc2) = csub(rn0, rs0);      // antisymmetric part
-    *(d2 *)(Bs + (0 * 8 + brow + 4) * LG_LDB + 2 * bc2) = cadd(rn1, rs1);
-    *(d2 *)(Bs + (1 * 8 + brow + 4) * LG_LDB + 2 * bc2) = csub(rn1, rs1);
-    EMI_SYNC();
-    rn0 = qn0; rs0 = qs0; rn1 = qn1; rs1 = qs1;  // stage s+1 <- registers of stage s+2 (in flight)
-    if (s + 1 < nst) {
-      ra0 = *(const d2 *)(pS + (s + 1) * stepA);
-      ra1 = *(const d2 *)(pA + (s + 1) * stepA);
-    }
-    if (s + 2 < nst) LEGDIR_LOADB(s + 2, qn0, qs0, qn1, qs1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const int kk = 4 * ks + (l >> 4);
-      double a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[(par * 8 + kk) * LG_LDA + i * 16 + (l & 15)];
-#pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[(par * 8 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
-    }
-  }
-#undef LEGDIR_LOADB
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int k = k0 + i * 16 + (l >> 4) + 4 * q;
-      if (k < nkpad) {
-        double *pw = W + (wb + 2 * k + par) * ldw + col0 + wn * 64 + (l & 15);
-#pragma unroll
-        for (int jn = 0; jn < 4; jn++) pw[jn * 16] = acc[i][jn][q];
-      }
-    }
-}
-
-// ==========================================================================================
-// FFT engine in LDS (v2): in-place mixed-radix Cooley-Tukey on `nfl` fields of S complex points.
-//   DIT: input at perm[] positions -> natural output.  DIF: natural input -> output at perm[].
-//   tw[k] = exp(-2 pi i k/S); sgn=+1 conjugates.
-//   * radices 2,3,4,5,8,16 are hard-coded register butterflies; 7,11,13 use the DFT matrix from tw
-//   * the host orders the factors so that every pass stride (lenp) of a 2-3-5-smooth size is a power
-//     of two (odd radices last in DIT order) -> no integer divisions in those passes
-//   * logical element i lives at LDS slot FPAD(i) = i ^ ((i >> 3) & 15) (XOR swizzle inside aligned
-//     16-element blocks): stride-1 passes stay conflict free and the pass whose butterflies are
-//     contiguous runs of 8 elements (stride 128 B between lanes) becomes conflict free too
-//   * inter-pass twiddles come from per-pass tables laid out [t][j] so that a wave reads them
-//     coalesced (the single table tw[j*t*S/len] is a 64-line gather per wave instruction)
-//   * Bluestein: DIF passes -> [last DIF pass + pointwise filter + first DIT pass fused in
-//     registers] -> DIT passes; the final DIT pass of the inverse transform multiplies by the chirp
-//     and stores the real row straight to the user's grid array (no LDS round trip)
-// ==========================================================================================
-#define FFT_MAXR 16
-#define FFT_TWPOW_MIN (1 << 30)  // chained twiddle powers (1 load + R-2 products) measured no faster than the coalesced table reads: off
-#define FPAD(i) ((i) ^ (((i) >> 3) & 15))
-#define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
-
-EMI_DEVFN d2 tw_get(const d2 *tw, int idx, int sgn) {
-  d2 t = tw[idx];
-  if (sgn > 0) t.y = -t.y;
-  return t;
-}
-// multiply by -i (forward, sgn<0) or +i (inverse)
-EMI_DEVFN d2 cmul_mi(d2 a, int sgn) { return (sgn < 0) ? mk2(a.y, -a.x) : mk2(-a.y, a.x); }
-
-EMI_DEVFN void bf4(d2 &x0, d2 &x1, d2 &x2, d2 &x3, int sgn) {
-  d2 a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = cmul_mi(csub(x1, x3), sgn);
-  x0 = cadd(a, c);
-  x1 = cadd(b, d);
-  x2 = csub(a, c);
-  x3 = csub(b, d);
-}
-
-template <int R>
-EMI_DEVFN void butterfly(d2 *v, const d2 *tw, int S, int sgn) {
-  if (R == 2) {
-    d2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
-  } else if (R == 4) {
-    bf4(v[0], v[1], v[2], v[3], sgn);
-  } else if (R == 3) {
-    const double s60 = 0.86602540378443864676;
-    d2 t1 = cadd(v[1], v[2]);
-    d2 t2 = mk2(v[0].x - 0.5 * t1.x, v[0].y - 0.5 * t1.y);
-    d2 t3 = cscale(cmul_mi(csub(v[1], v[2]), sgn), s60);
-    v[0] = cadd(v[0], t1);
-    v[1] = cadd(t2, t3);
-    v[2] = csub(t2, t3);
-  } else if (R == 5) {
-    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
-    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
-    d2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), d1 = csub(v[1], v[4]), d2_ = csub(v[2], v[3]);
-    d2 r1 = mk2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-    d2 r2 = mk2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
-    d2 q1 = cmul_mi(mk2(s1 * d1.x + s2 * d2_.x, s1 * d1.y + s2 * d2_.y), sgn);
-    d2 q2 = cmul_mi(mk2(s2 * d1.x - s1 * d2_.x, s2 * d1.y - s1 * d2_.y), sgn);
-    v[0] = cadd(v[0], cadd(a1, a2));
-    v[1] = cadd(r1, q1);
-    v[4] = csub(r1, q1);
-    v[2] = cadd(r2, q2);
-    v[3] = csub(r2, q2);
-  } else if (R == 8) {
-    // n = 4 n1 + n2, k = k1 + 2 k2
-    const double h = 0.70710678118654752440;
-    d2 t0[4], t1[4];
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) {
-      t0[n2] = cadd(v[n2], v[4 + n2]);
-      t1[n2] = csub(v[n2], v[4 + n2]);
-    }
-    // t1[n2] *= W8^{n2}
-    t1[1] = (sgn < 0) ? mk2(h * (t1[1].x + t1[1].y), h * (t1[1].y - t1[1].x)) : mk2(h * (t1[1].x - t1[1].y), h * (t1[1].y + t1[1].x));
-    t1[2] = cmul_mi(t1[2], sgn);
-    t1[3] = (sgn < 0) ? mk2(h * (t1[3].y - t1[3].x), -h * (t1[3].x + t1[3].y)) : mk2(-h * (t1[3].x + t1[3].y), h * (t1[3].x - t1[3].y));
-    bf4(t0[0], t0[1], t0[2], t0[3], sgn);
-    bf4(t1[0], t1[1], t1[2], t1[3], sgn);
-#pragma unroll
-    for (int k2 = 0; k2 < 4; k2++) {
-      v[2 * k2] = t0[k2];
-      v[2 * k2 + 1] = t1[k2];
-    }
-  } else if (R == 16) {
-    // n = 4 n1 + n2, k = k1 + 4 k2, computed in place: after step 1 register 4*k1+n2 holds
-    // t[n2][k1]; after step 3 register 4*k1+k2 holds X[k1 + 4*k2] (un-permuted by the caller-side
-    // index map OUT16 below, which is static)
-    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) {
-      d2 a0 = v[n2], a1 = v[4 + n2], a2 = v[8 + n2], a3 = v[12 + n2];
-      bf4(a0, a1, a2, a3, sgn);
-      v[n2] = a0;       // k1 = 0
-      v[4 + n2] = a1;   // k1 = 1
-      v[8 + n2] = a2;   // k1 = 2
-      v[12 + n2] = a3;  // k1 = 3
-    }
-    const double wc[10] = {1.0, c1, h, s1, 0.0, -s1, -h, -c1, -1.0, -c1};
-    const double ws[10] = {0.0, s1, h, c1, 1.0, c1, h, s1, 0.0, -s1};
-#pragma unroll
-    for (int k1 = 1; k1 < 4; k1++)
-#pragma unroll
-      for (int n2 = 1; n2 < 4; n2++) {
-        const int e = n2 * k1;
-        v[4 * k1 + n2] = cmul(v[4 * k1 + n2], mk2(wc[e], (sgn < 0) ? -ws[e] : ws[e]));
-      }
-    d2 y[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) {
-      d2 a0 = v[4 * k1], a1 = v[4 * k1 + 1], a2 = v[4 * k1 + 2], a3 = v[4 * k1 + 3];
-      bf4(a0, a1, a2, a3, sgn);
-      y[k1] = a0;
-      y[k1 + 4] = a1;
-      y[k1 + 8] = a2;
-      y[k1 + 12] = a3;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) v[u] = y[u];
-  } else {
-    // generic small prime (7): DFT matrix rows from the twiddle table, fully unrolled
-    d2 y[R], w[R];
-    const int st = S / R;
-#pragma unroll
-    for (int e = 1; e < R; e++) w[e] = tw_get(tw, e * st, sgn);
-#pragma unroll
-    for (int u = 0; u < R; u++) {
-      d2 s = v[0];
-#pragma unroll
-      for (int t = 1; t < R; t++) s = ((u * t) % R) ? cadd(s, cmul(v[t], w[(u * t) % R])) : cadd(s, v[t]);
-      y[u] = s;
-    }
-#pragma unroll
-    for (int u = 0; u < R; u++) v[u] = y[u];
-  }
-}
-
-// split a butterfly number q into (block, j) for stride lenp (power of two when sh >= 0)
-EMI_DEVFN void split_q(int q, int lenp, int sh, int &blk, int &j) {
-  if (sh >= 0) {
-    blk = q >> sh;
-    j = q & (lenp - 1);
-  } else {
-    blk = q / lenp;
-    j = q - blk * lenp;
-  }
-}
-EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_clz((unsigned)v)); }
-
-// one in-place pass over nfl fields.  MASK: logical elements >= nvalid read as zero (only the first
-// DIF pass of a zero-padded Bluestein input).
-template <int R, int DIF, int MASK>
-EMI_DEVFN void fft_pass(d2 *a, int nfl, int fstride, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
-  const int len = lenp * R, nb = S / R, sh = log2_exact(lenp);
-  for (int fl = 0; fl < nfl; fl++) {
-    d2 *af = a + (long long)fl * fstride;
-    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
-      int blk, j;
-      split_q(q, lenp, sh, blk, j);
-      const int base = blk * len + j;
-      d2 v[R];
-#pragma unroll
-      for (int t = 0; t < R; t++) {
-        const int i = base + t * lenp;
-        if (MASK)
-          v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
-        else
-          v[t] = af[FPAD(i)];
-      }
-      // inter-pass twiddles W_len^{j t}: coalesced reads of the per-pass table [t-1][j]
-      // (FFT_TWPOW_MIN: optional product chain from W^j, measured no faster)
-#define FFT_APPLY_TW()                                                              \
-  if (lenp >= FFT_TWPOW_MIN && R > 2) {                                             \
-    const d2 w1 = tw_get(ptw, j, sgn);                                              \
-    d2 wt = w1;                                                                     \
-    v[1] = cmul(v[1], wt);                                                          \
-    _Pragma("unroll") for (int t = 2; t < R; t++) {                                 \
-      wt = cmul(wt, w1);                                                            \
-      v[t] = cmul(v[t], wt);                                                        \
-    }                                                                               \
-  } else if (lenp > 1) {                                                            \
-    const d2 *pw_ = ptw + j;                                                        \
-    _Pragma("unroll") for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(pw_, (t - 1) * lenp, sgn)); \
-  }
-      if (!DIF) {
-        FFT_APPLY_TW();
-      }
-      butterfly<R>(v, tw, S, sgn);
-      if (DIF) {
-        FFT_APPLY_TW();
-      }
-#pragma unroll
-      for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
-    }
-  }
-}
-
-#define FFT_DISPATCH(FN, r, ...)                  \
-  switch (r) {                                    \
-    case 2: FN<2>(__VA_ARGS__); break;            \
-    case 3: FN<3>(__VA_ARGS__); break;            \
-    case 4: FN<4>(__VA_ARGS__); break;            \
-    case 5: FN<5>(__VA_ARGS__); break;            \
-    case 7: FN<7>(__VA_ARGS__); break;            \
-    case 8: FN<8>(__VA_ARGS__); break;            \
-    default: break;                               \
-  }
-// Bluestein lengths are 2^a * {1,3,5,9,15}: their first DIT factor is a power of two
-#define FFT_DISPATCH_POW2(FN, r, ...)             \
-  switch (r) {                                    \
-    case 2: FN<2>(__VA_ARGS__); break;            \
-    case 4: FN<4>(__VA_ARGS__); break;            \
-    case 8: FN<8>(__VA_ARGS__); break;            \
-    default: break;                               \
-  }
-
-template <int R>
-EMI_DEVFN void pass_dit(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
-  fft_pass<R, 0, 0>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
-}
-template <int R>
-EMI_DEVFN void pass_dif(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, int sgn, int nvalid) {
-  if (nvalid < S)
-    fft_pass<R, 1, 1>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
-  else
-    fft_pass<R, 1, 0>(a, nfl, fs, S, lenp, tw, ptw, sgn, nvalid);
-}
-
-// DIT passes ip = first..last-1 (factor order); returns lenp after them
-EMI_DEVFN int run_dit(d2 *a, int nfl, int fs, int S, const FftPlanDev &pl, const FftTabDev &T, int first, int last, int lenp, int sgn) {
-  const int *fac = pl.fac;
-  const d2 *tw = T.tw + pl.tw_off;
-  for (int ip = first; ip < last; ip++) {
-    const int r = fac[ip];
-    FFT_DISPATCH(pass_dit, r, a, nfl, fs, S, lenp, tw, T.ptw + pl.ptw_off[ip], sgn, S);
-    lenp *= r;
-    EMI_SYNC();
-  }
-  return lenp;
-}
-// DIF passes over factors nfac-1 down to `stop` (inclusive); nvalid applies to the first one
-EMI_DEVFN void run_dif(d2 *a, int nfl, int fs, int S, const FftPlanDev &pl, const FftTabDev &T, int stop, int sgn, int nvalid) {
-  const int *fac = pl.fac;
-  const d2 *tw = T.tw + pl.tw_off;
-  int lenp = S;
-  for (int ip = pl.nfac - 1; ip >= stop; ip--) {
-    const int r = fac[ip];
-    lenp /= r;
-    FFT_DISPATCH(pass_dif, r, a, nfl, fs, S, lenp, tw, T.ptw + pl.ptw_off[ip], sgn, nvalid);
-    nvalid = S;
-    EMI_SYNC();
-  }
-}
-
-// Bluestein middle: last DIF pass (radix fac[0], contiguous runs) * filter * first DIT pass
-template <int R>
-EMI_DEVFN void blue_middle(d2 *a, int nfl, int fs, int S, const d2 *tw, const d2 *bh, int conj_b, int nvalid) {
-  const int nb = S / R;
-  for (int fl = 0; fl < nfl; fl++) {
-    d2 *af = a + (long long)fl * fs;
-    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
-      const int base = q * R;
-      d2 v[R];
-#pragma unroll
-      for (int t = 0; t < R; t++) v[t] = (base + t < nvalid) ? af[FPAD(base + t)] : mk2(0.0, 0.0);
-      butterfly<R>(v, tw, S, -1);
-#pragma unroll
-      for (int t = 0; t < R; t++) {
-        d2 b = bh[base + t];
-        v[t] = conj_b ? cmulc(v[t], b) : cmul(v[t], b);
-      }
-      butterfly<R>(v, tw, S, +1);
-#pragma unroll
-      for (int t = 0; t < R; t++) af[FPAD(base + t)] = v[t];
-    }
-  }
-}
-
-// circular convolution with the chirp filter: a (natural, logically zero beyond nvalid) -> natural,
-// leaving the LAST DIT pass to the caller (returns its lenp) when defer_last != 0.
-EMI_DEVFN int blue_conv(d2 *a, int nfl, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid, int defer_last) {
-  const int L = pl.S;
-  const d2 *tw = T.tw + pl.tw_off, *bh = T.bhat + pl.bhat_off;
-  run_dif(a, nfl, fs, L, pl, T, 1, -1, nvalid);
-  const int r0 = pl.fac[0];
-  const int nv0 = (pl.nfac == 1) ? nvalid : L;
-  FFT_DISPATCH_POW2(blue_middle, r0, a, nfl, fs, L, tw, bh, conj_b, nv0);
-  EMI_SYNC();
-  const int last = defer_last ? pl.nfac - 1 : pl.nfac;
-  return run_dit(a, nfl, fs, L, pl, T, 1, last < 1 ? 1 : last, r0, +1);
-}
-
-EMI_DEVFN long long grid_index(const GridFld &gf, long long p, int nproma) {
-  long long blk = p / nproma;
-  return (blk * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk * nproma);
-}
-
-// block -> (latitude, field chunk) through a per-class prefix table
-struct FftLaunchDev {
-  const int *lats;      // latitudes of this LDS class
-  const int *blk_pref;  // [nlat_class+1] prefix of chunks per latitude
-  int nlat;
-  long long nblocks;
-};
-EMI_DEVFN int fft_find(const int *pref, int n, int b) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (pref[mid] <= b)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  return lo;
-}
-
-// final DIT pass of the inverse real transform, stored straight to the grid array:
-// logical output z_i (i < sz): x_{2i} = Re, x_{2i+1} = Im (or x_i = Re z_i in complex mode),
-// Bluestein: z_i = a'_i * conj(chirp_i) / L.
-template <int R>
-EMI_DEVFN void dit_last_to_grid(d2 *a, int nfl, int fs, int S, int lenp, const d2 *tw, const d2 *ptw, const FftPlanDev &pl,
-                                const d2 *chirp, const GridFld *flds, int f0, long long gp0, int nproma) {
-  const int nb = S / R, sh = log2_exact(lenp), sz = pl.sz;
-  const double invL = pl.blue ? 1.0 / (double)S : 1.0;
-  for (int fl = 0; fl < nfl; fl++) {
-    d2 *af = a + (long long)fl * fs;
-    const GridFld gf = flds[f0 + fl];
-    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
-      int blk, j;
-      split_q(q, lenp, sh, blk, j);  // last pass: len == S, blk == 0
-      d2 v[R];
-#pragma unroll
-      for (int t = 0; t < R; t++) v[t] = af[FPAD(j + t * lenp)];
-      {
-        const int sgn = +1;
-        FFT_APPLY_TW();
-      }
-      butterfly<R>(v, tw, S, +1);
-#pragma unroll
-      for (int t = 0; t < R; t++) {
-        const int i = j + t * lenp;
-        if (i < sz) {
-          d2 z = v[t];
-          if (pl.blue) z = cscale(cmulc(z, chirp[i]), invL);
-          if (!pl.cmode) {
-            const long long p = gp0 + 2LL * i;
-            const long long blk0 = p / nproma;
-            if (blk0 == (p + 1) / nproma && (((uintptr_t)gf.base & 15) == 0) && (((blk0 * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk0 * nproma)) & 1) == 0) {
-              *(d2 *)(gf.base + (blk0 * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk0 * nproma)) = z;
-            } else {
-              gf.base[grid_index(gf, p, nproma)] = z.x;
-              gf.base[grid_index(gf, p + 1, nproma)] = z.y;
-            }
-          } else {
-            gf.base[grid_index(gf, gp0 + i, nproma)] = z.x;
-          }
-        }
-      }
-    }
-  }
-}
-
-// ==========================================================================================
-// k_fft_inv: FOURIER_IN (fourier_in_mod.F90:64-76) + FSC (fsc_mod.F90:138-187) + FTINV
-// (ftinv_mod.F90:65-84; FFTW c2r semantics, unnormalised) + TRLTOG local copy.
-// ==========================================================================================
-EMI_DEVFN d2 fsc_load(const double *FB, long long row, int ldf, const GridFld &gf, int k, double racthe) {
-  d2 x = *(const d2 *)(FB + row * ldf + 2 * gf.src);
-  if (gf.mode == GM_ACOS)
-    x = cscale(x, racthe);
-  else if (gf.mode == GM_EWDER)
-    x = cscale(cmuli(x), racthe * (double)k);
-  else if (gf.mode == GM_EWDER_UV)
-    x = cscale(cmuli(x), racthe * racthe * (double)k);
-  return x;
-}
-
-EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const double *FB,
-                              int ldf, int nproma) {
-  EMI_LDS_DECL;
-  d2 *a = (d2 *)EMI_LDS_PTR;
-  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
-  const int li = fft_find(Lc.blk_pref, Lc.nlat, bid);
-  const int lat = Lc.lats[li];
-  const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = (bid - Lc.blk_pref[li]) * pl.fbk;
-  const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
-  const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
-  const int fs = FFT_LDS_ELEMS(S);
-  const double racthe = g.racthe[lat];
-  const int *frow = g.fftrow + g.fbase[lat];  // frow[k]: row of (lat, m=k) in the FFT-side buffer
-  const d2 *tw = T.tw + pl.tw_off;
-  const unsigned short *perm = T.perm + pl.perm_off;
-  const d2 *rtw = T.rtw + pl.rtw_off;
-  const d2 *chirp = T.chirp + pl.chirp_off;
-
-  // ---- stage 1: logical input Z_k, k in [0,sz), to LDS (natural for Bluestein, perm[] for DIT)
-  for (int fl = 0; fl < nfl; fl++) {
-    const GridFld gf = flds[f0 + fl];
-    d2 *af = a + (long long)fl * fs;
-    if (!pl.cmode) {
-      const int npair = sz / 2 + 1;  // k = 0..sz/2 pairs with sz-k
-      for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
-        const int k2 = sz - k;
-        d2 xa = (k <= nmen) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
-        d2 xb = (k2 <= nmen) ? fsc_load(FB, frow[k2], ldf, gf, k2, racthe) : mk2(0, 0);
-        // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
-        d2 wk = cconj(rtw[k]);
-        d2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
-        d2 zk = cadd(s1, cmuli(cmul(wk, d1)));
-        af[FPAD(pl.blue ? k : (int)perm[k])] = pl.blue ? cmulc(zk, chirp[k]) : zk;
-        if (k2 != k && k2 < sz) {
-          // Z_{sz-k}: w^{sz-k} = -conj(w^k)
-          d2 s2 = cadd(xb, cconj(xa)), d2_ = csub(xb, cconj(xa));
-          d2 zk2 = cadd(s2, cmuli(cmul(mk2(-wk.x, wk.y), d2_)));
-          af[FPAD(pl.blue ? k2 : (int)perm[k2])] = pl.blue ? cmulc(zk2, chirp[k2]) : zk2;
-        }
-      }
-    } else {
-      // complex mode (odd n): Z_k = X_k, Z_{n-k} = conj X_k
-      for (int k = EMI_TID; k < sz; k += EMI_NTHREADS) {
-        d2 z;
-        if (2 * k <= n) {
-          z = (k <= nmen) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
-          if (k == 0) z.y = 0.0;
-        } else {
-          z = (n - k <= nmen) ? cconj(fsc_load(FB, frow[n - k], ldf, gf, n - k, racthe)) : mk2(0, 0);
-        }
-        af[FPAD(pl.blue ? k : (int)perm[k])] = pl.blue ? cmulc(z, chirp[k]) : z;
-      }
-    }
-  }
-  EMI_SYNC();
-  // ---- stage 2 (all passes but the last) and stage 3 (last DIT pass -> grid, TRLTOG local copy)
-  const long long gp0 = g.gpoff[lat];
-  int lenp;
-  if (pl.blue) {
-    if (pl.nfac == 1) {
-      // degenerate single-factor filter length: no separate last pass to fuse with the store
-      blue_conv(a, nfl, fs, pl, T, 1, sz, 0);
-      const double invL = 1.0 / (double)S;
-      for (int fl = 0; fl < nfl; fl++) {
-        const GridFld gf = flds[f0 + fl];
-        const d2 *af = a + (long long)fl * fs;
-        for (int p = EMI_TID; p < n; p += EMI_NTHREADS) {
-          const int i = pl.cmode ? p : (p >> 1);
-          d2 z = cscale(cmulc(af[FPAD(i)], chirp[i]), invL);
-          gf.base[grid_index(gf, gp0 + p, nproma)] = (pl.cmode || !(p & 1)) ? z.x : z.y;
-        }
-      }
-      return;
-    }
-    lenp = blue_conv(a, nfl, fs, pl, T, 1, sz, 1);
-  } else {
-    if (pl.nfac == 0) {  // sz == 1
-      for (int fl = EMI_TID; fl < nfl; fl += EMI_NTHREADS) {
-        const GridFld gf = flds[f0 + fl];
-        d2 z = a[(long long)fl * fs];
-        gf.base[grid_index(gf, gp0, nproma)] = z.x;
-        if (!pl.cmode) gf.base[grid_index(gf, gp0 + 1, nproma)] = z.y;
-      }
-      return;
-    }
-    lenp = run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac - 1, 1, +1);
-  }
-  const int rl = pl.fac[pl.nfac - 1];
-  FFT_DISPATCH(dit_last_to_grid, rl, a, nfl, fs, S, lenp, tw, T.ptw + pl.ptw_off[pl.nfac - 1], pl, chirp, flds, f0, gp0, nproma);
-}
-
-// ==========================================================================================
-// k_fft_dir: TRGTOL local copy + FTDIR (ftdir_mod.F90:67-84; r2c, scaled 1/NLOEN at
-// tpm_fftw.F90:317-321) + FOURIER_OUT (fourier_out_mod.F90:64-76).  The Gaussian weight
-// (ledir_mod.F90:118-124) and LDFOU2's 1/(a cos) (ldfou2_mod.F90:90-96) only depend on the
-// latitude and are folded into the same scale factor.
-// ==========================================================================================
-EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, double *FB, int ldf,
-                              int nproma) {
-  EMI_LDS_DECL;
-  d2 *a = (d2 *)EMI_LDS_PTR;
-  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
-  const int li = fft_find(Lc.blk_pref, Lc.nlat, bid);
-  const int lat = Lc.lats[li];
-  const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = (bid - Lc.blk_pref[li]) * pl.fbk;
-  const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
-  const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
-  const int fs = FFT_LDS_ELEMS(S);
-  const int *frow = g.fftrow + g.fbase[lat];
-  const long long gp0 = g.gpoff[lat];
-  const d2 *tw = T.tw + pl.tw_off;
-  const unsigned short *perm = T.perm + pl.perm_off;
-  const d2 *rtw = T.rtw + pl.rtw_off;
-  const d2 *chirp = T.chirp + pl.chirp_off;
-
-  // ---- stage 1: z_l = x_{2l} + i x_{2l+1} (or x_l in complex mode)
-  for (int fl = 0; fl < nfl; fl++) {
-    const GridFld gf = flds[f0 + fl];
-    d2 *af = a + (long long)fl * fs;
-    const bool flat = (gp0 + n <= (long long)nproma) && ((((uintptr_t)(gf.base + (long long)gf.fidx * nproma + gp0)) & 15) == 0);
-    const double *rowp = gf.base + (long long)gf.fidx * nproma + gp0;
-    for (int lz = EMI_TID; lz < sz; lz += EMI_NTHREADS) {
-      d2 z;
-      if (!pl.cmode) {
-        if (flat) {
-          z = *(const d2 *)(rowp + 2 * lz);
-        } else {
-          z.x = gf.base[grid_index(gf, gp0 + 2 * lz, nproma)];
-          z.y = gf.base[grid_index(gf, gp0 + 2 * lz + 1, nproma)];
-        }
-      } else {
-        z.x = gf.base[grid_index(gf, gp0 + lz, nproma)];
-        z.y = 0.0;
-      }
-      af[FPAD(pl.blue ? lz : (int)perm[lz])] = pl.blue ? cmul(z, chirp[lz]) : z;
-    }
-  }
-  EMI_SYNC();
-  if (pl.blue)
-    blue_conv(a, nfl, fs, pl, T, 0, sz, 0);
-  else
-    run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac, 1, -1);
-  // ---- stage 3: X_k, k = 0..NMEN
-  const double invL = pl.blue ? 1.0 / (double)S : 1.0;
-  const double base_scale = g.rw[lat] / (double)n;
-  for (int fl = 0; fl < nfl; fl++) {
-    const GridFld gf = flds[f0 + fl];
-    const d2 *af = a + (long long)fl * fs;
-    const double sc = base_scale * ((gf.mode == GM_ACOS) ? g.racthe[lat] : 1.0);
-    for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
-      d2 x;
-      if (!pl.cmode) {
-        const int kb = (k == 0) ? 0 : sz - k;
-        d2 za = af[FPAD(k)], zb = af[FPAD(kb)];
-        if (pl.blue) {
-          za = cscale(cmul(za, chirp[k]), invL);
-          zb = cscale(cmul(zb, chirp[kb]), invL);
-        }
-        // X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ]
-        d2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
-        d2 t = cmuli(cmul(rtw[k], d1));
-        x = mk2(0.5 * (s1.x - t.x), 0.5 * (s1.y - t.y));
-      } else {
-        x = af[FPAD(k)];
-        if (pl.blue) x = cscale(cmul(x, chirp[k]), invL);
-      }
-      *(d2 *)(FB + (long long)frow[k] * ldf + 2 * (f0 + fl)) = cscale(x, sc);
-    }
-  }
-}
-
-// ==========================================================================================
-// k_specnorm: SPNORMD (spnormd_mod.F90:40-57).  One block per field; deterministic order.
-// ==========================================================================================
-EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, long long nspec2, const double *sp, int stride, double *out) {
-  EMI_LDS_DECL;
-  double *red = (double *)EMI_LDS_PTR;
-  const int f = EMI_BID;
-  double s = 0.0;
-  for (long long i = EMI_TID; i < nspec2; i += EMI_NTHREADS) {
-    double v = sp[i * stride + f];
-    s += g.specw[i] * v * v;  // m = 0: real parts weight 1, imaginary 0; m > 0: weight 2
-  }
-  red[EMI_TID] = s;
-  EMI_SYNC();
-  for (int st = EMI_NTHREADS / 2; st > 0; st >>= 1) {
-    if (EMI_TID < st) red[EMI_TID] += red[EMI_TID + st];
-    EMI_SYNC();
-  }
-  if (EMI_TID == 0) out[f] = red[0];  // sum of squares; the host takes the root (after the task sum)
-}
+namespace emi_f32 {
+#define EMI_REAL float
+#define EMI_REAL2 f2
+#define EMI_ACC4 v4f
+#define EMI_MFMA emi_mfma_f32
+#define EMI_ACC_ROW(l, i) (4 * ((l) >> 4) + (i))
+#include "emi_kernels_body.h"
+#undef EMI_REAL
+#undef EMI_REAL2
+#undef EMI_ACC4
+#undef EMI_MFMA
+#undef EMI_ACC_ROW
+}  // namespace emi_f32

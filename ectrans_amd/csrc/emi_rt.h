@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 
 #ifndef EMI_CPU_EMU
 #include <hip/hip_runtime.h>
@@ -31,11 +32,17 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));  // native 16-byte vector: whole-value copies stay in VGPRs
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-EMI_DEVFN v4d emi_mfma_f64_16x16x4(double a, double b, v4d c) {
+EMI_DEVFN v4d emi_mfma_f64(double a, double b, v4d c) {
   // v_mfma_f64_16x16x4_f64: A[row=l&15][k=l>>4], B[k=l>>4][col=l&15],
   // C/D: col=l&15, row=(l>>4)+4*i  (cdna_hip_programming.md §3)
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+EMI_DEVFN v4f emi_mfma_f32(float a, float b, v4f c) {
+  // v_mfma_f32_16x16x4_f32: same A/B lane maps; C/D: col=l&15, row=4*(l>>4)+i (exact f32 fma chain)
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
 typedef hipStream_t emi_stream_t;
@@ -84,8 +91,12 @@ struct __attribute__((aligned(16))) d2 {
 struct int2 {
   int x, y;
 };
+typedef float v4f __attribute__((vector_size(16)));
+struct __attribute__((aligned(8))) f2 {
+  float x, y;
+};
 
-inline v4d emi_mfma_f64_16x16x4(double a, double b, v4d c) {
+inline v4d emi_mfma_f64(double a, double b, v4d c) {
   EmuCtx *x = emu_ctx;
   int w = x->tid >> 6, l = x->tid & 63;
   x->sa[w * 64 + l] = a;
@@ -95,6 +106,21 @@ inline v4d emi_mfma_f64_16x16x4(double a, double b, v4d c) {
     int row = (l >> 4) + 4 * i, col = l & 15;
     double s = c[i];
     for (int k = 0; k < 4; k++) s += x->sa[w * 64 + k * 16 + row] * x->sb[w * 64 + k * 16 + col];
+    c[i] = s;
+  }
+#pragma omp barrier
+  return c;
+}
+inline v4f emi_mfma_f32(float a, float b, v4f c) {
+  EmuCtx *x = emu_ctx;
+  int w = x->tid >> 6, l = x->tid & 63;
+  x->sa[w * 64 + l] = a;
+  x->sb[w * 64 + l] = b;
+#pragma omp barrier
+  for (int i = 0; i < 4; i++) {
+    int row = 4 * (l >> 4) + i, col = l & 15;  // f32 accumulator row map
+    float s = c[i];
+    for (int k = 0; k < 4; k++) s = fmaf((float)x->sa[w * 64 + k * 16 + row], (float)x->sb[w * 64 + k * 16 + col], s);
     c[i] = s;
   }
 #pragma omp barrier

@@ -1,0 +1,101 @@
+// emi_types.h -- device-visible descriptors shared by host code and both kernel precisions.
+#pragma once
+#include "emi_rt.h"
+
+// ------------------------------------------------------------------------------------------
+// device-visible descriptors
+// ------------------------------------------------------------------------------------------
+struct EmiGeomDev {
+  // Everything is indexed by LOCAL zonal-wavenumber number ml (0..nump-1, actual wavenumber
+  // mval[ml]) and LOCAL latitude number (0..nlat-1): with one task local == global; with several
+  // tasks each task owns the wavenumbers of its W-set (suwavedi_mod.F90:118-137) and a contiguous
+  // latitude band.
+  int nsmax, nump, nlat, ngptot;
+  const int *mval;    // [nump] actual zonal wavenumber
+  const int *nmen, *gpoff;  // [nlat]
+  const int *nasm0;   // [nump] 0-based index of Re(m, n=m) in the (local) user spectral dimension
+  const int *fbase;   // [nlat+1]  Fourier rows (lat, m<=NMEN) before the local latitude
+  const int *fftrow;  // [fbase[nlat]] row of (lat, m) in the FFT-side Fourier buffer
+  const int *lbase;   // [nump+1] start of wavenumber ml in legN/legS
+  const int *legN, *legS;  // row of (ml, j-th northern latitude with m<=NMEN) / its southern mirror
+                           // in the Legendre-side Fourier buffer
+  const int *wbase;   // [nump+1] packed-spectral rows before ml (padded to 16)
+  const int *wrows;   // [nump] padded row count (multiple of 16)
+  const int *rowm;    // [wbase[nump]] row -> ml
+  const int *ebase;   // [nump] index of eps(n=m) in eps[] (n = m..N+2)
+  const double *eps;  // REPSNM
+  const double *lapin;  // RLAPIN(n) at [n+1], n=-1..N+2
+  const double *rw, *racthe;   // [nlat]
+  const void *P;               // Legendre panels (real_t of the library precision)
+  const long long *offS, *offA;  // [nump] element offsets of the even/odd (n-m) panels
+  const int *ldp;              // [nump] padded latitude count (multiple of 64)
+  const void *PT;              // transposed panels for the direct transform: [par][lat j][k], k fastest
+  const long long *offTS, *offTA;  // [nump]
+  const int *ldk;              // [nump] padded k count (multiple of 64)
+  const int *lattile_pref;     // [nump+1] prefix of ceil(ndglu/64)
+  const int *ktile_pref;       // [nump+1] prefix of ceil((wrows/2)/64)
+  const double *specw;         // [nspec2 local] SPECNORM weight of every spectral entry (0, 1 or 2)
+};
+
+enum { SPK_COPY = 0, SPK_U = 1, SPK_V = 2, SPK_NSD = 3 };
+struct SpecSrc {  // one Legendre-space input field of the inverse transform
+  const void *a, *b;  // real_t arrays; element (ispec) of field = a[ispec*sa + ia]
+  int sa, ia, sb, ib;
+  int kind, pad_;
+};
+enum { SPO_COPY = 0, SPO_VOR = 1, SPO_DIV = 2 };
+struct SpecDst {  // one spectral output field of the direct transform
+  void *dst;  // real_t array
+  int stride, idx;
+  int kind, src0, src1, pad_;  // src*: field index in W (U and V for vor/div)
+};
+enum { GM_PLAIN = 0, GM_ACOS = 1, GM_EWDER = 2, GM_EWDER_UV = 3 };
+struct GridFld {  // one Fourier-space field <-> one user grid field
+  void *base;     // real_t array base; element (p) = base[((p/nproma)*nf_arr + fidx)*nproma + p%nproma]
+  int nf_arr, fidx;
+  int mode, src;  // src: field index inside FB (inverse only)
+};
+
+struct FftPlanDev {
+  int n;      // row length (NLOEN)
+  int sz;     // logical complex transform size: n/2 (n even) or n (cmode)
+  int S;      // LDS work size per field (complex): sz, or Bluestein length L
+  int cmode;  // 1: odd n, complex transform of the real row
+  int blue;   // 1: Bluestein
+  int nfac;
+  int fac[14];
+  int tw_off, perm_off, rtw_off, chirp_off, bhat_off;
+  int ptw_off[14];  // per pass (DIT order): table [(t-1)*lenp + j] = exp(-2 pi i j t/(lenp*R))
+  int fbk;  // fields per workgroup
+  int lds_class, pad_;
+};
+struct FftTabDev {
+  const void *tw;              // real2 tables of the library precision: e^{-2 pi i k/S}
+  const void *ptw;             // per-pass twiddles, coalesced layout
+  const unsigned short *perm;  // DIT input position of natural index
+  const void *rtw;             // e^{-2 pi i k/n}, k=0..sz
+  const void *chirp;           // e^{-i pi k^2/sz}
+  const void *bhat;            // DFT_L of the chirp filter, at perm positions
+  const FftPlanDev *plans;
+  const int *planid;           // [ndgl]
+};
+
+// block -> (latitude, field chunk) through a per-class prefix table
+struct FftLaunchDev {
+  const int *lats;      // latitudes of this LDS class
+  const int *blk_pref;  // [nlat_class+1] prefix of chunks per latitude
+  int nlat;
+  long long nblocks;
+};
+
+
+// ---- tile / LDS constants shared by both precisions
+#define LG_THREADS 256
+#define LG_BN 128
+#define LG_LDA 80
+#define LG_LDB 144
+#define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)  // sized for fp64; the fp32 kernels use half of it
+#define FFT_MAXR 16
+#define FFT_TWPOW_MIN (1 << 30)  // chained twiddle powers (1 load + R-2 products) measured no faster than the coalesced table reads: off
+#define FPAD(i) ((i) ^ (((i) >> 3) & 15))
+#define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)

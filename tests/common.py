@@ -47,13 +47,17 @@ def unblock(gp, ngptot):
     return np.concatenate([gp[b] for b in range(nb)], axis=1)[:, :ngptot]
 
 
-def run_case(et, Oracle, xp, nsmax, nloen, nuv, nsc, flags=None, nproma=None, seed=1):
+def run_case(et, Oracle, xp, nsmax, nloen, nuv, nsc, flags=None, nproma=None, seed=1, precision=8):
     """inverse + direct through the C-ABI (`et`) against the oracle; returns (e_inv, e_dir).
-    xp(a) moves a numpy array to the memory space under test and back: (to, back)."""
+    xp(a) moves a numpy array to the memory space under test and back: (to, back).
+    precision=4 runs the fp32 library on float32 copies of the same inputs (the oracle stays fp64)."""
     flags = flags or {}
     to, back = xp
+    if precision == 4:
+        to0, back0 = xp
+        to, back = (lambda a: to0(a.astype(np.float32))), (lambda a: np.asarray(back0(a), dtype=np.float64))
     nloen = np.asarray(nloen, dtype=np.int32)
-    r = et.setup_trans(nsmax, len(nloen), nloen)
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
     try:
         o = Oracle(nsmax, nloen)
         rng = np.random.default_rng(seed)

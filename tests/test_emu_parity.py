@@ -46,6 +46,26 @@ def test_emulated_kernels_match_oracle(et, name):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
+@pytest.mark.parametrize("name", ["octahedral_winds", "bluestein_even", "odd_lengths", "derivatives"])
+def test_emulated_fp32_library_matches_oracle(et, name):
+    """precision=4 (the reference's libtrans_sp arithmetic): same kernels instantiated for float with
+    v_mfma_f32_16x16x4_f32's accumulator layout.  Tolerance: a few float epsilons x log-ish growth."""
+    nsmax, nloen, nuv, nsc, flags, nproma = CASES[name]
+    e_inv, e_dir = run_case(et, Oracle, XP, nsmax, nloen, nuv, nsc, flags, nproma, precision=4)
+    assert e_inv < 2e-5 and e_dir < 2e-5, (e_inv, e_dir)
+    assert e_inv > 1e-9  # really computed in float
+
+
+def test_fp32_library_rejects_double_arrays(et):
+    nloen = octahedral(7)
+    r = et.setup_trans(7, len(nloen), nloen, precision=4)
+    try:
+        with pytest.raises(et.TransError, match="float32"):
+            et.inv_trans(r, pspscalar=np.zeros((et.trans_inq(r, "nspec2"), 1)), pgp=np.zeros((1, 1, et.trans_inq(r, "ngptot"))))
+    finally:
+        et.trans_release(r)
+
+
 def test_setup_tables_match_oracle(et):
     N = 15
     nloen = octahedral(N)

@@ -91,6 +91,22 @@ def test_device_arrays_match_oracle(et, dev, name):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
+FP32_CASES = ["O64_winds", "O160_winds", "full_grid_F64", "bluestein_even", "odd_lengths", "derivatives", "nproma_blocks",
+              "many_fields_two_tiles"]
+
+
+@pytest.mark.parametrize("name", FP32_CASES)
+def test_fp32_library_matches_oracle(et, dev, name):
+    """precision=4: the reference's single-precision library (libtrans_sp, JPRB=JPRM; BASELINE's
+    AIFS configuration computes in it).  Same kernels instantiated for float / v_mfma_f32_16x16x4_f32;
+    checked against the fp64 oracle on float32-rounded inputs.  Tolerance 3e-5 of the field maximum
+    (= 250 float epsilons; observed <= 3e-6)."""
+    nsmax, nloen, nuv, nsc, flags, nproma = CASES[name]
+    from oracle.oracle import Oracle as O
+    e_inv, e_dir = run_case(et, O, dev, nsmax, nloen, nuv, nsc, flags, nproma, precision=4)
+    assert e_inv < 3e-5 and e_dir < 3e-5, (e_inv, e_dir)
+
+
 def test_host_arrays_match_oracle(et):
     """EMI_MEM_HOST: numpy arrays staged over PCIe, as a Fortran/C caller would pass them."""
     from oracle.oracle import Oracle as O
@@ -142,13 +158,18 @@ def test_call_mode_2(et, dev):
     et.trans_release(r)
 
 
-def test_benchmark_harmonic_round_trips(et, dev):
+@pytest.mark.parametrize("precision", [8, 4])
+def test_benchmark_harmonic_round_trips(et, dev, precision):
     """ectrans-benchmark semantics at T47/O48 (tests/CMakeLists.txt:219-326): Re(4,19)=1 in every
-    field, 2 x (inv, dir), spectral-norm drift <= 100 eps (ectrans-benchmark.F90:847-871)."""
+    field, 2 x (inv, dir), spectral-norm drift <= 100 eps (ectrans-benchmark.F90:847-871), eps being
+    that of the library's working precision (epsilon(1.0_jprb))."""
     to, back = dev
+    EPS = float(np.finfo(np.float32 if precision == 4 else np.float64).eps)
+    if precision == 4:
+        to = lambda a, _to=dev[0]: _to(a.astype(np.float32))
     N = 47
     nloen = octahedral(N)
-    r = et.setup_trans(N, len(nloen), nloen)
+    r = et.setup_trans(N, len(nloen), nloen, precision=precision)
     ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
     nlev, nfld = 20, 10
     i419 = int(et.trans_inq(r, "nasm0")[4] - 1 + 2 * 15)

@@ -1,4 +1,4 @@
-"""Phase timings on the GPU: python tools/gpu_perf.py NSMAX NLEV NFLD [iters]"""
+"""Phase timings on the GPU: python tools/gpu_perf.py NSMAX NLEV NFLD [iters] [precision]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,13 +7,14 @@ import torch
 import ectrans_amd as et
 N, nlev, nfld = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+prec = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 dev = torch.device("cuda:0")
 et.setup_trans0(kmax_resol=2, device=0)
 H = N + 1
 nloen = np.array([20 + 4 * i for i in range(H)] + [20 + 4 * i for i in reversed(range(H))], dtype=np.int32)
-t0 = time.time(); r = et.setup_trans(N, 2 * H, nloen); print("setup %.2fs" % (time.time() - t0), flush=True)
+t0 = time.time(); r = et.setup_trans(N, 2 * H, nloen, precision=prec); print("setup %.2fs" % (time.time() - t0), flush=True)
 ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
-z = lambda *s: torch.zeros(s, dtype=torch.float64, device=dev)
+z = lambda *s: torch.zeros(s, dtype=torch.float32 if prec == 4 else torch.float64, device=dev)
 vor, div, sc3, sc2 = z(ns2, nlev), z(ns2, nlev), z(nfld, ns2, nlev), z(ns2, 1)
 g = torch.Generator(device=dev); g.manual_seed(1)
 for a in (vor, div, sc3, sc2):
