@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 # 2048 FLOP / 64 cycles) x 2.4 GHz = 78.6 TFLOP/s (AMD MI355X datasheet "FP64 matrix 78.6 TF";
 # /opt/skills/guides/MI355X_MICROARCH.md lists no fp64 row, tools/mfma_f64_peak.hip measures it).
 PEAK_F64_MFMA_TFLOPS = 78.6
+# fp32 matrix-core peak (v_mfma_f32_16x16x4_f32: 2048 FLOP / 32 cycles): 157.3 TFLOP/s
+# (/opt/skills/guides/MI355X_MICROARCH.md, "FP32 matrix")
+PEAK_F32_MFMA_TFLOPS = 157.3
 
 
 def octahedral(nsmax):
@@ -75,6 +78,8 @@ def main():
     ap.add_argument("--nsmax", type=int, default=1279)
     ap.add_argument("--nlev", type=int, default=137)
     ap.add_argument("--nfld", type=int, default=10)
+    ap.add_argument("--precision", type=int, default=8, choices=(4, 8),
+                    help="8: fp64 library (headline metric); 4: fp32 library (BASELINE configs[4]'s arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-batch", type=int, default=0)
     args = ap.parse_args()
@@ -107,14 +112,16 @@ def main():
     if args.max_batch:
         et.set_max_batch(args.max_batch)
     t0 = time.time()
-    r = et.setup_trans(N, 2 * (N + 1), octahedral(N))
+    r = et.setup_trans(N, 2 * (N + 1), octahedral(N), precision=args.precision)
+    esz = args.precision
+    peak = PEAK_F64_MFMA_TFLOPS if esz == 8 else PEAK_F32_MFMA_TFLOPS
     t_setup = time.time() - t0
     nspec2, ngptot = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")  # this rank's share
     a4 = int(et.trans_inq(r, "nasm0")[4])
     i419 = a4 - 1 + 2 * (19 - 4) if a4 > 0 else None  # only the rank owning m=4 holds the harmonic
 
     def z(*shape):
-        return torch.zeros(shape, dtype=torch.float64, device=dev)
+        return torch.zeros(shape, dtype=torch.float64 if esz == 8 else torch.float32, device=dev)
 
     # call mode 2 arrays of the reference harness (ectrans-benchmark.F90:450-479)
     spvor, spdiv, spsc3a, spsc2 = z(nspec2, nlev), z(nspec2, nlev), z(nfld, nspec2, nlev), z(nspec2, 1)
@@ -180,22 +187,22 @@ def main():
             "metric": "dir+inv transform-pairs/sec, TCo%d %dL x %d fields; spectral-norm rel-error" % (N, nlev, nfld),
             "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if esz == 8 else "f32", "data": "synthetic",
             "config": {"workload": "TCo%d/O%d, %d levels x %d 3-D fields + vor/div + 1 surface field, KF=%d, "
                                    "device-resident call-mode-2 arrays" % (N, N + 1, nlev, nfld, kf),
                        "parallelism": "1 GPU" if world == 1 else
                        "%d GPUs: zonal wavenumbers zig-zag + latitude bands, RCCL all-to-all-v per direction" % world,
                        "setup_s": round(t_setup, 2)},
             "spectral_norm_rel_error": abs(n0 / n1 - 1.0),
-            "roofline": {"bound": "mfma", "kernel": "k_leg_inv + k_leg_dir (fp64 MFMA Legendre transforms)",
-                         "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS * world, "unit": "TFLOP/s",
-                         "frac": ach / (PEAK_F64_MFMA_TFLOPS * world), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "k_leg_inv + k_leg_dir (fp%d MFMA Legendre transforms)" % (8 * esz),
+                         "achieved": ach, "peak": peak * world, "unit": "TFLOP/s",
+                         "frac": ach / (peak * world), "traffic": None,
                          "launches": leg_launches, "avg_launch_ms": ms_per_launch,
                          "algorithmic_flops_per_launch": flops_per_launch},
             "phase_ms_per_step": {"spectral_pack_unpack": pack_ms / args.steps, "legendre_mfma": leg_ms / args.steps,
                                   "fft": fft_ms / args.steps},
-            "fft_hbm": {"algorithmic_GB_per_step": 2 * (wm["fourier_bytes"] + kf * ngptot * 8.0) / 1e9,
-                        "achieved_GBps": 2 * (wm["fourier_bytes"] + kf * ngptot * 8.0) / 1e9 / max(fft_ms / args.steps * 1e-3, 1e-9),
+            "fft_hbm": {"algorithmic_GB_per_step": 2 * (wm["fourier_bytes"] + kf * ngptot * float(esz)) / 1e9,
+                        "achieved_GBps": 2 * (wm["fourier_bytes"] + kf * ngptot * float(esz)) / 1e9 / max(fft_ms / args.steps * 1e-3, 1e-9),
                         "peak_GBps": 8000.0 * world},
         }
         if world == 1 and not args.no_cpu_baseline:

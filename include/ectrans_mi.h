@@ -58,7 +58,9 @@ typedef struct {
   int kdgl;          /* KDGL number of Gaussian latitudes (even)                           */
   const int *kloen;  /* KLOEN(kdgl) points per latitude, NULL: full grid with 2*KDGL       */
   int kdlon;         /* KDLON (used only when kloen == NULL and > 0)                       */
-  int precision;     /* 8: fp64 (the _dp library).  4 is reserved for the fp32 path        */
+  int precision;     /* bytes per real of every data array of this resolution: 8 (or 0) =
+                      * fp64, the reference's libtrans_dp (JPRB=JPRD); 4 = fp32, its
+                      * libtrans_sp (JPRB=JPRM).  Setup arithmetic is double in both.       */
   /* options the reference GPU backend also refuses (gpu/external/setup_trans.F90:309,442):
    * a non-zero value returns EMI_ERR_UNSUPPORTED */
   int lduseflt, ldll, ldstretch;

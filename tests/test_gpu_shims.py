@@ -22,6 +22,12 @@ def test_fortran_shim_roundtrip():
     _run("fortran", "test_shim", "FORTRAN SHIM OK")
 
 
+def test_fortran_shim_single_precision():
+    """The same caller compiled with JPRB = real32 against the _sp flavour of the shim (-DEMI_SP):
+    SETUP_TRANS selects the fp32 kernels; norm drift <= 100 epsilon(1.0_jprb)."""
+    _run("fortran", "test_shim_sp", "FORTRAN SHIM OK (JPRB = real32)")
+
+
 def test_transi_c_api():
     """trans_new/trans_setup/trans_inquire/trans_dirtrans/trans_invtrans/trans_specnorm
     (tests/transi/transi_test.c, modelled on the reference's transi_test_program.c)."""
