@@ -112,7 +112,8 @@ static int upload(const std::vector<T> &h, T **d) {
 // ------------------------------------------------------------------------------------------
 // per-resolution plan
 // ------------------------------------------------------------------------------------------
-struct FftClass {
+struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a workgroup size and fields per workgroup
+  int nthr = 0, fbk = 0;
   std::vector<int> lats;
   int *d_lats = nullptr;
   size_t lds = 0;
@@ -127,10 +128,6 @@ struct FftClass {
 struct LegMaps {
   int2 *d_inv = nullptr, *d_dir = nullptr;
   long long n_inv = 0, n_dir = 0;
-};
-struct FftPref {  // block -> (latitude, field chunk) prefix tables of the three LDS classes for one field count
-  int *d_pref[3] = {nullptr, nullptr, nullptr};
-  long long nblocks[3] = {0, 0, 0};
 };
 
 struct Plan {
@@ -163,8 +160,7 @@ struct Plan {
   std::vector<FftPlanDev> fplans;
   std::vector<int> planid;  // [nlat]
   FftTabDev ftab{};
-  FftClass fclass[3];
-  std::map<int, FftPref> prefs;  // by field count
+  std::vector<FftClass> fclass;
   std::map<int, LegMaps> legmaps;  // by column-tile count
   // work buffers (grown on demand): W, Legendre-side Fourier buffer, FFT-side Fourier buffer
   // (the same allocation when nproc == 1)
@@ -308,23 +304,44 @@ static int build_fft_plans(Plan &P) {
       });
       bhat.insert(bhat.end(), bh.begin(), bh.end());
     }
-    // fields per workgroup: as many as fit ~40 KiB of LDS (power of two, <= 16); longer rows get
-    // one field per workgroup and more threads (512 / 1024) to keep the CU's SIMDs busy
+    // fields per workgroup: as many as fit ~40 KiB of LDS (power of two, <= 16); longer rows get one
+    // field per workgroup and more threads.  Threads per workgroup follow the LDS footprint: 256 up to
+    // 40 KiB, 512 up to 80 KiB, else 1024 -- i.e. always 16 waves per CU at 128 VGPRs.  (One thread per
+    // radix-8 butterfly, S/8, removes the idle lanes of the second sweep at S = 2560/3072/4608/5120
+    // but makes workgroups of 5, 9 and 10 waves, of which only one fits the 16-wave budget: measured
+    // 25 % slower.  EMI_FFT_THREADS = -1 selects that rule, N >= 64 a fixed size, for experiments.)
     size_t per_field = (size_t)FFT_LDS_ELEMS(pl.S) * 2 * P.esz;
     int fbk = 16;
     while (fbk > 1 && fbk * per_field > 40960) fbk >>= 1;
     pl.fbk = fbk;
     size_t need = fbk * per_field;
-    pl.lds_class = need <= 40960 ? 0 : (need <= 81920 ? 1 : 2);
     if (need > 160 * 1024) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d needs %zu B of LDS (> 160 KiB)", n, need);
+    int nthr = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);
+    const char *ft = getenv("EMI_FFT_THREADS");
+    if (ft && atoi(ft) == -1) {
+      int rmax = 2;
+      for (int r : fac) rmax = std::max(rmax, r);
+      const long long nbf = (long long)fbk * (pl.S / rmax);
+      for (int k = 1;; k++) {
+        nthr = roundup((int)((nbf + k - 1) / k), 64);
+        if (nthr <= 1024) break;
+      }
+    }
+    if (ft && atoi(ft) >= 64) nthr = std::min(1024, roundup(atoi(ft), 64));
+    int cls = -1;
+    for (size_t c = 0; c < P.fclass.size(); c++)
+      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk) cls = (int)c;
+    if (cls < 0) {
+      cls = (int)P.fclass.size();
+      P.fclass.emplace_back();
+      P.fclass[cls].nthr = nthr;
+      P.fclass[cls].fbk = fbk;
+    }
+    pl.lds_class = cls;
     int id = (int)P.fplans.size();
     P.fplans.push_back(pl);
     idx[n] = id;
     P.planid[j] = id;
-  }
-  for (int c = 0; c < 3; c++) {
-    P.fclass[c].lats.clear();
-    P.fclass[c].lds = 0;
   }
   for (int j = 0; j < P.nlat; j++) {
     const FftPlanDev &pl = P.fplans[P.planid[j]];
@@ -356,9 +373,9 @@ static int build_fft_plans(Plan &P) {
   P.ftab.perm = d_perm;
   P.ftab.plans = d_plans;
   P.ftab.planid = d_planid;
-  for (int c = 0; c < 3; c++) {
-    if (upload(P.fclass[c].lats, &P.fclass[c].d_lats)) return EMI_ERR_RUNTIME;
-    P.dev_allocs.push_back(P.fclass[c].d_lats);
+  for (FftClass &fc : P.fclass) {
+    if (upload(fc.lats, &fc.d_lats)) return EMI_ERR_RUNTIME;
+    P.dev_allocs.push_back(fc.d_lats);
   }
   return 0;
 }
@@ -733,8 +750,6 @@ extern "C" int emi_release(int kresol) {
   if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_RELEASE: unknown resolution %d", kresol);
   emi_stream_sync(0);
   for (void *p : P->dev_allocs) emi_dev_free(p);
-  for (auto &kv : P->prefs)
-    for (int c = 0; c < 3; c++) emi_dev_free(kv.second.d_pref[c]);
   for (auto &kv : P->legmaps) {
     emi_dev_free(kv.second.d_inv);
     emi_dev_free(kv.second.d_dir);
@@ -1021,32 +1036,6 @@ static int leg_tilemaps(Plan &P, int nct, LegMaps **out) {
   return 0;
 }
 
-static int fft_prefix(Plan &P, int nfld, FftPref **out) {
-  auto it = P.prefs.find(nfld);
-  if (it == P.prefs.end()) {
-    if (P.prefs.size() > 64) {  // bounded cache
-      emi_stream_sync(0);
-      for (auto &kv : P.prefs)
-        for (int c = 0; c < 3; c++) emi_dev_free(kv.second.d_pref[c]);
-      P.prefs.clear();
-    }
-    FftPref fp;
-    for (int c = 0; c < 3; c++) {
-      FftClass &fc = P.fclass[c];
-      std::vector<int> pref(fc.lats.size() + 1, 0);
-      for (size_t i = 0; i < fc.lats.size(); i++) {
-        int fbk = P.fplans[P.planid[fc.lats[i]]].fbk;
-        pref[i + 1] = pref[i] + (nfld + fbk - 1) / fbk;
-      }
-      fp.nblocks[c] = pref.back();
-      if (upload(pref, &fp.d_pref[c])) return EMI_ERR_RUNTIME;
-    }
-    it = P.prefs.emplace(nfld, fp).first;
-  }
-  *out = &it->second;
-  return 0;
-}
-
 static int pick_batch(Plan &P, int nfields, int depth) {
   // fields per batch: bounded by free HBM (W + FB rows x 16 B per field; FB twice when batches are
   // pipelined) and EMI_MAX_BATCH; multiples of 64 fields so the 128-column tiles are full
@@ -1127,17 +1116,20 @@ static PhaseTimer g_pt;
     }                                                                          \
   } while (0)
 
-static void launch_fft(Plan &P, const FftPref &fp, bool inverse, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
+static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
                        emi_stream_t st) {
-  for (int c = 0; c < 3; c++) {
+  for (size_t c = 0; c < P.fclass.size(); c++) {
     FftClass &fc = P.fclass[c];
-    if (fc.lats.empty() || fp.nblocks[c] == 0) continue;
-    FftLaunchDev lc{fc.d_lats, fp.d_pref[c], (int)fc.lats.size(), fp.nblocks[c]};
-    const int nthr = c == 0 ? 256 : (c == 1 ? 512 : 1024);
+    if (fc.lats.empty() || nfld <= 0) continue;
+    static const int fft_dbg = getenv("EMI_FFT_DBG") ? atoi(getenv("EMI_FFT_DBG")) : 0;
+    const int nchunk = (nfld + fc.fbk - 1) / fc.fbk;
+    const long long nblocks = (long long)fc.lats.size() * nchunk;
+    FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, fft_dbg};
+    const int nthr = fc.nthr;
     if (inverse)
-      EMI_LAUNCH_P(P.esz, k_fft_inv, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);
+      EMI_LAUNCH_P(P.esz, k_fft_inv, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);
     else
-      EMI_LAUNCH_P(P.esz, k_fft_dir, fp.nblocks[c], nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
+      EMI_LAUNCH_P(P.esz, k_fft_dir, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
   }
 }
 
@@ -1384,7 +1376,7 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
   if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
   const int ldw = 2 * bfpad;
   // all descriptors of the call in one upload
-  struct Bat { size_t off_l, off_g; int nl, ng; FftPref *fp; };
+  struct Bat { size_t off_l, off_g; int nl, ng; };
   std::vector<Bat> bats;
   std::vector<char> hdesc;
   for (int b0 = 0; b0 < nlt; b0 += bsz) {
@@ -1405,7 +1397,6 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     bt.off_g = hdesc.size();
     hdesc.resize(bt.off_g + (bg.size() * sizeof(GridFld) + 255) / 256 * 256);
     memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
-    if (fft_prefix(P, bt.ng, &bt.fp)) return EMI_ERR_RUNTIME;
     bats.push_back(bt);
   }
   if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
@@ -1445,7 +1436,7 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     // stream B: FFTs
     if (piped) g_pipe.wait(2 * ib, sB);
     iv = g_pt.start(2, sB);
-    launch_fft(P, *bt.fp, true, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    launch_fft(P, true, d_bg, bt.ng, FBf, ldw, nproma, sB);
     g_pt.stop(iv, sB);
     if (piped) g_pipe.signal(2 * ib + 1, sB);
   }
@@ -1545,7 +1536,7 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
   const int bfpad = roundup(maxb, 64);
   if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
   const int ldw = 2 * bfpad;
-  struct Bat { size_t off_g, off_o; int ng, no; FftPref *fp; };
+  struct Bat { size_t off_g, off_o; int ng, no; };
   std::vector<Bat> bats;
   std::vector<char> hdesc;
   for (auto &b : batches) {
@@ -1586,7 +1577,6 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     bt.off_o = hdesc.size();
     hdesc.resize(bt.off_o + (bo.size() * sizeof(SpecDst) + 255) / 256 * 256);
     memcpy(hdesc.data() + bt.off_o, bo.data(), bo.size() * sizeof(SpecDst));
-    if (fft_prefix(P, bt.ng, &bt.fp)) return EMI_ERR_RUNTIME;
     bats.push_back(bt);
   }
   if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
@@ -1612,7 +1602,7 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     // stream B: FFTs (need FB[ib&1] released by the Legendre transform of batch ib-2)
     if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sB);
     int iv = g_pt.start(2, sB);
-    launch_fft(P, *bt.fp, false, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    launch_fft(P, false, d_bg, bt.ng, FBf, ldw, nproma, sB);
     g_pt.stop(iv, sB);
     if (piped) g_pipe.signal(2 * ib, sB);
     if (exchange(P, false, ldw, st)) return EMI_ERR_RUNTIME;  // TRLTOM (several tasks: never piped)

@@ -23,12 +23,14 @@ namespace emi_f64 {
 #define EMI_ACC4 v4d
 #define EMI_MFMA emi_mfma_f64
 #define EMI_ACC_ROW(l, i) (((l) >> 4) + 4 * (i))
+#define EMI_FFT_WAVES 4
 #include "emi_kernels_body.h"
 #undef EMI_REAL
 #undef EMI_REAL2
 #undef EMI_ACC4
 #undef EMI_MFMA
 #undef EMI_ACC_ROW
+#undef EMI_FFT_WAVES
 }  // namespace emi_f64
 
 namespace emi_f32 {
@@ -37,10 +39,12 @@ namespace emi_f32 {
 #define EMI_ACC4 v4f
 #define EMI_MFMA emi_mfma_f32
 #define EMI_ACC_ROW(l, i) (4 * ((l) >> 4) + (i))
+#define EMI_FFT_WAVES 4
 #include "emi_kernels_body.h"
 #undef EMI_REAL
 #undef EMI_REAL2
 #undef EMI_ACC4
 #undef EMI_MFMA
 #undef EMI_ACC_ROW
+#undef EMI_FFT_WAVES
 }  // namespace emi_f32

@@ -522,16 +522,30 @@ EMI_DEVFN void split_q(int q, int lenp, int sh, int &blk, int &j) {
 EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_clz((unsigned)v)); }
 
 // one in-place pass over nfl fields.  MASK: logical elements >= nvalid read as zero (only the first
-// DIF pass of a zero-padded Bluestein input).
-template <int R, int DIF, int MASK>
-EMI_DEVFN void fft_pass(real2 *a, int nfl, int fstride, int S, int lenp, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
+// DIF pass of a zero-padded Bluestein input).  TW: the pass has inter-pass twiddles (lenp > 1).
+// The R-1 twiddles W_len^{j t} are fetched into registers first -- coalesced reads of the per-pass
+// table [t-1][j], all in flight together with the LDS reads -- and applied before (DIT) or after
+// (DIF) the butterfly.
+template <int R, int DIF, int MASK, int TW>
+EMI_DEVFN void fft_pass_body(real2 *a, int nfl, int fstride, int S, int lenp, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
   const int len = lenp * R, nb = S / R, sh = log2_exact(lenp);
   for (int fl = 0; fl < nfl; fl++) {
     real2 *af = a + (long long)fl * fstride;
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
       int blk, j;
-      split_q(q, lenp, sh, blk, j);
+      if (R == 2 || R == 4 || R == 8) {  // power-of-two radices come first: their lenp is a power of two
+        blk = q >> sh;
+        j = q & (lenp - 1);
+      } else {
+        split_q(q, lenp, sh, blk, j);
+      }
       const int base = blk * len + j;
+      real2 w[R];
+      if (TW) {
+        const real2 *pw_ = ptw + j;
+#pragma unroll
+        for (int t = 1; t < R; t++) w[t] = pw_[(t - 1) * lenp];
+      }
       real2 v[R];
 #pragma unroll
       for (int t = 0; t < R; t++) {
@@ -541,32 +555,32 @@ EMI_DEVFN void fft_pass(real2 *a, int nfl, int fstride, int S, int lenp, const r
         else
           v[t] = af[FPAD(i)];
       }
-      // inter-pass twiddles W_len^{j t}: coalesced reads of the per-pass table [t-1][j]
-      // (FFT_TWPOW_MIN: optional product chain from W^j, measured no faster)
-#define FFT_APPLY_TW()                                                              \
-  if (lenp >= FFT_TWPOW_MIN && R > 2) {                                             \
-    const real2 w1 = tw_get(ptw, j, sgn);                                              \
-    real2 wt = w1;                                                                     \
-    v[1] = cmul(v[1], wt);                                                          \
-    _Pragma("unroll") for (int t = 2; t < R; t++) {                                 \
-      wt = cmul(wt, w1);                                                            \
-      v[t] = cmul(v[t], wt);                                                        \
-    }                                                                               \
-  } else if (lenp > 1) {                                                            \
-    const real2 *pw_ = ptw + j;                                                        \
-    _Pragma("unroll") for (int t = 1; t < R; t++) v[t] = cmul(v[t], tw_get(pw_, (t - 1) * lenp, sgn)); \
-  }
-      if (!DIF) {
-        FFT_APPLY_TW();
+      if (TW) {
+        if (sgn > 0) {
+#pragma unroll
+          for (int t = 1; t < R; t++) w[t].y = -w[t].y;
+        }
+      }
+      if (TW && !DIF) {
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
       }
       butterfly<R>(v, tw, S, sgn);
-      if (DIF) {
-        FFT_APPLY_TW();
+      if (TW && DIF) {
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
       }
 #pragma unroll
       for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
     }
   }
+}
+template <int R, int DIF, int MASK>
+EMI_DEVFN void fft_pass(real2 *a, int nfl, int fstride, int S, int lenp, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
+  if (lenp > 1)
+    fft_pass_body<R, DIF, MASK, 1>(a, nfl, fstride, S, lenp, tw, ptw, sgn, nvalid);
+  else
+    fft_pass_body<R, DIF, MASK, 0>(a, nfl, fstride, S, lenp, tw, ptw, sgn, nvalid);
 }
 
 #define FFT_DISPATCH(FN, r, ...)                  \
@@ -634,15 +648,14 @@ EMI_DEVFN void blue_middle(real2 *a, int nfl, int fs, int S, const real2 *tw, co
     real2 *af = a + (long long)fl * fs;
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
       const int base = q * R;
-      real2 v[R];
+      real2 v[R], b[R];
+#pragma unroll
+      for (int t = 0; t < R; t++) b[t] = bh[base + t];  // filter values: in flight with the LDS reads
 #pragma unroll
       for (int t = 0; t < R; t++) v[t] = (base + t < nvalid) ? af[FPAD(base + t)] : mk2(0.0, 0.0);
       butterfly<R>(v, tw, S, -1);
 #pragma unroll
-      for (int t = 0; t < R; t++) {
-        real2 b = bh[base + t];
-        v[t] = conj_b ? cmulc(v[t], b) : cmul(v[t], b);
-      }
+      for (int t = 0; t < R; t++) v[t] = conj_b ? cmulc(v[t], b[t]) : cmul(v[t], b[t]);
       butterfly<R>(v, tw, S, +1);
 #pragma unroll
       for (int t = 0; t < R; t++) af[FPAD(base + t)] = v[t];
@@ -664,21 +677,32 @@ EMI_DEVFN int blue_conv(real2 *a, int nfl, int fs, const FftPlanDev &pl, const F
   return run_dit(a, nfl, fs, L, pl, T, 1, last < 1 ? 1 : last, r0, +1);
 }
 
-EMI_DEVFN long long grid_index(const GridFld &gf, long long p, int nproma) {
-  long long blk = p / nproma;
-  return (blk * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk * nproma);
+// Grid arrays are blocked (ngpblks, nfld, nproma).  One latitude row of one field starts at point
+// gp0 of the task's grid; GridRow resolves the NPROMA block of gp0 once (the only 64-bit division),
+// every element then costs an add and a compare unless the row crosses a block boundary.
+struct GridRow {
+  real_t *p0;         // first element of (block of gp0, this field)
+  unsigned rem0, np;  // gp0's offset inside its block; NPROMA
+  long long bstride;  // elements from one block of this field to the next: nf_arr * NPROMA
+};
+EMI_DEVFN GridRow grid_row(const GridFld &gf, long long gp0, int nproma) {
+  GridRow r;
+  const long long blk0 = gp0 / nproma;
+  r.rem0 = (unsigned)(gp0 - blk0 * nproma);
+  r.np = (unsigned)nproma;
+  r.bstride = (long long)gf.nf_arr * nproma;
+  r.p0 = (real_t *)gf.base + (blk0 * gf.nf_arr + gf.fidx) * (long long)nproma;
+  return r;
 }
-
-EMI_DEVFN int fft_find(const int *pref, int n, int b) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (pref[mid] <= b)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  return lo;
+EMI_DEVFN real_t *grid_ptr(const GridRow &r, unsigned o) {  // o: point number within the latitude row
+  unsigned q = r.rem0 + o;
+  if (q < r.np) return r.p0 + q;
+  const unsigned b = q / r.np;
+  return r.p0 + (long long)b * r.bstride + (q - b * r.np);
+}
+// points o, o+1 contiguous and 2-element aligned: one real2 access
+EMI_DEVFN bool grid_pair_ok(const GridRow &r, unsigned o) {
+  return (r.rem0 + o + 1 < r.np) && ((((uintptr_t)(r.p0 + r.rem0 + o)) & (2 * sizeof(real_t) - 1)) == 0);
 }
 
 // final DIT pass of the inverse real transform, stored straight to the grid array:
@@ -691,16 +715,25 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
   const real_t invL = pl.blue ? (real_t)(1.0 / (double)S) : (real_t)1.0;
   for (int fl = 0; fl < nfl; fl++) {
     real2 *af = a + (long long)fl * fs;
-    const GridFld gf = flds[f0 + fl];
+    const GridRow gr = grid_row(flds[f0 + fl], gp0, nproma);
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
       int blk, j;
       split_q(q, lenp, sh, blk, j);  // last pass: len == S, blk == 0
-      real2 v[R];
+      real2 v[R], w[R], ch[R];
+      if (lenp > 1) {
+        const real2 *pw_ = ptw + j;
+#pragma unroll
+        for (int t = 1; t < R; t++) w[t] = pw_[(t - 1) * lenp];
+      }
 #pragma unroll
       for (int t = 0; t < R; t++) v[t] = af[FPAD(j + t * lenp)];
-      {
-        const int sgn = +1;
-        FFT_APPLY_TW();
+      if (lenp > 1) {
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmulc(v[t], w[t]);  // inverse: conjugate twiddles
+      }
+      if (pl.blue) {  // chirp values of the outputs: in flight during the butterfly
+#pragma unroll
+        for (int t = 0; t < R; t++) ch[t] = (j + t * lenp < sz) ? chirp[j + t * lenp] : mk2(0.0, 0.0);
       }
       butterfly<R>(v, tw, S, +1);
 #pragma unroll
@@ -708,18 +741,16 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
         const int i = j + t * lenp;
         if (i < sz) {
           real2 z = v[t];
-          if (pl.blue) z = cscale(cmulc(z, chirp[i]), invL);
+          if (pl.blue) z = cscale(cmulc(z, ch[t]), invL);
           if (!pl.cmode) {
-            const long long p = gp0 + 2LL * i;
-            const long long blk0 = p / nproma;
-            if (blk0 == (p + 1) / nproma && (((uintptr_t)gf.base & (2 * sizeof(real_t) - 1)) == 0) && (((blk0 * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk0 * nproma)) & 1) == 0) {
-              *(real2 *)((real_t *)gf.base + (blk0 * gf.nf_arr + gf.fidx) * (long long)nproma + (p - blk0 * nproma)) = z;
+            if (grid_pair_ok(gr, 2u * i)) {
+              *(real2 *)grid_ptr(gr, 2u * i) = z;
             } else {
-              ((real_t *)gf.base)[grid_index(gf, p, nproma)] = z.x;
-              ((real_t *)gf.base)[grid_index(gf, p + 1, nproma)] = z.y;
+              *grid_ptr(gr, 2u * i) = z.x;
+              *grid_ptr(gr, 2u * i + 1) = z.y;
             }
           } else {
-            ((real_t *)gf.base)[grid_index(gf, gp0 + i, nproma)] = z.x;
+            *grid_ptr(gr, (unsigned)i) = z.x;
           }
         }
       }
@@ -742,15 +773,15 @@ EMI_DEVFN real2 fsc_load(const real_t *FB, long long row, int ldf, const GridFld
   return x;
 }
 
-EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
                               int ldf, int nproma) {
   EMI_LDS_DECL;
   real2 *a = (real2 *)EMI_LDS_PTR;
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
-  const int li = fft_find(Lc.blk_pref, Lc.nlat, bid);
+  const int li = bid / Lc.nchunk;
   const int lat = Lc.lats[li];
   const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = (bid - Lc.blk_pref[li]) * pl.fbk;
+  const int f0 = (bid - li * Lc.nchunk) * pl.fbk;
   const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
   const int fs = FFT_LDS_ELEMS(S);
@@ -769,8 +800,8 @@ EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
       const int npair = sz / 2 + 1;  // k = 0..sz/2 pairs with sz-k
       for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
         const int k2 = sz - k;
-        real2 xa = (k <= nmen) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
-        real2 xb = (k2 <= nmen) ? fsc_load(FB, frow[k2], ldf, gf, k2, racthe) : mk2(0, 0);
+        real2 xa = (k <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
+        real2 xb = (k2 <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, frow[k2], ldf, gf, k2, racthe) : mk2(0, 0);
         // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
         real2 wk = cconj(rtw[k]);
         real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
@@ -807,30 +838,34 @@ EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
       blue_conv(a, nfl, fs, pl, T, 1, sz, 0);
       const real_t invL = (real_t)(1.0 / (double)S);
       for (int fl = 0; fl < nfl; fl++) {
-        const GridFld gf = flds[f0 + fl];
+        const GridRow gr = grid_row(flds[f0 + fl], gp0, nproma);
         const real2 *af = a + (long long)fl * fs;
         for (int p = EMI_TID; p < n; p += EMI_NTHREADS) {
           const int i = pl.cmode ? p : (p >> 1);
           real2 z = cscale(cmulc(af[FPAD(i)], chirp[i]), invL);
-          ((real_t *)gf.base)[grid_index(gf, gp0 + p, nproma)] = (pl.cmode || !(p & 1)) ? z.x : z.y;
+          *grid_ptr(gr, (unsigned)p) = (pl.cmode || !(p & 1)) ? z.x : z.y;
         }
       }
       return;
     }
+    if (Lc.dbg & 2) {
+      lenp = S / pl.fac[pl.nfac - 1];
+    } else
     lenp = blue_conv(a, nfl, fs, pl, T, 1, sz, 1);
   } else {
     if (pl.nfac == 0) {  // sz == 1
       for (int fl = EMI_TID; fl < nfl; fl += EMI_NTHREADS) {
-        const GridFld gf = flds[f0 + fl];
+        const GridRow gr = grid_row(flds[f0 + fl], gp0, nproma);
         real2 z = a[(long long)fl * fs];
-        ((real_t *)gf.base)[grid_index(gf, gp0, nproma)] = z.x;
-        if (!pl.cmode) ((real_t *)gf.base)[grid_index(gf, gp0 + 1, nproma)] = z.y;
+        *grid_ptr(gr, 0u) = z.x;
+        if (!pl.cmode) *grid_ptr(gr, 1u) = z.y;
       }
       return;
     }
     lenp = run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac - 1, 1, +1);
   }
   const int rl = pl.fac[pl.nfac - 1];
+  if (Lc.dbg & 4) return;
   FFT_DISPATCH(dit_last_to_grid, rl, a, nfl, fs, S, lenp, tw, (const real2 *)T.ptw + pl.ptw_off[pl.nfac - 1], pl, chirp, flds, f0, gp0, nproma);
 }
 
@@ -840,15 +875,15 @@ EMI_KERNEL_LBV void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
 // (ledir_mod.F90:118-124) and LDFOU2's 1/(a cos) (ldfou2_mod.F90:90-96) only depend on the
 // latitude and are folded into the same scale factor.
 // ==========================================================================================
-EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
                               int nproma) {
   EMI_LDS_DECL;
   real2 *a = (real2 *)EMI_LDS_PTR;
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
-  const int li = fft_find(Lc.blk_pref, Lc.nlat, bid);
+  const int li = bid / Lc.nchunk;
   const int lat = Lc.lats[li];
   const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = (bid - Lc.blk_pref[li]) * pl.fbk;
+  const int f0 = (bid - li * Lc.nchunk) * pl.fbk;
   const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
   const int fs = FFT_LDS_ELEMS(S);
@@ -863,19 +898,18 @@ EMI_KERNEL_LBV void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const 
   for (int fl = 0; fl < nfl; fl++) {
     const GridFld gf = flds[f0 + fl];
     real2 *af = a + (long long)fl * fs;
-    const real_t *rowp = (const real_t *)gf.base + (long long)gf.fidx * nproma + gp0;
-    const bool flat = (gp0 + n <= (long long)nproma) && ((((uintptr_t)rowp) & (2 * sizeof(real_t) - 1)) == 0);
+    const GridRow gr = grid_row(gf, gp0, nproma);
     for (int lz = EMI_TID; lz < sz; lz += EMI_NTHREADS) {
       real2 z;
       if (!pl.cmode) {
-        if (flat) {
-          z = *(const real2 *)(rowp + 2 * lz);
+        if (grid_pair_ok(gr, 2u * lz)) {
+          z = *(const real2 *)grid_ptr(gr, 2u * lz);
         } else {
-          z.x = ((real_t *)gf.base)[grid_index(gf, gp0 + 2 * lz, nproma)];
-          z.y = ((real_t *)gf.base)[grid_index(gf, gp0 + 2 * lz + 1, nproma)];
+          z.x = *grid_ptr(gr, 2u * lz);
+          z.y = *grid_ptr(gr, 2u * lz + 1);
         }
       } else {
-        z.x = ((real_t *)gf.base)[grid_index(gf, gp0 + lz, nproma)];
+        z.x = *grid_ptr(gr, (unsigned)lz);
         z.y = 0.0;
       }
       af[FPAD(pl.blue ? lz : (int)perm[lz])] = pl.blue ? cmul(z, chirp[lz]) : z;

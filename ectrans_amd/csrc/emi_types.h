@@ -82,10 +82,11 @@ struct FftTabDev {
 
 // block -> (latitude, field chunk) through a per-class prefix table
 struct FftLaunchDev {
-  const int *lats;      // latitudes of this LDS class
-  const int *blk_pref;  // [nlat_class+1] prefix of chunks per latitude
+  const int *lats;  // latitudes of this launch group (same workgroup size and fields per workgroup)
   int nlat;
+  int nchunk;       // field chunks per latitude: block b works on latitude b / nchunk, chunk b % nchunk
   long long nblocks;
+  int dbg;  // EMI_FFT_DBG (timing experiments only): 1 skip global input loads, 2 skip the LDS passes, 4 skip the output stage
 };
 
 
@@ -96,6 +97,5 @@ struct FftLaunchDev {
 #define LG_LDB 144
 #define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)  // sized for fp64; the fp32 kernels use half of it
 #define FFT_MAXR 16
-#define FFT_TWPOW_MIN (1 << 30)  // chained twiddle powers (1 load + R-2 products) measured no faster than the coalesced table reads: off
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
