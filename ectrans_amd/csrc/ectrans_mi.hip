@@ -524,7 +524,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
       P.offA[ml] = poff + pan;
       poff += 2 * pan;
       P.ldk[ml] = roundup(P.wrows[ml] / 2, 64);
-      long long pant = (long long)roundup(std::max(nd, 1), 8) * P.ldk[ml];
+      long long pant = (long long)roundup(std::max(nd, 1), 16) * P.ldk[ml];  // k_leg_dir reads 16-latitude stages
       P.offTS[ml] = ptoff;
       P.offTA[ml] = ptoff + pant;
       ptoff += 2 * pant;
@@ -660,7 +660,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
         return rc;
       };
       if (put(P.d_P + P.offS[ml] * esz, pan)) bad = 1;
-      const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), 8);
+      const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), 16);
       std::vector<double> pt((size_t)2 * ndp * ldk, 0.0);
       for (int par = 0; par < 2; par++)
         for (int k = 0; k < nk; k++)
@@ -1208,6 +1208,8 @@ static int pipeline_depth(const Plan &P, int nfields) {
 static int set_lds_attrs() {
   static bool done = false;
   if (done) return 0;
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_leg_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_leg_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1609,7 +1611,7 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     // stream A: Legendre + spectral unpack
     if (piped) g_pipe.wait(2 * ib, sA);
     iv = g_pt.start(1, sA);
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES + 8 * ((P.ndgnh + 8) & ~7) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, ldw, (RT *)P.d_W, ldw);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, ldw, (RT *)P.d_W, ldw);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(2 * ib + 1, sA);
     iv = g_pt.start(0, sA);

@@ -274,7 +274,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, int ldf, real_t *W, int ldw) {
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
-  real_t *Bs = As + 2 * 8 * LG_LDA;
+  real_t *Bs = As + 2 * 16 * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int par = w & 1, wn = w >> 1;
   const int2 tm = tilemap[EMI_BID];
@@ -283,7 +283,8 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
-  const int nst = (ndglu + 7) >> 3;
+  const int nst = (ndglu + 15) >> 4;  // stages of 16 latitudes: 32 MFMAs per wave between barriers
+  const int ni = (nkpad - k0 + 15) >> 4 < 4 ? (nkpad - k0 + 15) >> 4 : 4;  // live 16-row groups of this tile
   const long long wb = g.wbase[m];
 
   acc4 acc[4][4];
@@ -292,23 +293,24 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (acc4){0.0, 0.0, 0.0, 0.0};
 
-  // P^T tile: 8 latitudes x 64 k per parity, k contiguous in HBM (coalesced 512-B rows) and in LDS
-  const int arow = tid >> 5, ac2 = tid & 31;
+  // P^T tile: 16 latitudes x 64 k per parity, k contiguous in HBM (coalesced 512-B rows) and in LDS
+  const int arow = tid >> 5, ac2 = tid & 31;  // latitude rows arow and arow+8 of the stage
   const int ldk = g.ldk[m];
   const real_t *pS = (const real_t *)g.PT + g.offTS[m] + (long long)arow * ldk + k0 + 2 * ac2;
   const real_t *pA = (const real_t *)g.PT + g.offTA[m] + (long long)arow * ldk + k0 + 2 * ac2;
-  const long long stepA = 8LL * ldk;
-  const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow and brow+4 of each 8-row stage
+  const long long stepA = 16LL * ldk, rowA8 = 8LL * ldk;
+  const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow + 4 i, i = 0..3, of each stage
   const real_t *FBc = FB + col0 + 2 * bc2;
-  real2 ra0, ra1, rn0, rn1, rs0, rs1;     // stage s+1 (written to LDS at the top of the next iteration)
-  real2 qn0, qn1, qs0, qs1;               // stage s+2 (FB rows only: their latency is the long one)
+  real2 ra0, ra1, ra2, ra3;                      // P^T of stage s+1
+  real2 rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
   // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
-  // kernels), so each stage touches 16 far-apart rows: they are prefetched TWO stages ahead.  Their
-  // row numbers (fbase[lat]+m) are staged once per tile in LDS, so that looking them up is an LDS
-  // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
-  int *rowN = (int *)(Bs + 2 * 8 * LG_LDB);
-  int *rowS = rowN + 8 * nst;
-  for (int j = tid; j < 8 * nst; j += LG_THREADS) {
+  // kernels), so each stage touches 32 far-apart rows, prefetched one stage (~2 x 2048 MFMA cycles
+  // per SIMD) ahead.  Their row numbers (fbase[lat]+m) are staged once per tile in LDS, so that
+  // looking them up is an LDS read (lgkmcnt) and never a vector-memory load that would order behind
+  // the prefetches (vmcnt).
+  int *rowN = (int *)(Bs + 2 * 16 * LG_LDB);
+  int *rowS = rowN + 16 * nst;
+  for (int j = tid; j < 16 * nst; j += LG_THREADS) {
     int rn_ = -1, rs_ = -1;
     if (j < ndglu) {
       rn_ = g.legN[lb + j];
@@ -318,48 +320,66 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
     rowS[j] = rs_;
   }
   EMI_SYNC();
-#define LEGDIR_LOADB(s_, n0_, s0_, n1_, s1_)                                       \
-  {                                                                                \
-    const int j0_ = 8 * (s_) + brow;                                               \
-    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + 4], is1 = rowS[j0_ + 4]; \
-    n0_ = in0 >= 0 ? *(const real2 *)(FBc + (long long)in0 * ldf) : mk2(0, 0);        \
-    s0_ = is0 >= 0 ? *(const real2 *)(FBc + (long long)is0 * ldf) : mk2(0, 0);        \
-    n1_ = in1 >= 0 ? *(const real2 *)(FBc + (long long)in1 * ldf) : mk2(0, 0);        \
-    s1_ = is1 >= 0 ? *(const real2 *)(FBc + (long long)is1 * ldf) : mk2(0, 0);        \
+#define LEGDIR_LOADB(s_)                                                            \
+  {                                                                                 \
+    const int j0_ = 16 * (s_) + brow;                                               \
+    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + 4], is1 = rowS[j0_ + 4];         \
+    const int in2 = rowN[j0_ + 8], is2 = rowS[j0_ + 8], in3 = rowN[j0_ + 12], is3 = rowS[j0_ + 12]; \
+    rn0 = in0 >= 0 ? *(const real2 *)(FBc + (long long)in0 * ldf) : mk2(0, 0);      \
+    rs0 = is0 >= 0 ? *(const real2 *)(FBc + (long long)is0 * ldf) : mk2(0, 0);      \
+    rn1 = in1 >= 0 ? *(const real2 *)(FBc + (long long)in1 * ldf) : mk2(0, 0);      \
+    rs1 = is1 >= 0 ? *(const real2 *)(FBc + (long long)is1 * ldf) : mk2(0, 0);      \
+    rn2 = in2 >= 0 ? *(const real2 *)(FBc + (long long)in2 * ldf) : mk2(0, 0);      \
+    rs2 = is2 >= 0 ? *(const real2 *)(FBc + (long long)is2 * ldf) : mk2(0, 0);      \
+    rn3 = in3 >= 0 ? *(const real2 *)(FBc + (long long)in3 * ldf) : mk2(0, 0);      \
+    rs3 = is3 >= 0 ? *(const real2 *)(FBc + (long long)is3 * ldf) : mk2(0, 0);      \
   }
-  LEGDIR_LOADB(0, rn0, rs0, rn1, rs1);
-  ra0 = *(const real2 *)pS;
-  ra1 = *(const real2 *)pA;
-  if (nst > 1) LEGDIR_LOADB(1, qn0, qs0, qn1, qs1);
+#define LEGDIR_LOADA(s_)                                          \
+  {                                                               \
+    ra0 = *(const real2 *)(pS + (s_) * stepA);                    \
+    ra1 = *(const real2 *)(pA + (s_) * stepA);                    \
+    ra2 = *(const real2 *)(pS + (s_) * stepA + rowA8);            \
+    ra3 = *(const real2 *)(pA + (s_) * stepA + rowA8);            \
+  }
+  LEGDIR_LOADB(0);
+  LEGDIR_LOADA(0);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
-    *(real2 *)(As + (0 * 8 + arow) * LG_LDA + 2 * ac2) = ra0;  // As[par][kk = latitude in stage][k index]
-    *(real2 *)(As + (1 * 8 + arow) * LG_LDA + 2 * ac2) = ra1;
-    *(real2 *)(Bs + (0 * 8 + brow) * LG_LDB + 2 * bc2) = cadd(rn0, rs0);      // symmetric part
-    *(real2 *)(Bs + (1 * 8 + brow) * LG_LDB + 2 * bc2) = csub(rn0, rs0);      // antisymmetric part
-    *(real2 *)(Bs + (0 * 8 + brow + 4) * LG_LDB + 2 * bc2) = cadd(rn1, rs1);
-    *(real2 *)(Bs + (1 * 8 + brow + 4) * LG_LDB + 2 * bc2) = csub(rn1, rs1);
+    // As[par][latitude in stage][k index], Bs[par][latitude in stage][column]
+    *(real2 *)(As + (0 * 16 + arow) * LG_LDA + 2 * ac2) = ra0;
+    *(real2 *)(As + (1 * 16 + arow) * LG_LDA + 2 * ac2) = ra1;
+    *(real2 *)(As + (0 * 16 + arow + 8) * LG_LDA + 2 * ac2) = ra2;
+    *(real2 *)(As + (1 * 16 + arow + 8) * LG_LDA + 2 * ac2) = ra3;
+    *(real2 *)(Bs + (0 * 16 + brow) * LG_LDB + 2 * bc2) = cadd(rn0, rs0);  // symmetric part
+    *(real2 *)(Bs + (1 * 16 + brow) * LG_LDB + 2 * bc2) = csub(rn0, rs0);  // antisymmetric part
+    *(real2 *)(Bs + (0 * 16 + brow + 4) * LG_LDB + 2 * bc2) = cadd(rn1, rs1);
+    *(real2 *)(Bs + (1 * 16 + brow + 4) * LG_LDB + 2 * bc2) = csub(rn1, rs1);
+    *(real2 *)(Bs + (0 * 16 + brow + 8) * LG_LDB + 2 * bc2) = cadd(rn2, rs2);
+    *(real2 *)(Bs + (1 * 16 + brow + 8) * LG_LDB + 2 * bc2) = csub(rn2, rs2);
+    *(real2 *)(Bs + (0 * 16 + brow + 12) * LG_LDB + 2 * bc2) = cadd(rn3, rs3);
+    *(real2 *)(Bs + (1 * 16 + brow + 12) * LG_LDB + 2 * bc2) = csub(rn3, rs3);
     EMI_SYNC();
-    rn0 = qn0; rs0 = qs0; rn1 = qn1; rs1 = qs1;  // stage s+1 <- registers of stage s+2 (in flight)
     if (s + 1 < nst) {
-      ra0 = *(const real2 *)(pS + (s + 1) * stepA);
-      ra1 = *(const real2 *)(pA + (s + 1) * stepA);
+      LEGDIR_LOADB(s + 1);
+      LEGDIR_LOADA(s + 1);
     }
-    if (s + 2 < nst) LEGDIR_LOADB(s + 2, qn0, qs0, qn1, qs1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
+    for (int ks = 0; ks < 4; ks++) {
       const int kk = 4 * ks + (l >> 4);
       real_t a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[(par * 8 + kk) * LG_LDA + i * 16 + (l & 15)];
+      for (int i = 0; i < 4; i++) a[i] = As[(par * 16 + kk) * LG_LDA + i * 16 + (l & 15)];
 #pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[(par * 8 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
+      for (int j = 0; j < 4; j++) b[j] = Bs[(par * 16 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
 #pragma unroll
       for (int i = 0; i < 4; i++)
+        if (i < ni) {  // the last k tile of a wavenumber: 16-row groups past the end are skipped
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
+        }
     }
   }
+#undef LEGDIR_LOADA
 #undef LEGDIR_LOADB
 #pragma unroll
   for (int i = 0; i < 4; i++)

@@ -95,7 +95,8 @@ struct FftLaunchDev {
 #define LG_BN 128
 #define LG_LDA 80
 #define LG_LDB 144
-#define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)  // sized for fp64; the fp32 kernels use half of it
+#define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)  // k_leg_inv, 8-row stages; sized for fp64 (fp32 uses half)
+#define LG_LDS_BYTES_DIR (2 * LG_LDS_BYTES)                  // k_leg_dir, 16-row stages (+ its row-number tables)
 #define FFT_MAXR 16
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
