@@ -703,7 +703,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   g.gpoff = d_gpoff;
   g.nasm0 = d_nasm0;
   g.fbase = d_fbase;
-  g.fftrow = d_fftrow;
+  g.fftrow = NP == 1 ? nullptr : d_fftrow;  // one task: rows are fbase[lat] + m, no table
   g.lbase = d_lbase;
   g.legN = d_legN;
   g.legS = d_legS;

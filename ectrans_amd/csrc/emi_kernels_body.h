@@ -736,6 +736,7 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
   for (int fl = 0; fl < nfl; fl++) {
     real2 *af = a + (long long)fl * fs;
     const GridRow gr = grid_row(flds[f0 + fl], gp0, nproma);
+    const bool flat = (gr.rem0 + (unsigned)pl.n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
       int blk, j;
       split_q(q, lenp, sh, blk, j);  // last pass: len == S, blk == 0
@@ -763,7 +764,9 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
           real2 z = v[t];
           if (pl.blue) z = cscale(cmulc(z, ch[t]), invL);
           if (!pl.cmode) {
-            if (grid_pair_ok(gr, 2u * i)) {
+            if (flat) {  // whole row inside one NPROMA block and 2-element aligned (uniform)
+              *(real2 *)(gr.p0 + gr.rem0 + 2u * i) = z;
+            } else if (grid_pair_ok(gr, 2u * i)) {
               *(real2 *)grid_ptr(gr, 2u * i) = z;
             } else {
               *grid_ptr(gr, 2u * i) = z.x;
@@ -806,7 +809,11 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
   const int fs = FFT_LDS_ELEMS(S);
   const real_t racthe = (real_t)g.racthe[lat];
-  const int *frow = g.fftrow + g.fbase[lat];  // frow[k]: row of (lat, m=k) in the FFT-side buffer
+  // row of (lat, m=k) in the FFT-side buffer: affine for one task (no table load in front of the
+  // data load), through the exchange-order table otherwise
+  const int fb0 = g.fbase[lat];
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
+#define FROW(k_) (frow ? frow[k_] : fb0 + (k_))
   const real2 *tw = (const real2 *)T.tw + pl.tw_off;
   const unsigned short *perm = T.perm + pl.perm_off;
   const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
@@ -820,8 +827,8 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
       const int npair = sz / 2 + 1;  // k = 0..sz/2 pairs with sz-k
       for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
         const int k2 = sz - k;
-        real2 xa = (k <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
-        real2 xb = (k2 <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, frow[k2], ldf, gf, k2, racthe) : mk2(0, 0);
+        real2 xa = (k <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
+        real2 xb = (k2 <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
         // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
         real2 wk = cconj(rtw[k]);
         real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
@@ -839,10 +846,10 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
       for (int k = EMI_TID; k < sz; k += EMI_NTHREADS) {
         real2 z;
         if (2 * k <= n) {
-          z = (k <= nmen) ? fsc_load(FB, frow[k], ldf, gf, k, racthe) : mk2(0, 0);
+          z = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
           if (k == 0) z.y = 0.0;
         } else {
-          z = (n - k <= nmen) ? cconj(fsc_load(FB, frow[n - k], ldf, gf, n - k, racthe)) : mk2(0, 0);
+          z = (n - k <= nmen) ? cconj(fsc_load(FB, FROW(n - k), ldf, gf, n - k, racthe)) : mk2(0, 0);
         }
         af[FPAD(pl.blue ? k : (int)perm[k])] = pl.blue ? cmulc(z, chirp[k]) : z;
       }
@@ -907,7 +914,8 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
   const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
   const int fs = FFT_LDS_ELEMS(S);
-  const int *frow = g.fftrow + g.fbase[lat];
+  const int fb0 = g.fbase[lat];
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
   const long long gp0 = g.gpoff[lat];
   const real2 *tw = (const real2 *)T.tw + pl.tw_off;
   const unsigned short *perm = T.perm + pl.perm_off;
@@ -919,10 +927,13 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
     const GridFld gf = flds[f0 + fl];
     real2 *af = a + (long long)fl * fs;
     const GridRow gr = grid_row(gf, gp0, nproma);
+    const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
     for (int lz = EMI_TID; lz < sz; lz += EMI_NTHREADS) {
       real2 z;
       if (!pl.cmode) {
-        if (grid_pair_ok(gr, 2u * lz)) {
+        if (flat) {
+          z = *(const real2 *)(gr.p0 + gr.rem0 + 2u * lz);
+        } else if (grid_pair_ok(gr, 2u * lz)) {
           z = *(const real2 *)grid_ptr(gr, 2u * lz);
         } else {
           z.x = *grid_ptr(gr, 2u * lz);
@@ -964,7 +975,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
         x = af[FPAD(k)];
         if (pl.blue) x = cscale(cmul(x, chirp[k]), invL);
       }
-      *(real2 *)(FB + (long long)frow[k] * ldf + 2 * (f0 + fl)) = cscale(x, sc);
+      *(real2 *)(FB + (long long)FROW(k) * ldf + 2 * (f0 + fl)) = cscale(x, sc);
     }
   }
 }
@@ -990,4 +1001,5 @@ EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, long long nspec2, const real_t 
   if (EMI_TID == 0) out[f] = red[0];  // sum of squares; the host takes the root (after the task sum)
 }
 
+#undef FROW
 #undef emi_mfma_f64_16x16x4

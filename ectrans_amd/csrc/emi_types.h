@@ -15,7 +15,7 @@ struct EmiGeomDev {
   const int *nmen, *gpoff;  // [nlat]
   const int *nasm0;   // [nump] 0-based index of Re(m, n=m) in the (local) user spectral dimension
   const int *fbase;   // [nlat+1]  Fourier rows (lat, m<=NMEN) before the local latitude
-  const int *fftrow;  // [fbase[nlat]] row of (lat, m) in the FFT-side Fourier buffer
+  const int *fftrow;  // [fbase[nlat]] row of (lat, m) in the FFT-side Fourier buffer; NULL: one task, row = fbase[lat] + m
   const int *lbase;   // [nump+1] start of wavenumber ml in legN/legS
   const int *legN, *legS;  // row of (ml, j-th northern latitude with m<=NMEN) / its southern mirror
                            // in the Legendre-side Fourier buffer
