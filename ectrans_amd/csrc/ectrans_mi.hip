@@ -112,8 +112,9 @@ static int upload(const std::vector<T> &h, T **d) {
 // ------------------------------------------------------------------------------------------
 // per-resolution plan
 // ------------------------------------------------------------------------------------------
-struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a workgroup size and fields per workgroup
+struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a workgroup size, fields per workgroup and kernel
   int nthr = 0, fbk = 0;
+  int hot = 0;  // > 0: specialised kernel k_fft_*_hot<hot> (EMI_HOT_PLAN_LIST)
   std::vector<int> lats;
   int *d_lats = nullptr;
   size_t lds = 0;
@@ -328,14 +329,29 @@ static int build_fft_plans(Plan &P) {
       }
     }
     if (ft && atoi(ft) >= 64) nthr = std::min(1024, roundup(atoi(ft), 64));
+    // specialised kernel for this work length?  (Bluestein, even NLOEN, one field per workgroup)
+    int hot = 0;
+    if (pl.blue && !pl.cmode && fbk == 1 && !getenv("EMI_FFT_NO_HOT")) {
+      static const int hp[][8] = {
+#define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_) {pc_, S_, nf_, a_, b_, c_, d_, e_},
+          EMI_HOT_PLAN_LIST(EMI_HOT_ROW)
+#undef EMI_HOT_ROW
+      };
+      for (const auto &r : hp) {
+        bool same = r[1] == pl.S && r[2] == pl.nfac;
+        for (int i = 0; same && i < pl.nfac; i++) same = r[3 + i] == pl.fac[i];
+        if (same) hot = r[0];
+      }
+    }
     int cls = -1;
     for (size_t c = 0; c < P.fclass.size(); c++)
-      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk) cls = (int)c;
+      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot) cls = (int)c;
     if (cls < 0) {
       cls = (int)P.fclass.size();
       P.fclass.emplace_back();
       P.fclass[cls].nthr = nthr;
       P.fclass[cls].fbk = fbk;
+      P.fclass[cls].hot = hot;
     }
     pl.lds_class = cls;
     int id = (int)P.fplans.size();
@@ -1126,10 +1142,22 @@ static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, c
     const long long nblocks = (long long)fc.lats.size() * nchunk;
     FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, fft_dbg};
     const int nthr = fc.nthr;
-    if (inverse)
-      EMI_LAUNCH_P(P.esz, k_fft_inv, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);
-    else
-      EMI_LAUNCH_P(P.esz, k_fft_dir, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
+    switch (fc.hot) {
+#define EMI_HOT_LAUNCH(pc_, S_, nf_, a_, b_, c_, d_, e_)                                                                                       \
+  case pc_:                                                                                                                                    \
+    if (inverse)                                                                                                                               \
+      EMI_LAUNCH_P(P.esz, k_fft_inv_hot<pc_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);         \
+    else                                                                                                                                       \
+      EMI_LAUNCH_P(P.esz, k_fft_dir_hot<pc_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);               \
+    break;
+      EMI_HOT_PLAN_LIST(EMI_HOT_LAUNCH)
+#undef EMI_HOT_LAUNCH
+      default:
+        if (inverse)
+          EMI_LAUNCH_P(P.esz, k_fft_inv, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);
+        else
+          EMI_LAUNCH_P(P.esz, k_fft_dir, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
+    }
   }
 }
 
@@ -1210,6 +1238,13 @@ static int set_lds_attrs() {
   if (done) return 0;
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_leg_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_leg_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+#define EMI_HOT_ATTR(pc_, S_, nf_, a_, b_, c_, d_, e_)                                                                                  \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv_hot<pc_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir_hot<pc_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv_hot<pc_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_hot<pc_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_HOT_PLAN_LIST(EMI_HOT_ATTR)
+#undef EMI_HOT_ATTR
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -981,6 +981,163 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
 }
 
 // ==========================================================================================
+// Specialised FFT kernels for the work lengths that carry an octahedral grid (93 % of its
+// rows, by weight, are Bluestein rows; at TCo1279 all of the long ones use one of six lengths):
+// Bluestein, even NLOEN, one field per workgroup, factor list known at compile time.  Same
+// arithmetic, pass for pass, as the generic kernels above (results agree to fma-contraction
+// rounding, tests/test_gpu_parity.py); what changes is that the pass sequence is straight-line code with constant strides -- no radix
+// dispatch, no plan loops, a fraction of the scalar registers -- so nothing spills.
+// ==========================================================================================
+struct HotPlanC {
+  int S, nfac, fac[5];
+};
+EMI_DEVFN constexpr HotPlanC hot_plan(int pc) {
+  switch (pc) {
+#define EMI_HOT_CASE(pc_, S_, nf_, a_, b_, c_, d_, e_) \
+  case pc_: return {S_, nf_, {a_, b_, c_, d_, e_}};
+    EMI_HOT_PLAN_LIST(EMI_HOT_CASE)
+#undef EMI_HOT_CASE
+    default: return {0, 0, {1, 1, 1, 1, 1}};
+  }
+}
+EMI_DEVFN constexpr int hot_lenp(int pc, int ip) {  // stride of factor ip = product of the factors before it
+  int l = 1;
+  for (int i = 0; i < ip; i++) l *= hot_plan(pc).fac[i];
+  return l;
+}
+
+// forward Bluestein chain on one field: DIF passes nfac-1..1, fused middle, DIT passes 1..last-1
+template <int PC, int LASTDIT>
+EMI_DEVFN void hot_conv(real2 *a, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid) {
+  constexpr HotPlanC H = hot_plan(PC);
+  const real2 *tw = (const real2 *)T.tw + pl.tw_off, *bh = (const real2 *)T.bhat + pl.bhat_off;
+  const real2 *ptw = (const real2 *)T.ptw;
+  if constexpr (H.nfac == 5) {
+    fft_pass_body<H.fac[4], 1, 1, 1>(a, 1, fs, H.S, hot_lenp(PC, 4), tw, ptw + pl.ptw_off[4], -1, nvalid);
+    EMI_SYNC();
+    fft_pass_body<H.fac[3], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], -1, H.S);
+  } else {
+    fft_pass_body<H.fac[3], 1, 1, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], -1, nvalid);
+  }
+  EMI_SYNC();
+  fft_pass_body<H.fac[2], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 2), tw, ptw + pl.ptw_off[2], -1, H.S);
+  EMI_SYNC();
+  fft_pass_body<H.fac[1], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 1), tw, ptw + pl.ptw_off[1], -1, H.S);
+  EMI_SYNC();
+  blue_middle<H.fac[0]>(a, 1, fs, H.S, tw, bh, conj_b, H.S);
+  EMI_SYNC();
+  fft_pass_body<H.fac[1], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 1), tw, ptw + pl.ptw_off[1], +1, H.S);
+  EMI_SYNC();
+  fft_pass_body<H.fac[2], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 2), tw, ptw + pl.ptw_off[2], +1, H.S);
+  EMI_SYNC();
+  if constexpr (H.nfac == 5 || LASTDIT) {
+    fft_pass_body<H.fac[3], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], +1, H.S);
+    EMI_SYNC();
+  }
+  if constexpr (H.nfac == 5 && LASTDIT) {
+    fft_pass_body<H.fac[4], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 4), tw, ptw + pl.ptw_off[4], +1, H.S);
+    EMI_SYNC();
+  }
+}
+
+template <int PC>
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+                                  int ldf, int nproma) {
+  constexpr HotPlanC H = hot_plan(PC);
+  EMI_LDS_DECL;
+  real2 *a = (real2 *)EMI_LDS_PTR;
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = bid / Lc.nchunk;
+  const int lat = Lc.lats[li];
+  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const int f0 = bid - li * Lc.nchunk;  // one field per workgroup
+  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
+  constexpr int fs = FFT_LDS_ELEMS(H.S);
+  const real_t racthe = (real_t)g.racthe[lat];
+  const int fb0 = g.fbase[lat];
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
+  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
+  const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
+  const GridFld gf = flds[f0];
+  // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times the chirp
+  {
+    const int npair = sz / 2 + 1;
+    for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
+      const int k2 = sz - k;
+      real2 xa = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
+      real2 xb = (k2 <= nmen) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
+      real2 wk = cconj(rtw[k]);
+      real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
+      real2 zk = cadd(s1, cmuli(cmul(wk, d1)));
+      a[FPAD(k)] = cmulc(zk, chirp[k]);
+      if (k2 != k && k2 < sz) {
+        real2 s2 = cadd(xb, cconj(xa)), d2_ = csub(xb, cconj(xa));
+        real2 zk2 = cadd(s2, cmuli(cmul(mk2(-wk.x, wk.y), d2_)));
+        a[FPAD(k2)] = cmulc(zk2, chirp[k2]);
+      }
+    }
+  }
+  EMI_SYNC();
+  hot_conv<PC, 0>(a, fs, pl, T, 1, sz);
+  constexpr int last = H.nfac - 1;
+  dit_last_to_grid<H.fac[last]>(a, 1, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
+                                (const real2 *)T.ptw + pl.ptw_off[last], pl, chirp, flds, f0, g.gpoff[lat], nproma);
+  (void)n;
+}
+
+template <int PC>
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+                                  int nproma) {
+  constexpr HotPlanC H = hot_plan(PC);
+  EMI_LDS_DECL;
+  real2 *a = (real2 *)EMI_LDS_PTR;
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = bid / Lc.nchunk;
+  const int lat = Lc.lats[li];
+  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const int f0 = bid - li * Lc.nchunk;
+  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
+  constexpr int fs = FFT_LDS_ELEMS(H.S);
+  const int fb0 = g.fbase[lat];
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
+  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
+  const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
+  const GridFld gf = flds[f0];
+  // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp
+  {
+    const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
+    const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
+    for (int lz = EMI_TID; lz < sz; lz += EMI_NTHREADS) {
+      real2 z;
+      if (flat) {
+        z = *(const real2 *)(gr.p0 + gr.rem0 + 2u * lz);
+      } else if (grid_pair_ok(gr, 2u * lz)) {
+        z = *(const real2 *)grid_ptr(gr, 2u * lz);
+      } else {
+        z.x = *grid_ptr(gr, 2u * lz);
+        z.y = *grid_ptr(gr, 2u * lz + 1);
+      }
+      a[FPAD(lz)] = cmul(z, chirp[lz]);
+    }
+  }
+  EMI_SYNC();
+  hot_conv<PC, 1>(a, fs, pl, T, 0, sz);
+  // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
+  const real_t invL = (real_t)(1.0 / (double)H.S);
+  const real_t sc = (real_t)(g.rw[lat] / (double)n) * ((gf.mode == GM_ACOS) ? (real_t)g.racthe[lat] : (real_t)1.0);
+  for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
+    const int kb = (k == 0) ? 0 : sz - k;
+    real2 za = a[FPAD(k)], zb = a[FPAD(kb)];
+    za = cscale(cmul(za, chirp[k]), invL);
+    zb = cscale(cmul(zb, chirp[kb]), invL);
+    real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
+    real2 t = cmuli(cmul(rtw[k], d1));
+    real2 x = mk2((real_t)0.5 * (s1.x - t.x), (real_t)0.5 * (s1.y - t.y));
+    *(real2 *)(FB + (long long)FROW(k) * ldf + 2 * f0) = cscale(x, sc);
+  }
+}
+
+// ==========================================================================================
 // k_specnorm: SPNORMD (spnormd_mod.F90:40-57).  One block per field; deterministic order.
 // ==========================================================================================
 EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, long long nspec2, const real_t *sp, int stride, double *out) {

@@ -100,3 +100,15 @@ struct FftLaunchDev {
 #define FFT_MAXR 16
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
+
+// Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors...).  The factor
+// lists are what emi::factorize_smooth yields for S (checked when a plan is matched).
+#define EMI_HOT_PLAN_LIST(X)      \
+  X(1, 2048, 4, 8, 8, 8, 4, 1)    \
+  X(2, 2560, 4, 8, 8, 8, 5, 1)    \
+  X(3, 3072, 5, 8, 8, 8, 2, 3)    \
+  X(4, 4096, 4, 8, 8, 8, 8, 1)    \
+  X(5, 4608, 5, 8, 8, 8, 3, 3)    \
+  X(6, 5120, 5, 8, 8, 8, 2, 5)    \
+  X(7, 1536, 4, 8, 8, 8, 3, 1)    \
+  X(8, 1280, 4, 8, 8, 4, 5, 1)

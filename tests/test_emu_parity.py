@@ -56,6 +56,19 @@ def test_emulated_fp32_library_matches_oracle(et, name):
     assert e_inv > 1e-9  # really computed in float
 
 
+HOT_A = [1028, 1284, 1540, 2052, 2564, 3076, 4100, 4612]  # first row length of every specialised Bluestein work length
+HOT_B = [1276, 1532, 2044, 2556, 3068, 4092, 4604, 5116]  # ... and the last one
+
+
+@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4)])
+def test_specialised_fft_kernels_match_oracle(et, half, precision):
+    """k_fft_inv_hot / k_fft_dir_hot (work lengths 1280 ... 5120, the rows that carry TCo1279): a
+    16-latitude grid whose rows select each of them, against the oracle."""
+    e_inv, e_dir = run_case(et, Oracle, XP, 15, half + half[::-1], 1, 1, dict(scders=True), None, precision=precision)
+    tol = TOL if precision == 8 else 2e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
 def test_fp32_library_rejects_double_arrays(et):
     nloen = octahedral(7)
     r = et.setup_trans(7, len(nloen), nloen, precision=4)

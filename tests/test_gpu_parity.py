@@ -107,6 +107,44 @@ def test_fp32_library_matches_oracle(et, dev, name):
     assert e_inv < 3e-5 and e_dir < 3e-5, (e_inv, e_dir)
 
 
+HOT_A = [1028, 1284, 1540, 2052, 2564, 3076, 4100, 4612]  # first row length of every specialised Bluestein work length
+HOT_B = [1276, 1532, 2044, 2556, 3068, 4092, 4604, 5116]  # ... and the last one
+
+
+@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4), (HOT_B, 4)])
+def test_specialised_fft_kernels_match_oracle(et, dev, half, precision):
+    """k_fft_inv_hot / k_fft_dir_hot (the Bluestein work lengths 1280 ... 5120 that carry TCo1279): a
+    16-latitude grid whose rows select each of them, against the oracle."""
+    from oracle.oracle import Oracle as O
+    e_inv, e_dir = run_case(et, O, dev, 15, half + half[::-1], 2, 3, dict(scders=True, uvder=True), None, precision=precision)
+    tol = TOL if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
+    """The specialised kernels run the same passes in the same order; only the compiler's fma
+    contraction may differ: agreement to a few ulp."""
+    to, back = dev
+    nloen = np.array(HOT_A + HOT_A[::-1], dtype=np.int32)
+    rng = np.random.default_rng(5)
+    outs = []
+    for no_hot in (False, True):
+        if no_hot:
+            monkeypatch.setenv("EMI_FFT_NO_HOT", "1")
+        r = et.setup_trans(15, len(nloen), nloen)
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        if not outs:
+            sp = random_spectrum(rng, et.trans_inq(r, "nasm0"), 15, ns2, 3, False)
+        gp = to(np.zeros((1, 3, ng)))
+        et.inv_trans(r, pspscalar=to(sp), pgp=gp)
+        s2 = to(np.zeros((ns2, 3)))
+        et.dir_trans(r, pspscalar=s2, pgp=gp)
+        outs.append((back(gp).copy(), back(s2).copy()))
+        et.trans_release(r)
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-14 and rel_err(outs[0][1], outs[1][1]) < 1e-14
+    assert not np.array_equal(outs[0][0], np.zeros_like(outs[0][0]))
+
+
 def test_host_arrays_match_oracle(et):
     """EMI_MEM_HOST: numpy arrays staged over PCIe, as a Fortran/C caller would pass them."""
     from oracle.oracle import Oracle as O
