@@ -101,7 +101,8 @@ struct FftLaunchDev {
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 
-// Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors...).  The factor
+// Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors...); 1-8 carry
+// TCo1279, 9-12 the longer rows of TCo2559 (fp32: up to 10240 points fit the LDS).  The factor
 // lists are what emi::factorize_smooth yields for S (checked when a plan is matched).
 #define EMI_HOT_PLAN_LIST(X)      \
   X(1, 2048, 4, 8, 8, 8, 4, 1)    \
@@ -111,4 +112,8 @@ struct FftLaunchDev {
   X(5, 4608, 5, 8, 8, 8, 3, 3)    \
   X(6, 5120, 5, 8, 8, 8, 2, 5)    \
   X(7, 1536, 4, 8, 8, 8, 3, 1)    \
-  X(8, 1280, 4, 8, 8, 4, 5, 1)
+  X(8, 1280, 4, 8, 8, 4, 5, 1)    \
+  X(9, 6144, 5, 8, 8, 8, 4, 3)    \
+  X(10, 7680, 5, 8, 8, 8, 3, 5)   \
+  X(11, 8192, 5, 8, 8, 8, 8, 2)   \
+  X(12, 10240, 5, 8, 8, 8, 4, 5)

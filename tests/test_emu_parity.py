@@ -60,7 +60,10 @@ HOT_A = [1028, 1284, 1540, 2052, 2564, 3076, 4100, 4612]  # first row length of 
 HOT_B = [1276, 1532, 2044, 2556, 3068, 4092, 4604, 5116]  # ... and the last one
 
 
-@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4)])
+HOT_C = [5124, 6140, 6148, 7676, 7684, 8188, 8196, 10236]  # TCo2559 rows: work lengths 6144 ... 10240
+
+
+@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4), (HOT_C, 4)])
 def test_specialised_fft_kernels_match_oracle(et, half, precision):
     """k_fft_inv_hot / k_fft_dir_hot (work lengths 1280 ... 5120, the rows that carry TCo1279): a
     16-latitude grid whose rows select each of them, against the oracle."""
