@@ -327,6 +327,125 @@ def specnorm(kresol, pspec):
     return np.sqrt(_dist.all_reduce_sum(out, _DIST["group"], _DIST["device"]))  # every task gets the norms
 
 
+# ---------------------------------------------------------------------------------------------
+# DIST_SPEC / GATH_SPEC / DIST_GRID / GATH_GRID: global <-> distributed arrays.
+# Not on the transform hot path: host (numpy) arrays, moved with torch.distributed collectives.
+# Global spectral order (dist_spec_control_mod.F90:158-161, IASM0G): m = 0..N, n = m..N, (re, im).
+# Global grid order: latitudes north to south = the tasks' latitude bands in task order.
+# ---------------------------------------------------------------------------------------------
+def _np(a):
+    return a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a)
+
+
+def _global_spec_index(kresol):
+    """indices into the global spectral array of this task's coefficients, in local order"""
+    n, myms = trans_inq(kresol, "nsmax"), trans_inq(kresol, "myms")
+    iasm0g = np.concatenate([[0], np.cumsum([2 * (n - m + 1) for m in range(n + 1)])])
+    return np.concatenate([np.arange(iasm0g[m], iasm0g[m] + 2 * (n - m + 1)) for m in myms]) if len(myms) else \
+        np.zeros(0, dtype=np.int64)
+
+
+def _roots(k, nfld, what):
+    k = np.broadcast_to(np.asarray(k, dtype=np.int64), (nfld,)) if np.ndim(k) <= 1 else None
+    if k is None or k.min() < 1 or k.max() > _DIST["nproc"]:
+        raise TransError("%s: task numbers must be 1..%d" % (what, _DIST["nproc"]))
+    return k
+
+
+def dist_spec(kresol, pspecg, kfdistg, kfrom=1):
+    """DIST_SPEC (dist_spec.h:11): global spectral fields `pspecg` (nspec2g, kfdistg), field f held by
+    task kfrom[f] (1-based; None elsewhere), -> this task's (nspec2, kfdistg) local array."""
+    dt = real_dtype(kresol)
+    ns2g = trans_inq(kresol, "nspec2g")
+    kfrom = _roots(kfrom, kfdistg, "DIST_SPEC:KFROM")
+    idx = _global_spec_index(kresol)
+    out = np.zeros((idx.size, kfdistg), dtype=dt)
+    me = trans_inq(kresol, "myproc")
+    for root in np.unique(kfrom):
+        f = np.flatnonzero(kfrom == root)
+        if _DIST["nproc"] == 1:
+            g = _np(pspecg)[:, f]
+        else:
+            from . import dist as _dist
+            src = np.ascontiguousarray(_np(pspecg)[:, f]) if me == root else None
+            if me == root and src.shape[0] != ns2g:
+                raise TransError("DIST_SPEC: PSPECG must have shape (nspec2g=%d, nfld)" % ns2g)
+            g = _dist.broadcast_from(src, (ns2g, f.size), np.dtype(dt), int(root) - 1, _DIST["group"], _DIST["device"])
+        out[:, f] = g[idx]
+    return out
+
+
+def gath_spec(kresol, pspec, kfgathg, kto=1):
+    """GATH_SPEC (gath_spec.h:11): local (nspec2, kfgathg) -> global (nspec2g, kfgathg) on task kto[f]
+    (returned array holds the fields this task is the target of; None if it is the target of none)."""
+    dt = real_dtype(kresol)
+    ns2g, me = trans_inq(kresol, "nspec2g"), trans_inq(kresol, "myproc")
+    kto = _roots(kto, kfgathg, "GATH_SPEC:KTO")
+    loc = np.ascontiguousarray(_np(pspec), dtype=dt)
+    full = np.zeros((ns2g, kfgathg), dtype=dt)
+    if _DIST["nproc"] == 1:
+        full[_global_spec_index(kresol)] = loc
+        return full
+    from . import dist as _dist
+    nmx = trans_inq(kresol, "nspec2mx")
+    idxs = _dist.all_gather_padded(_global_spec_index(kresol)[:, None].astype(np.int64), nmx, _DIST["group"], _DIST["device"])
+    cnts = _dist.all_gather_padded(np.array([[loc.shape[0]]], dtype=np.int64), 1, _DIST["group"], _DIST["device"])
+    parts = _dist.all_gather_padded(loc, nmx, _DIST["group"], _DIST["device"])
+    for i, (ix, c, p) in enumerate(zip(idxs, cnts, parts)):
+        c = int(c[0, 0])
+        full[ix[:c, 0]] = p[:c]
+    mine = np.flatnonzero(kto == me)
+    return full if mine.size == kfgathg else (full[:, mine] if mine.size else None)
+
+
+def gath_grid(kresol, pgp, kfgathg, kto=1):
+    """GATH_GRID (gath_grid.h:11): local blocked grid array (ngpblks, kfgathg, nproma) -> global
+    (kfgathg, ngptotg) on task kto[f]."""
+    dt = real_dtype(kresol)
+    ngl, ngg, me = trans_inq(kresol, "ngptot"), trans_inq(kresol, "ngptotg"), trans_inq(kresol, "myproc")
+    kto = _roots(kto, kfgathg, "GATH_GRID:KTO")
+    a = _np(pgp)
+    loc = np.ascontiguousarray(np.concatenate([a[b] for b in range(a.shape[0])], axis=1)[:, :ngl].T, dtype=dt)  # (ngptot, nfld)
+    if _DIST["nproc"] == 1:
+        return np.ascontiguousarray(loc.T)
+    from . import dist as _dist
+    nmx = trans_inq(kresol, "ngptotmx")
+    cnts = _dist.all_gather_padded(np.array([[ngl]], dtype=np.int64), 1, _DIST["group"], _DIST["device"])
+    parts = _dist.all_gather_padded(loc, nmx, _DIST["group"], _DIST["device"])
+    full = np.concatenate([p[:int(c[0, 0])] for p, c in zip(parts, cnts)], axis=0)
+    if full.shape[0] != ngg:
+        raise TransError("GATH_GRID: gathered %d points, expected %d" % (full.shape[0], ngg))
+    mine = np.flatnonzero(kto == me)
+    return np.ascontiguousarray(full.T) if mine.size == kfgathg else (np.ascontiguousarray(full[:, mine].T) if mine.size else None)
+
+
+def dist_grid(kresol, pgpg, kfdistg, kfrom=1, kproma=None):
+    """DIST_GRID (dist_grid.h:11): global (kfdistg, ngptotg) on task kfrom[f] -> this task's blocked
+    (ngpblks, kfdistg, nproma) array."""
+    dt = real_dtype(kresol)
+    ngl, ngg, me = trans_inq(kresol, "ngptot"), trans_inq(kresol, "ngptotg"), trans_inq(kresol, "myproc")
+    kfrom = _roots(kfrom, kfdistg, "DIST_GRID:KFROM")
+    nloen, lat0 = trans_inq(kresol, "nloen"), trans_inq(kresol, "nfrstlat") - 1
+    gp0 = int(nloen[:lat0].sum())
+    loc = np.zeros((kfdistg, ngl), dtype=dt)
+    for root in np.unique(kfrom):
+        f = np.flatnonzero(kfrom == root)
+        if _DIST["nproc"] == 1:
+            g = _np(pgpg)[f]
+        else:
+            from . import dist as _dist
+            src = np.ascontiguousarray(_np(pgpg)[f]) if me == root else None
+            g = _dist.broadcast_from(src, (f.size, ngg), np.dtype(dt), int(root) - 1, _DIST["group"], _DIST["device"])
+        loc[f] = g[:, gp0:gp0 + ngl]
+    nproma = int(kproma) if kproma else ngl
+    nb = (ngl - 1) // nproma + 1
+    out = np.zeros((nb, kfdistg, nproma), dtype=dt)
+    for b in range(nb):
+        w = min(nproma, ngl - b * nproma)
+        out[b, :, :w] = loc[:, b * nproma:b * nproma + w]
+    return out
+
+
 def trans_release(kresol):
     _chk(lib().emi_release(kresol))
 

@@ -89,3 +89,37 @@ def all_reduce_sum(values, group=None, device=None):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
+
+
+def _comm_tensor(a, group, device):
+    """numpy array -> tensor the group's backend can move (CUDA for RCCL, host otherwise)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if device is not None and torch.device(device).type == "cuda" and dist.get_backend(group) != "gloo":
+        t = t.to(device)
+    return t
+
+
+def broadcast_from(a, shape, dtype, src, group=None, device=None):
+    """Task `src` (0-based) holds numpy array `a`; every task returns a copy (DIST_* helpers)."""
+    import torch.distributed as dist
+    buf = np.ascontiguousarray(a, dtype=dtype) if dist.get_rank(group) == src else np.empty(shape, dtype=dtype)
+    if tuple(buf.shape) != tuple(shape):
+        raise ValueError("broadcast_from: array of shape %s, expected %s" % (buf.shape, tuple(shape)))
+    t = _comm_tensor(buf, group, device)
+    dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return t.cpu().numpy()
+
+
+def all_gather_padded(a, nmax, group=None, device=None):
+    """Every task contributes a (n_i, ...) numpy array with n_i <= nmax; returns the list of the
+    tasks' arrays padded to nmax rows (GATH_* helpers: pieces differ in length)."""
+    import torch
+    import torch.distributed as dist
+    pad = np.zeros((nmax,) + a.shape[1:], dtype=a.dtype)
+    pad[:a.shape[0]] = a
+    t = _comm_tensor(pad, group, device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [o.cpu().numpy() for o in out]

@@ -153,7 +153,7 @@ int trans_dirtrans(struct DirTrans_t *d) {
   if (!d->trans || !d->rgp) return TRANS_MISSING_ARG;
   if (d->nscalar > 0 && !d->rspscalar) return TRANS_MISSING_ARG;
   if (d->nvordiv > 0 && (!d->rspvor || !d->rspdiv)) return TRANS_MISSING_ARG;
-  if (d->lglobal || d->rmeanu || d->rmeanv) return TRANS_NOTIMPL;
+  if (d->rmeanu || d->rmeanv) return TRANS_NOTIMPL; /* LAM only */
   emi_dirtrans_t a;
   memset(&a, 0, sizeof(a));
   a.mem_space = EMI_MEM_HOST;
@@ -166,7 +166,9 @@ int trans_dirtrans(struct DirTrans_t *d) {
     a.spscalar = d->rspscalar;
     a.nf_scalar = d->nscalar;
   }
-  a.kproma = d->nproma > 0 ? d->nproma : d->trans->ngptot;
+  /* lglobal: rgp is the global field [nfld][ngptotg] (transi_module.F90:1721-1728); this layer drives
+   * one task, so global == local and the call is the unblocked one */
+  a.kproma = (d->nproma > 0 && !d->lglobal) ? d->nproma : d->trans->ngptot;
   a.gp = d->rgp;
   a.gp_nfld = 2 * d->nvordiv + d->nscalar;
   return emi_dir_trans(d->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
@@ -184,7 +186,7 @@ int trans_invtrans(struct InvTrans_t *v) {
   if (!v->trans || !v->rgp) return TRANS_MISSING_ARG;
   if (v->nscalar > 0 && !v->rspscalar) return TRANS_MISSING_ARG;
   if (v->nvordiv > 0 && (!v->rspvor || !v->rspdiv)) return TRANS_MISSING_ARG;
-  if (v->lglobal || v->rmeanu || v->rmeanv) return TRANS_NOTIMPL;
+  if (v->rmeanu || v->rmeanv) return TRANS_NOTIMPL; /* LAM only */
   emi_invtrans_t a;
   memset(&a, 0, sizeof(a));
   a.mem_space = EMI_MEM_HOST;
@@ -200,11 +202,83 @@ int trans_invtrans(struct InvTrans_t *v) {
   a.ldscders = v->lscalarders;
   a.lduvder = v->luvder_EW;
   a.ldvorgp = a.lddivgp = v->lvordivgp;
-  a.kproma = v->nproma > 0 ? v->nproma : v->trans->ngptot;
+  a.kproma = (v->nproma > 0 && !v->lglobal) ? v->nproma : v->trans->ngptot; /* lglobal: as trans_dirtrans */
   a.gp = v->rgp;
   a.gp_nfld = 2 * v->nvordiv + v->nscalar + (v->lscalarders ? 2 * v->nscalar : 0) + (v->lvordivgp ? 2 * v->nvordiv : 0) +
               (v->luvder_EW ? 2 * v->nvordiv : 0);
   return emi_inv_trans(v->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+
+/* ---- global <-> distributed arrays (one task: re-layouts) ---- */
+static int only_task_one(const int *v, int n) {
+  for (int i = 0; v && i < n; i++)
+    if (v[i] != 1) return 0;
+  return 1;
+}
+struct DistGrid_t new_distgrid(struct Trans_t *t) {
+  struct DistGrid_t a;
+  memset(&a, 0, sizeof(a));
+  a.trans = t;
+  a.nproma = t->ngptot;
+  a.ngpblks = 1;
+  return a;
+}
+struct GathGrid_t new_gathgrid(struct Trans_t *t) {
+  struct GathGrid_t a;
+  memset(&a, 0, sizeof(a));
+  a.trans = t;
+  a.nproma = t->ngptot;
+  a.ngpblks = 1;
+  return a;
+}
+struct DistSpec_t new_distspec(struct Trans_t *t) {
+  struct DistSpec_t a;
+  memset(&a, 0, sizeof(a));
+  a.trans = t;
+  return a;
+}
+struct GathSpec_t new_gathspec(struct Trans_t *t) {
+  struct GathSpec_t a;
+  memset(&a, 0, sizeof(a));
+  a.trans = t;
+  return a;
+}
+int trans_distgrid(struct DistGrid_t *a) {
+  if (a->count++ > 0) return TRANS_STALE_ARG;
+  if (!a->trans || !a->rgpg || !a->rgp || a->nfld <= 0 || a->nproma <= 0) return TRANS_MISSING_ARG;
+  if (!only_task_one(a->nfrom, a->nfld)) return TRANS_ERROR;
+  const long ng = a->trans->ngptot, np = a->nproma, nb = (ng - 1) / np + 1;
+  if (a->ngpblks < nb) return TRANS_ERROR;
+  for (long b = 0; b < nb; b++)
+    for (long f = 0; f < a->nfld; f++)
+      for (long i = 0; i < np; i++) {
+        long p = b * np + i;
+        a->rgp[(b * a->nfld + f) * np + i] = p < ng ? a->rgpg[f * ng + p] : 0.0;
+      }
+  return TRANS_SUCCESS;
+}
+int trans_gathgrid(struct GathGrid_t *a) {
+  if (a->count++ > 0) return TRANS_STALE_ARG;
+  if (!a->trans || !a->rgpg || !a->rgp || a->nfld <= 0 || a->nproma <= 0) return TRANS_MISSING_ARG;
+  if (!only_task_one(a->nto, a->nfld)) return TRANS_ERROR;
+  const long ng = a->trans->ngptot, np = a->nproma;
+  for (long f = 0; f < a->nfld; f++)
+    for (long p = 0; p < ng; p++) a->rgpg[f * ng + p] = a->rgp[((p / np) * a->nfld + f) * np + p % np];
+  return TRANS_SUCCESS;
+}
+int trans_distspec(struct DistSpec_t *a) {
+  if (a->count++ > 0) return TRANS_STALE_ARG;
+  if (!a->trans || !a->rspecg || !a->rspec || a->nfld <= 0) return TRANS_MISSING_ARG;
+  if (!only_task_one(a->nfrom, a->nfld)) return TRANS_ERROR;
+  memcpy(a->rspec, a->rspecg, sizeof(double) * (size_t)a->trans->nspec2 * (size_t)a->nfld); /* local order == global order */
+  return TRANS_SUCCESS;
+}
+int trans_gathspec(struct GathSpec_t *a) {
+  if (a->count++ > 0) return TRANS_STALE_ARG;
+  if (!a->trans || !a->rspecg || !a->rspec || a->nfld <= 0) return TRANS_MISSING_ARG;
+  if (!only_task_one(a->nto, a->nfld)) return TRANS_ERROR;
+  memcpy(a->rspecg, a->rspec, sizeof(double) * (size_t)a->trans->nspec2 * (size_t)a->nfld);
+  return TRANS_SUCCESS;
 }
 
 struct SpecNorm_t new_specnorm(struct Trans_t *t) {

@@ -6,8 +6,8 @@
  * (rgp[ngpblks][nfld][nproma], rsp[nspec2][nfld], transi.h:908-921), same return convention
  * (TRANS_SUCCESS = 0, negative error codes, trans_error_msg()).
  *
- * Not provided (outside SURVEY.md section 8): distgrid/gathgrid/distspec/gathspec, vordiv_to_UV,
- * adjoints, LAM, lonlat, legendre-cache I/O, lglobal != 0, rmeanu/rmeanv.  They return
+ * Not provided (outside SURVEY.md section 8): vordiv_to_UV,
+ * adjoints, LAM, lonlat, legendre-cache I/O, rmeanu/rmeanv (lglobal is honoured: one task, global == local).  They return
  * TRANS_NOTIMPL instead of being silently ignored.
  */
 #ifndef TRANSI_MI_H
@@ -96,6 +96,49 @@ struct DirTrans_t new_dirtrans(struct Trans_t *);
 int trans_dirtrans(struct DirTrans_t *);
 struct InvTrans_t new_invtrans(struct Trans_t *);
 int trans_invtrans(struct InvTrans_t *);
+/* trans_distgrid / trans_gathgrid / trans_distspec / trans_gathspec (transi.h:1082-1186): global <->
+ * distributed arrays.  This layer drives one task, so they are re-layouts; a task number other than 1
+ * in nfrom / nto is an error. */
+struct DistGrid_t {
+  const double *rgpg; /* [nfld][ngptotg] */
+  double *rgp;        /* [ngpblks][nfld][nproma] */
+  const int *nfrom;   /* [nfld] */
+  int nproma, nfld, ngpblks;
+  struct Trans_t *trans;
+  int count;
+};
+struct GathGrid_t {
+  double *rgpg;
+  const double *rgp;
+  const int *nto;
+  int nproma, nfld, ngpblks;
+  struct Trans_t *trans;
+  int count;
+};
+struct DistSpec_t {
+  const double *rspecg; /* [nspec2g][nfld] */
+  double *rspec;        /* [nspec2][nfld] */
+  const int *nfrom;
+  int nfld;
+  struct Trans_t *trans;
+  int count;
+};
+struct GathSpec_t {
+  double *rspecg;
+  const double *rspec;
+  const int *nto;
+  int nfld;
+  struct Trans_t *trans;
+  int count;
+};
+struct DistGrid_t new_distgrid(struct Trans_t *);
+int trans_distgrid(struct DistGrid_t *);
+struct GathGrid_t new_gathgrid(struct Trans_t *);
+int trans_gathgrid(struct GathGrid_t *);
+struct DistSpec_t new_distspec(struct Trans_t *);
+int trans_distspec(struct DistSpec_t *);
+struct GathSpec_t new_gathspec(struct Trans_t *);
+int trans_gathspec(struct GathSpec_t *);
 struct SpecNorm_t new_specnorm(struct Trans_t *);
 int trans_specnorm(struct SpecNorm_t *);
 int trans_delete(struct Trans_t *);

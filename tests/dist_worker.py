@@ -64,6 +64,30 @@ def main():
     print("rank %d/%d: nump %d nlat %d e_inv %.2e e_dir %.2e e_norm %.2e" % (rank, world, len(myms), lat1 - lat0, e_inv, e_dir, e_norm),
           flush=True)
     assert e_inv < 1e-12 and e_dir < 1e-12 and e_norm < 1e-13, (e_inv, e_dir, e_norm)
+    # ---- DIST_SPEC / GATH_SPEC / DIST_GRID / GATH_GRID: fields 0,1 live on the last task, field 2 on task 1
+    roots = np.array([world, world, 1])
+    glob = np.concatenate([vor, sc], axis=1)  # (nspec2g, 3), identical on every task by construction
+    src = glob.copy()
+    src[:, roots != rank + 1] = np.nan  # a task only has to provide the fields it is the source of
+    locsp = et.dist_spec(r, src, 3, kfrom=roots)
+    assert np.array_equal(locsp, glob[gidx])
+    back_g = et.gath_spec(r, locsp, 3, kto=roots)
+    tgt = np.flatnonzero(roots == rank + 1)
+    if tgt.size:
+        assert np.array_equal(back_g, glob[:, tgt])
+    else:
+        assert back_g is None
+    ggrid = gref[:3]
+    srcg = ggrid.copy()
+    srcg[roots != rank + 1] = np.nan
+    locgp = et.dist_grid(r, srcg, 3, kfrom=roots, kproma=37)
+    assert locgp.shape == ((ng - 1) // 37 + 1, 3, 37)
+    assert np.array_equal(np.concatenate(list(locgp), axis=1)[:, :ng], ggrid[:, gp0:gp0 + ng])
+    back_gp = et.gath_grid(r, locgp, 3, kto=roots)
+    if tgt.size:
+        assert np.array_equal(back_gp, ggrid[tgt])
+    else:
+        assert back_gp is None
     et.trans_release(r)
     et.trans_end()
     dist.barrier()

@@ -72,6 +72,27 @@ def test_specialised_fft_kernels_match_oracle(et, half, precision):
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
+def test_dist_and_gath_routines_single_task(et):
+    """DIST_SPEC/GATH_SPEC/DIST_GRID/GATH_GRID with one task are pure re-layouts."""
+    N = 10
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        rng = np.random.default_rng(3)
+        g = rng.standard_normal((ns2, 4))
+        loc = et.dist_spec(r, g, 4)
+        assert np.array_equal(loc, g) and np.array_equal(et.gath_spec(r, loc, 4), g)
+        gg = rng.standard_normal((4, ng))
+        blk = et.dist_grid(r, gg, 4, kproma=100)
+        assert blk.shape == ((ng - 1) // 100 + 1, 4, 100)
+        assert np.array_equal(et.gath_grid(r, blk, 4), gg)
+        with pytest.raises(et.TransError, match="task numbers"):
+            et.dist_spec(r, g, 4, kfrom=2)
+    finally:
+        et.trans_release(r)
+
+
 def test_fp32_library_rejects_double_arrays(et):
     nloen = octahedral(7)
     r = et.setup_trans(7, len(nloen), nloen, precision=4)

@@ -70,6 +70,46 @@ int main(void) {
     if (fabs(norm[f] / sqrt(2.0) - 1.0) > 1e-13 || fabs(rsc[i419 * nscalar + f] - 1.0) > 1e-13) return 5;
   for (int f = 0; f < nvordiv; f++)
     if (fabs(rvor[i419 * nvordiv + f] - 1.0) > 1e-12 || fabs(rdiv[i419 * nvordiv + f] - 1.0) > 1e-12) return 6;
+  /* global <-> distributed helpers and lglobal (transi.h:512-616, 929): blocked copy and back */
+  {
+    const int nf = 2 * nvordiv + nscalar, np = 1000, nb = (trans.ngptot - 1) / np + 1;
+    double *rgpg = malloc(sizeof(double) * (size_t)nf * trans.ngptot), *rblk = calloc((size_t)nb * nf * np, sizeof(double));
+    int *one = malloc(sizeof(int) * nf);
+    for (int f = 0; f < nf; f++) one[f] = 1;
+    struct GathGrid_t gg = new_gathgrid(&trans);
+    gg.rgpg = rgpg, gg.rgp = rgp, gg.nto = one, gg.nfld = nf;
+    CHECK(trans_gathgrid(&gg));
+    for (long i = 0; i < (long)nf * trans.ngptot; i++)
+      if (rgpg[i] != rgp[i]) return 7; /* unblocked local == global for one task */
+    struct DistGrid_t dg = new_distgrid(&trans);
+    dg.rgpg = rgpg, dg.rgp = rblk, dg.nfrom = one, dg.nfld = nf, dg.nproma = np, dg.ngpblks = nb;
+    CHECK(trans_distgrid(&dg));
+    struct DirTrans_t d3 = new_dirtrans(&trans);  /* blocked input */
+    d3.nscalar = nscalar, d3.nvordiv = nvordiv, d3.rgp = rblk, d3.nproma = np, d3.ngpblks = nb;
+    d3.rspscalar = rsc, d3.rspvor = rvor, d3.rspdiv = rdiv;
+    CHECK(trans_dirtrans(&d3));
+    for (int f = 0; f < nscalar; f++)
+      if (fabs(rsc[i419 * nscalar + f] - 1.0) > 1e-13) return 8;
+    struct DirTrans_t d4 = new_dirtrans(&trans);  /* lglobal: the global field as is */
+    d4.nscalar = nscalar, d4.nvordiv = nvordiv, d4.rgp = rgpg, d4.lglobal = 1;
+    d4.rspscalar = rsc, d4.rspvor = rvor, d4.rspdiv = rdiv;
+    CHECK(trans_dirtrans(&d4));
+    for (int f = 0; f < nscalar; f++)
+      if (fabs(rsc[i419 * nscalar + f] - 1.0) > 1e-13) return 9;
+    double *rspg = malloc(sizeof(double) * (size_t)trans.nspec2 * nscalar);
+    struct GathSpec_t gs = new_gathspec(&trans);
+    gs.rspecg = rspg, gs.rspec = rsc, gs.nto = one, gs.nfld = nscalar;
+    CHECK(trans_gathspec(&gs));
+    struct DistSpec_t ds = new_distspec(&trans);
+    ds.rspecg = rspg, ds.rspec = rsc, ds.nfrom = one, ds.nfld = nscalar;
+    CHECK(trans_distspec(&ds));
+    if (rspg[i419 * nscalar] != rsc[i419 * nscalar]) return 10;
+    one[0] = 2;
+    struct GathSpec_t bad = new_gathspec(&trans);
+    bad.rspecg = rspg, bad.rspec = rsc, bad.nto = one, bad.nfld = nscalar;
+    if (trans_gathspec(&bad) == TRANS_SUCCESS) return 11; /* no task 2 */
+    free(rgpg), free(rblk), free(one), free(rspg);
+  }
   CHECK(trans_delete(&trans));
   CHECK(trans_finalize());
   printf("TRANSI API OK\n");
