@@ -1,8 +1,10 @@
 // ectrans_mi.hip -- host orchestration + C-ABI (include/ectrans_mi.h) of libectrans_mi.so.
 // Built with hipcc --offload-arch=gfx950 (product) or g++ -x c++ -DEMI_CPU_EMU (test emulator).
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstdio>
 #include <map>
 #include <string>
 #include <vector>
@@ -219,9 +221,19 @@ extern "C" int emi_init(const emi_init_t *cfg) {
 static int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
 static int build_fft_plans(Plan &P) {
-  std::map<int, int> idx;
-  std::vector<d2> tw, rtw, chirp, bhat, ptw;
-  std::vector<uint16_t> perm;
+  // Pass 1 (serial, cheap): one plan per distinct row length; table offsets.  The twiddle tables and
+  // the digit-reversal table depend only on the work size S and its factor list, so all plans with the
+  // same S share one copy (TCo1279: ~20 work sizes for 1280 row lengths -- 2 MB of twiddles that stay in
+  // L2 instead of 130 MB); the real-pack twiddles, the chirp and the filter spectrum are per length.
+  // Pass 2 fills the tables on the host threads, one task per table.
+  struct Shared {
+    int S, tw_off, perm_off, ptw_off[14];
+    std::vector<int> fac;
+  };
+  std::map<int, int> idx;            // row length -> plan
+  std::map<int, int> sidx;           // work size -> shared tables
+  std::vector<Shared> shared;
+  size_t n_tw = 0, n_ptw = 0, n_perm = 0, n_rtw = 0, n_chirp = 0, n_bhat = 0;
   P.planid.assign(P.nlat, 0);
   for (int j = 0; j < P.nlat; j++) {  // local latitudes
     int n = P.nloen[P.lat0 + j];
@@ -244,67 +256,37 @@ static int build_fft_plans(Plan &P) {
     if (pl.S > 65535 || fac.size() > 14) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d not supported (work size %d)", n, pl.S);
     pl.nfac = (int)fac.size();
     for (int i = 0; i < pl.nfac; i++) pl.fac[i] = fac[i];
-    pl.tw_off = (int)tw.size();
-    pl.perm_off = (int)perm.size();
-    pl.rtw_off = (int)rtw.size();
-    pl.chirp_off = (int)chirp.size();
-    pl.bhat_off = (int)bhat.size();
-    const double tpi = 2.0 * M_PI;
-    for (int k = 0; k < pl.S; k++) {
-      double a = tpi * (double)k / (double)pl.S;
-      tw.push_back(d2{std::cos(a), -std::sin(a)});
-    }
-    {  // per-pass twiddle tables, [t-1][j] with j fastest (coalesced reads)
+    auto si = sidx.find(pl.S);
+    if (si == sidx.end()) {
+      Shared sh{};
+      sh.S = pl.S;
+      sh.fac = fac;
+      sh.tw_off = (int)n_tw;
+      n_tw += pl.S;
+      sh.perm_off = (int)n_perm;
+      n_perm += pl.S;
       long long lenp = 1;
       for (int ip = 0; ip < pl.nfac; ip++) {
-        const int R = fac[ip];
-        pl.ptw_off[ip] = (int)ptw.size();
-        if (lenp > 1)
-          for (int t = 1; t < R; t++)
-            for (long long j = 0; j < lenp; j++) {
-              long double a = 2.0L * (long double)M_PIl * (long double)((j * t) % (lenp * R)) / (long double)(lenp * R);
-              ptw.push_back(d2{(double)cosl(a), (double)-sinl(a)});
-            }
-        lenp *= R;
+        sh.ptw_off[ip] = (int)n_ptw;
+        if (lenp > 1) n_ptw += (size_t)(fac[ip] - 1) * lenp;
+        lenp *= fac[ip];
       }
+      si = sidx.emplace(pl.S, (int)shared.size()).first;
+      shared.push_back(sh);
     }
-    std::vector<uint16_t> pm;
-    emi::dit_positions(pl.S, fac, pm);
-    perm.insert(perm.end(), pm.begin(), pm.end());
-    for (int k = 0; k <= pl.sz; k++) {
-      double a = tpi * (double)k / (double)n;
-      rtw.push_back(d2{std::cos(a), -std::sin(a)});
-    }
+    const Shared &sh = shared[si->second];
+    pl.tw_off = sh.tw_off;
+    pl.perm_off = sh.perm_off;
+    for (int ip = 0; ip < pl.nfac; ip++) pl.ptw_off[ip] = sh.ptw_off[ip];
+    pl.rtw_off = (int)n_rtw;
+    n_rtw += pl.sz + 1;
     if (pl.blue) {
-      std::vector<d2> c(pl.sz);
-      for (int k = 0; k < pl.sz; k++) {
-        long long k2 = ((long long)k * k) % (2LL * pl.sz);
-        double a = M_PI * (double)k2 / (double)pl.sz;
-        c[k] = d2{std::cos(a), -std::sin(a)};  // exp(-i pi k^2/sz)
-      }
-      chirp.insert(chirp.end(), c.begin(), c.end());
-      // filter b_j = conj(c_|j|) wrapped to length L; Bhat = DFT_L(b) (direct O(L*sz) sum in
-      // long double: setup only, keeps the table accurate to ~1e-17)
-      const int L = pl.S;
-      std::vector<d2> bh(L);
-      std::vector<long double> cr(L), ci(L);
-      for (int k = 0; k < L; k++) {
-        long double a = 2.0L * (long double)M_PIl * (long double)k / (long double)L;
-        cr[k] = cosl(a);
-        ci[k] = -sinl(a);
-      }
-      emi::parallel_for(L, [&](int k) {
-        long double sr = c[0].x, si = -c[0].y;
-        for (int jj = 1; jj < pl.sz; jj++) {
-          // b_j + b_{L-j} term: conj(c_j) * (w^{jk} + w^{-jk}) = conj(c_j) * 2 cos(2 pi j k/L)
-          long double cs = 2.0L * cr[(int)(((long long)jj * k) % L)];
-          sr += (long double)c[jj].x * cs;
-          si += -(long double)c[jj].y * cs;
-        }
-        bh[pm[k]] = d2{(double)sr, (double)si};
-      });
-      bhat.insert(bhat.end(), bh.begin(), bh.end());
+      pl.chirp_off = (int)n_chirp;
+      n_chirp += pl.sz;
+      pl.bhat_off = (int)n_bhat;
+      n_bhat += pl.S;
     }
+    if (n_tw > 0x7fffffffULL || n_ptw > 0x7fffffffULL || n_bhat > 0x7fffffffULL) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT tables too large");
     // fields per workgroup: as many as fit ~40 KiB of LDS (power of two, <= 16); longer rows get one
     // field per workgroup and more threads.  Threads per workgroup follow the LDS footprint: 256 up to
     // 40 KiB, 512 up to 80 KiB, else 1024 -- i.e. always 16 waves per CU at 128 VGPRs.  (One thread per
@@ -359,6 +341,73 @@ static int build_fft_plans(Plan &P) {
     idx[n] = id;
     P.planid[j] = id;
   }
+  // ---- pass 2: fill the tables
+  std::vector<d2> tw(n_tw), rtw(n_rtw), chirp(n_chirp), bhat(n_bhat), ptw(n_ptw);
+  std::vector<uint16_t> perm(n_perm);
+  emi::parallel_for((int)shared.size(), [&](int is) {
+    const Shared &sh = shared[is];
+    const int S = sh.S;
+    for (int k = 0; k < S; k++) {
+      long double a = 2.0L * (long double)M_PIl * (long double)k / (long double)S;
+      tw[sh.tw_off + k] = d2{(double)cosl(a), (double)-sinl(a)};
+    }
+    // per-pass twiddle tables, [t-1][j] with j fastest (coalesced reads)
+    long long lenp = 1;
+    for (size_t ip = 0; ip < sh.fac.size(); ip++) {
+      const int R = sh.fac[ip];
+      d2 *dst = ptw.data() + sh.ptw_off[ip];
+      if (lenp > 1)
+        for (int t = 1; t < R; t++)
+          for (long long j = 0; j < lenp; j++) {
+            long double a = 2.0L * (long double)M_PIl * (long double)((j * t) % (lenp * R)) / (long double)(lenp * R);
+            *dst++ = d2{(double)cosl(a), (double)-sinl(a)};
+          }
+      lenp *= R;
+    }
+    std::vector<uint16_t> pm;
+    emi::dit_positions(S, sh.fac, pm);
+    std::copy(pm.begin(), pm.end(), perm.begin() + sh.perm_off);
+  });
+  // longest rows first: their O(L * sz) filter sums dominate
+  std::vector<int> order(P.fplans.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return P.fplans[a].n > P.fplans[b].n; });
+  emi::parallel_for((int)order.size(), [&](int io) {
+    const FftPlanDev &pl = P.fplans[order[io]];
+    const int n = pl.n;
+    const double tpi = 2.0 * M_PI;
+    for (int k = 0; k <= pl.sz; k++) {
+      double a = tpi * (double)k / (double)n;
+      rtw[pl.rtw_off + k] = d2{std::cos(a), -std::sin(a)};
+    }
+    if (!pl.blue) return;
+    d2 *c = chirp.data() + pl.chirp_off;
+    for (int k = 0; k < pl.sz; k++) {
+      long long k2 = ((long long)k * k) % (2LL * pl.sz);
+      double a = M_PI * (double)k2 / (double)pl.sz;
+      c[k] = d2{std::cos(a), -std::sin(a)};  // exp(-i pi k^2/sz)
+    }
+    // filter b_j = conj(c_|j|) wrapped to length L; Bhat = DFT_L(b) (direct O(L*sz) sum in
+    // long double: setup only, keeps the table accurate to ~1e-17), stored at the DIT positions
+    const int L = pl.S;
+    const uint16_t *pm = perm.data() + pl.perm_off;
+    std::vector<long double> cr(L);
+    for (int k = 0; k < L; k++) cr[k] = cosl(2.0L * (long double)M_PIl * (long double)k / (long double)L);
+    d2 *bh = bhat.data() + pl.bhat_off;
+    for (int k = 0; k < L; k++) {
+      long double sr = c[0].x, si = -c[0].y;
+      long long jk = 0;
+      for (int jj = 1; jj < pl.sz; jj++) {
+        // b_j + b_{L-j} term: conj(c_j) * (w^{jk} + w^{-jk}) = conj(c_j) * 2 cos(2 pi j k/L)
+        jk += k;
+        if (jk >= L) jk -= L;
+        long double cs = 2.0L * cr[jk];
+        sr += (long double)c[jj].x * cs;
+        si += -(long double)c[jj].y * cs;
+      }
+      bh[pm[k]] = d2{(double)sr, (double)si};
+    }
+  });
   for (int j = 0; j < P.nlat; j++) {
     const FftPlanDev &pl = P.fplans[P.planid[j]];
     FftClass &fc = P.fclass[pl.lds_class];
@@ -456,7 +505,16 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   }
   P.ngptotg = (int)cum[L];
   // Gaussian latitudes / weights, cos^2, 1/(a cos)  (suleg_mod.F90:264-293, 386-394)
+  // EMI_SETUP_TIMING=1 prints where SETUP_TRANS spends its wall time
+  const bool timing = getenv("EMI_SETUP_TIMING") && atoi(getenv("EMI_SETUP_TIMING"));
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_ph = now();
+  auto phase = [&](const char *what) {
+    if (timing) fprintf(stderr, "[emi_setup] %-28s %8.3f s\n", what, now() - t_ph);
+    t_ph = now();
+  };
   emi::gauss_latitudes(L, P.rmu, P.rw);
+  phase("gaussian latitudes");
   P.cos2.assign(L, 0.0);
   P.racthe.assign(L, 0.0);
   for (int j = 0; j < L; j++) {
@@ -634,6 +692,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   std::vector<double> lapin(N + 4, 0.0);  // RLAPIN(-1:N+2) (pre_suleg_mod.F90:64-69)
   for (int n = 1; n <= N + 2; n++) lapin[n + 1] = -(P.ra * P.ra / (double)(n * (n + 1)));
 
+  phase("distribution + index tables");
   // ---- Legendre panels of the local wavenumbers: PS[k][j] = P_{m+2k}^m(mu_{isl0+j}),
   // PA[k][j] = P_{m+2k+1}^m, zero padded; plus the [j][k] transposed copy for the direct transform
   void *dP = nullptr, *dPT = nullptr;
@@ -689,6 +748,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
       return EMI_ERR_RUNTIME;
     }
   }
+  phase("legendre panels");
   // ---- device tables
   int *d_mval, *d_nmen, *d_gpoff, *d_nasm0, *d_fbase, *d_fftrow, *d_lbase, *d_legN, *d_legS, *d_wbase, *d_wrows, *d_rowm, *d_ebase,
       *d_ldp, *d_ldk, *d_ltp, *d_ktp;
@@ -742,7 +802,9 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   g.lattile_pref = d_ltp;
   g.ktile_pref = d_ktp;
   g.specw = d_specw;
+  phase("device tables");
   int rc = build_fft_plans(P);
+  phase("fft plans + tables");
   if (rc) {
     delete pp;
     return rc;
