@@ -111,6 +111,18 @@ static int upload(const std::vector<T> &h, T **d) {
   return 0;
 }
 
+// launch the fp64 or the fp32 instantiation of a kernel; RT names the real type inside the argument list
+#define EMI_LAUNCH_P(esz, kern, grid, block, lds, st, ...)                     \
+  do {                                                                         \
+    if ((esz) == 8) {                                                          \
+      typedef double RT;                                                       \
+      EMI_LAUNCH(emi_f64::kern, grid, block, lds, st, __VA_ARGS__);            \
+    } else {                                                                   \
+      typedef float RT;                                                        \
+      EMI_LAUNCH(emi_f32::kern, grid, block, lds, st, __VA_ARGS__);            \
+    }                                                                          \
+  } while (0)
+
 // ------------------------------------------------------------------------------------------
 // per-resolution plan
 // ------------------------------------------------------------------------------------------
@@ -705,10 +717,20 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   P.d_PT = (char *)dPT;
   P.dev_allocs.push_back(dP);
   P.dev_allocs.push_back(dPT);
+  // m >= 2: k_legpol on the device (below, once the device tables exist); m = 0, 1 (ordinary Legendre
+  // recurrence, supolf_mod.F90:124-142) on the host.  EMI_LEGPOL_HOST=1 computes every panel on the
+  // host threads instead (the two paths agree bit for bit, tests/test_gpu_parity.py).
+  const bool legpol_host = getenv("EMI_LEGPOL_HOST") && atoi(getenv("EMI_LEGPOL_HOST"));
+  if (emi_dev_memset(dP, 0, (size_t)P.p_elems * esz, 0) || emi_dev_memset(dPT, 0, (size_t)P.pt_elems * esz, 0)) {
+    delete pp;
+    return EMI_ERR_RUNTIME;
+  }
+  emi_stream_sync(0);
   {
     std::atomic<int> bad{0};
     emi::parallel_for(NU, [&](int ml) {
       const int m = P.mval[ml];
+      if (m >= 2 && !legpol_host) return;
       const int nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
       const int ld = P.ldp[ml], nk = P.wrows[ml] / 2;
       const int nmax = N + 2;
@@ -748,7 +770,7 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
       return EMI_ERR_RUNTIME;
     }
   }
-  phase("legendre panels");
+  phase("legendre panels (host part)");
   // ---- device tables
   int *d_mval, *d_nmen, *d_gpoff, *d_nasm0, *d_fbase, *d_fftrow, *d_lbase, *d_legN, *d_legS, *d_wbase, *d_wrows, *d_rowm, *d_ebase,
       *d_ldp, *d_ldk, *d_ltp, *d_ktp;
@@ -803,6 +825,41 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   g.ktile_pref = d_ktp;
   g.specw = d_specw;
   phase("device tables");
+  if (!legpol_host) {
+    // ---- Legendre panels, m >= 2: one thread per (wavenumber, parity, latitude)
+    const int nmax = N + 2;
+    std::vector<double> dcl((size_t)NU * (nmax + 1), 0.0), ddl((size_t)NU * (nmax + 1), 0.0), zf(NU, 0.0), mu(P.rmu.begin(), P.rmu.begin() + P.ndgnh);
+    std::vector<int> blk;
+    emi::parallel_for(NU, [&](int ml) {
+      if (P.mval[ml] < 2) return;
+      emi::LegCoef lc = emi::legendre_coefficients(P.mval[ml], nmax);
+      std::copy(lc.dcl.begin(), lc.dcl.end(), dcl.begin() + (size_t)ml * (nmax + 1));
+      std::copy(lc.ddl.begin(), lc.ddl.end(), ddl.begin() + (size_t)ml * (nmax + 1));
+      zf[ml] = lc.zfac_m;
+    });
+    for (int ml = 0; ml < NU; ml++) {  // m ascending = longest recurrences first
+      if (P.mval[ml] < 2) continue;
+      const int nd = P.lbase[ml + 1] - P.lbase[ml];
+      for (int par = 0; par < 2; par++)
+        for (int jt = 0; jt * 64 < nd; jt++) {
+          blk.push_back(ml);
+          blk.push_back(par << 16 | jt);
+        }
+    }
+    if (!blk.empty()) {
+      double *d_dcl, *d_ddl, *d_zf, *d_mu;
+      int *d_blk;
+      if (upload(dcl, &d_dcl) || upload(ddl, &d_ddl) || upload(zf, &d_zf) || upload(mu, &d_mu) || upload(blk, &d_blk)) {
+        delete pp;
+        return EMI_ERR_RUNTIME;
+      }
+      LegPolDev la{d_mu, d_dcl, d_ddl, d_zf, d_blk, P.ndgnh, nmax};
+      EMI_LAUNCH_P(P.esz, k_legpol, blk.size() / 2, 64, 0, (emi_stream_t)0, P.g, la);
+      emi_stream_sync(0);
+      for (void *q : {(void *)d_dcl, (void *)d_ddl, (void *)d_zf, (void *)d_mu, (void *)d_blk}) emi_dev_free(q);
+    }
+    phase("legendre panels (device)");
+  }
   int rc = build_fft_plans(P);
   phase("fft plans + tables");
   if (rc) {
@@ -1181,18 +1238,6 @@ struct PhaseTimer {
 #endif
 };
 static PhaseTimer g_pt;
-
-// launch the fp64 or the fp32 instantiation of a kernel; RT names the real type inside the argument list
-#define EMI_LAUNCH_P(esz, kern, grid, block, lds, st, ...)                     \
-  do {                                                                         \
-    if ((esz) == 8) {                                                          \
-      typedef double RT;                                                       \
-      EMI_LAUNCH(emi_f64::kern, grid, block, lds, st, __VA_ARGS__);            \
-    } else {                                                                   \
-      typedef float RT;                                                        \
-      EMI_LAUNCH(emi_f32::kern, grid, block, lds, st, __VA_ARGS__);            \
-    }                                                                          \
-  } while (0)
 
 static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
                        emi_stream_t st) {

@@ -1138,6 +1138,100 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
 }
 
 // ==========================================================================================
+// k_legpol: SUPOLF (supolf_mod.F90:13-251) for m >= 2 on the device -- the normalised associated
+// Legendre functions P_n^m(mu), n = m+par, m+par+2, ..., of one (wavenumber, parity, latitude) per
+// thread, by the reference's 4-term recurrence in n with its 1e+-100 rescaling, written straight into
+// the panels P[k][lat] and PT[lat][k].  The arithmetic is the oracle's / the reference's operation for
+// operation in double (fp contraction off: IEEE +,-,*,/,sqrt only), whatever the library precision;
+// the rescaling bookkeeping is streamed: a value is final once the step four degrees above it has been
+// taken (only that step and earlier ones can rescale it, supolf_mod.F90:222-236), so the two values in
+// flight live in registers and nothing is revisited.  (m = 0, 1 use the ordinary recurrence on the host.)
+// ==========================================================================================
+EMI_DEVFN double legpol_final(double v, int corr) {
+  const double big = 1.0e+100, eps = 2.220446049250313e-16;
+  for (int j = 1; j <= corr; j++) {
+    v /= big;
+    if (v < eps) v = eps;  // sic: no ABS in the reference (supolf_mod.F90:241-243)
+  }
+  return v;
+}
+EMI_KERNEL_LB(64) void k_legpol(EmiGeomDev g, LegPolDev a) {
+#ifndef EMI_CPU_EMU
+#pragma clang fp contract(off)
+#endif
+  const int ml = a.blk[2 * EMI_BID], par = a.blk[2 * EMI_BID + 1] >> 16, jt = a.blk[2 * EMI_BID + 1] & 0xffff;
+  const int m = g.mval[ml], N = g.nsmax, nmax = a.nmax;
+  const int nd = g.lbase[ml + 1] - g.lbase[ml], j = jt * 64 + EMI_TID;
+  if (j >= nd) return;
+  const int ld = g.ldp[ml], ldk = g.ldk[ml];
+  real_t *Pp = (real_t *)g.P + (par ? g.offA[ml] : g.offS[ml]) + j;                      // + k * ld
+  real_t *PTp = (real_t *)g.PT + (par ? g.offTA[ml] : g.offTS[ml]) + (long long)j * ldk;  // + k
+  const double *dcl = a.dcl + (long long)ml * (nmax + 1), *ddl = a.ddl + (long long)ml * (nmax + 1);
+  const double eps = 2.220446049250313e-16, big = 1.0e+100, small = 1.0e-100;
+  double x = a.mu[a.ndgnh - nd + j];
+  double c2 = 1.0 - x * x, cs = sqrt(c2);
+  if (fabs(cs) <= eps) {
+    x = 1.0;
+    cs = 0.0;
+    c2 = 0.0;
+  }
+  int corr3 = 0;
+  double lsita = 1.0;
+  for (int i = 1; i <= m / 2; i++) {
+    lsita *= c2;
+    if (fabs(lsita) < small) {
+      lsita *= big;
+      corr3++;
+    }
+  }
+  if (m & 1) lsita *= cs;
+  // starting values n = m .. m+3 (supolf_mod.F90:177-205); this thread needs those of its parity
+  double zfac = a.zfac[ml], zfac0 = 1.0, zfac1 = 1.0, mult = 0.0, st[4] = {0.0, 0.0, 0.0, 0.0};
+  const int icmax = nmax - m < 3 ? nmax - m : 3;
+  for (int ic = 0; ic <= icmax; ic++) {
+    zfac0 *= (double)(2 * m + ic);
+    switch (ic) {
+      case 0: zfac1 = 1.0; mult = zfac; break;
+      case 1: zfac1 = 1.0; zfac *= (double)(2 * m + 1); mult = zfac * x; break;
+      case 2: zfac1 = 2.0; mult = 0.5 * zfac * ((double)(2 * m + 3) * x * x - 1.0); break;
+      default: zfac1 = 6.0; zfac *= (double)(2 * m + 3); mult = (1.0 / 6.0) * x * zfac * ((double)(2 * m + 5) * x * x - 3.0); break;
+    }
+    st[ic] = lsita * mult * sqrt(2.0 * ((double)(m + ic) + 0.5) * zfac1 / zfac0);
+  }
+  const int nk = (N + 1 - m - par) / 2 + 1;  // outputs n = m + par + 2 k <= N + 1  (>= 1 for m <= N)
+  double w0 = st[par], w1 = st[par + 2];
+  int ev = 0, kout = 0;
+  for (int n = m + par + 4; n <= nmax; n += 2) {
+    if (fabs(w0) > big) {
+      w0 /= big;
+      w1 /= big;
+      ev++;
+    }
+    const double nw = ((x * x - ddl[n - 2]) * w1 - dcl[n - 4] * w0) / dcl[n - 2];
+    if (kout < nk) {
+      const double v = legpol_final(w0, corr3 - ev);
+      Pp[(long long)kout * ld] = (real_t)v;
+      PTp[kout] = (real_t)v;
+    }
+    kout++;
+    w0 = w1;
+    w1 = nw;
+  }
+  // the last two values (or the starting values when no step was taken)
+  if (kout < nk) {
+    const double v = legpol_final(w0, corr3 - ev);
+    Pp[(long long)kout * ld] = (real_t)v;
+    PTp[kout] = (real_t)v;
+  }
+  kout++;
+  if (kout < nk && m + par + 2 <= nmax) {
+    const double v = legpol_final(w1, corr3 - ev);
+    Pp[(long long)kout * ld] = (real_t)v;
+    PTp[kout] = (real_t)v;
+  }
+}
+
+// ==========================================================================================
 // k_specnorm: SPNORMD (spnormd_mod.F90:40-57).  One block per field; deterministic order.
 // ==========================================================================================
 EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, long long nspec2, const real_t *sp, int stride, double *out) {

@@ -37,6 +37,14 @@ struct EmiGeomDev {
   const double *specw;         // [nspec2 local] SPECNORM weight of every spectral entry (0, 1 or 2)
 };
 
+struct LegPolDev {  // SETUP_TRANS on the device: inputs of k_legpol
+  const double *mu;        // [ndgnh] Gaussian latitudes (sin) of the northern hemisphere, pole first
+  const double *dcl, *ddl;  // [nump][nmax+1] recurrence coefficients of SUPOLF (supolf_mod.F90:79-83), index n
+  const double *zfac;      // [nump] sqrt(2m-1) prod_{j<m} sqrt((2j-1)/(2j))
+  const int *blk;          // [nblocks][2]: local wavenumber, parity << 16 | latitude tile (64 latitudes)
+  int ndgnh, nmax;
+};
+
 enum { SPK_COPY = 0, SPK_U = 1, SPK_V = 2, SPK_NSD = 3 };
 struct SpecSrc {  // one Legendre-space input field of the inverse transform
   const void *a, *b;  // real_t arrays; element (ispec) of field = a[ispec*sa + ia]

@@ -121,6 +121,28 @@ def test_setup_tables_match_oracle(et):
     et.trans_release(r)
 
 
+def test_device_legendre_setup_with_rescaling(et, monkeypatch):
+    """k_legpol (SUPOLF on the device, m >= 2) on a full grid F64 / T127: every wavenumber at every latitude,
+    so sin^m(theta) underflows 1e-100 near the poles and the 1e+-100 rescaling path runs (corr3 = 2
+    at m = 127).  Panels against the oracle, and against the host path bit for bit."""
+    N, ndgl = 127, 128
+    r = et.setup_trans(N, ndgl, None, kdlon=256)
+    o = Oracle(N, np.full(ndgl, 256, dtype=np.int32))
+    monkeypatch.setenv("EMI_LEGPOL_HOST", "1")
+    rh = et.setup_trans(N, ndgl, None, kdlon=256)
+    try:
+        for m in (2, 3, 40, 100, 126, 127):
+            for sym in (False, True):
+                dev = et.legendre_panel(r, m, sym)
+                ref = o.rpnm(m, sym)
+                assert dev.shape == ref.shape
+                assert np.abs(dev - ref).max(initial=0.0) <= 1e-14 * max(1.0, np.abs(ref).max(initial=0.0))
+                assert np.array_equal(dev, et.legendre_panel(rh, m, sym))
+    finally:
+        et.trans_release(r)
+        et.trans_release(rh)
+
+
 def test_call_mode_2_arrays_and_batches(et):
     """PGPUV/PGP3A/PGP2 + PSPSC3A/PSPSC2 (ectrans-benchmark call mode 2) and field batching."""
     N = 8

@@ -148,6 +148,29 @@ def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
     assert not np.array_equal(outs[0][0], np.zeros_like(outs[0][0]))
 
 
+def test_device_legendre_setup_matches_host_and_oracle(et, monkeypatch):
+    """k_legpol (SUPOLF on the GPU, fp contraction off) against the host recurrence bit for bit and
+    against the oracle: a full grid F64 / T127 (1e+-100 rescaling near the poles) and TCo639 rows."""
+    from oracle.oracle import Oracle as O
+    for N, nloen, ms in ((127, np.full(128, 256, dtype=np.int32), (2, 3, 40, 100, 126, 127)),
+                         (639, octahedral(639), (2, 211, 500, 639))):
+        monkeypatch.delenv("EMI_LEGPOL_HOST", raising=False)
+        r = et.setup_trans(N, len(nloen), nloen)
+        monkeypatch.setenv("EMI_LEGPOL_HOST", "1")
+        rh = et.setup_trans(N, len(nloen), nloen)
+        o = O(N, nloen)
+        try:
+            for m in ms:
+                for sym in (False, True):
+                    dev, ref = et.legendre_panel(r, m, sym), o.rpnm(m, sym)
+                    assert dev.shape == ref.shape
+                    assert np.abs(dev - ref).max(initial=0.0) <= 1e-14 * max(1.0, np.abs(ref).max(initial=0.0))
+                    assert np.array_equal(dev, et.legendre_panel(rh, m, sym))
+        finally:
+            et.trans_release(r)
+            et.trans_release(rh)
+
+
 def test_host_arrays_match_oracle(et):
     """EMI_MEM_HOST: numpy arrays staged over PCIe, as a Fortran/C caller would pass them."""
     from oracle.oracle import Oracle as O
