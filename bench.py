@@ -70,6 +70,24 @@ def cpu_baseline(nsmax, kf_full, budget_s=20.0):
                       "oracle setup %.1fs not included" % (kf, kf_full, nf, t_setup)}
 
 
+def recorded_traffic(N, nlev, nfld, esz, world):
+    """HBM bytes per Legendre launch from the committed PMC passes (profiles/*_pmc_traffic.json, collected
+    with tools/collect_profiles.sh on this exact workload; rocprofv3 cannot run inside the timed region).
+    Only reported for the workload the counters were taken on."""
+    if (N, nlev, nfld, esz, world) != (1279, 137, 10, 8, 1):
+        return None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        vals = [k[n]["hbm_bytes_per_launch"] for n in ("emi_f64::k_leg_inv", "emi_f64::k_leg_dir")]
+        return sum(vals) / len(vals), os.path.basename(files[-1])
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +201,7 @@ def main():
         flops_per_launch = wm["legendre_flops"] * 2 * args.steps / max(leg_launches, 1)
         ms_per_launch = leg_ms / max(leg_launches, 1)
         ach = flops_per_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
+        traffic, traffic_src = recorded_traffic(N, nlev, nfld, esz, world)
         out = {
             "metric": "dir+inv transform-pairs/sec, TCo%d %dL x %d fields; spectral-norm rel-error" % (N, nlev, nfld),
             "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -196,7 +215,8 @@ def main():
             "spectral_norm_rel_error": abs(n0 / n1 - 1.0),
             "roofline": {"bound": "mfma", "kernel": "k_leg_inv + k_leg_dir (fp%d MFMA Legendre transforms)" % (8 * esz),
                          "achieved": ach, "peak": peak * world, "unit": "TFLOP/s",
-                         "frac": ach / (peak * world), "traffic": None,
+                         "frac": ach / (peak * world), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": 90.5e9 if traffic else None,
                          "launches": leg_launches, "avg_launch_ms": ms_per_launch,
                          "algorithmic_flops_per_launch": flops_per_launch},
             "phase_ms_per_step": {"spectral_pack_unpack": pack_ms / args.steps, "legendre_mfma": leg_ms / args.steps,
