@@ -87,6 +87,8 @@ def _bind(L):
     L.emi_inv_trans.argtypes = [C.c_int, C.POINTER(_Inv)]
     L.emi_dir_trans.argtypes = [C.c_int, C.POINTER(_Dir)]
     L.emi_specnorm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, dp]
+    L.emi_inv_transad.argtypes = [C.c_int, C.POINTER(_Inv)]
+    L.emi_dir_transad.argtypes = [C.c_int, C.POINTER(_Dir)]
     L.emi_release.argtypes = [C.c_int]
     L.emi_finalize.argtypes = []
     L.emi_last_error.restype = C.c_char_p
@@ -311,6 +313,36 @@ def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
     _chk(lib().emi_dir_trans(kresol, C.byref(a)))
+
+
+def inv_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
+                kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+    """INV_TRANSAD (inv_transad.h:12): adjoint of INV_TRANS -- reads pgp*, writes psp* (overwritten).
+    Inner products: plain sum in grid-point space, SPECNORM weights (1 for m = 0, 2 for m > 0) in
+    spectral space, as tests/trans/test_invtrans_adjoint.F90:243-315."""
+    a, space, keep = _Inv(), [None, real_dtype(kresol)], []
+    nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
+    nproma = int(kproma) if kproma else ngptot
+    _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, (ngptot - 1) // nproma + 1)
+    a.kproma = nproma
+    a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
+    a.stream = stream
+    _chk(lib().emi_inv_transad(kresol, C.byref(a)))
+
+
+def dir_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
+                kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+    """DIR_TRANSAD (dir_transad.h:12): adjoint of DIR_TRANS -- reads psp*, writes pgp*."""
+    a, space, keep = _Dir(), [None, real_dtype(kresol)], []
+    nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
+    nproma = int(kproma) if kproma else ngptot
+    _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, (ngptot - 1) // nproma + 1)
+    a.kproma = nproma
+    a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
+    a.stream = stream
+    _chk(lib().emi_dir_transad(kresol, C.byref(a)))
 
 
 def specnorm(kresol, pspec):

@@ -1239,7 +1239,7 @@ struct PhaseTimer {
 };
 static PhaseTimer g_pt;
 
-static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
+static void launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
                        emi_stream_t st) {
   for (size_t c = 0; c < P.fclass.size(); c++) {
     FftClass &fc = P.fclass[c];
@@ -1247,7 +1247,7 @@ static void launch_fft(Plan &P, bool inverse, const GridFld *d_flds, int nfld, c
     static const int fft_dbg = getenv("EMI_FFT_DBG") ? atoi(getenv("EMI_FFT_DBG")) : 0;
     const int nchunk = (nfld + fc.fbk - 1) / fc.fbk;
     const long long nblocks = (long long)fc.lats.size() * nchunk;
-    FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, fft_dbg};
+    FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0, fft_dbg};
     const int nthr = fc.nthr;
     switch (fc.hot) {
 #define EMI_HOT_LAUNCH(pc_, S_, nf_, a_, b_, c_, d_, e_)                                                                                       \
@@ -1389,7 +1389,11 @@ static int enumerate_scalars(const ARGS &a, const char *who, std::vector<ScalarR
   return 0;
 }
 
-extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
+// INV_TRANS, and DIR_TRANSAD when adj: the adjoint of DIR_TRANS (for the inner products of the
+// reference's adjoint tests: plain sum over grid points, SPECNORM weights in spectral space) is the same
+// spectral -> grid pipeline with the Gaussian weight and 1/NLOEN applied per latitude (ledirad_mod.F90:151,183,
+// ftdirad_mod.F90:84-89) and the adjoint of UVTVD in place of VDTUV.
+static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   Plan *Pp = get_plan(kresol);
   if (!Pp) EMI_FAIL(EMI_ERR_STATE, "INV_TRANS: unknown resolution %d", kresol);
   if (!ap) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS: null argument block");
@@ -1463,8 +1467,8 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     };
     if (lvorgp) { i_vor = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_COPY)); }
     if (ldivgp) { i_div = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_COPY + 100)); }
-    i_u = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_U));
-    i_v = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, SPK_V));
+    i_u = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, adj ? SPK_U_AD : SPK_U));
+    i_v = (int)lt.size(); for (int i = 0; i < nuv; i++) lt.push_back(uvsrc(i, adj ? SPK_V_AD : SPK_V));
   }
   if (nsc) {
     i_sc = (int)lt.size();
@@ -1580,7 +1584,7 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
     // stream B: FFTs
     if (piped) g_pipe.wait(2 * ib, sB);
     iv = g_pt.start(2, sB);
-    launch_fft(P, true, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    launch_fft(P, true, adj, d_bg, bt.ng, FBf, ldw, nproma, sB);
     g_pt.stop(iv, sB);
     if (piped) g_pipe.signal(2 * ib + 1, sB);
   }
@@ -1592,7 +1596,10 @@ extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *ap) {
   return EMI_SUCCESS;
 }
 
-extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
+// DIR_TRANS, and INV_TRANSAD when adj: the adjoint of INV_TRANS is the same grid -> spectral pipeline
+// without the Gaussian weight and the 1/NLOEN (ftinvad_mod.F90:77-83: "change of metric") and with the
+// adjoint of VDTUV (= -RLAPIN x UVTVD) in place of UVTVD.
+static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   Plan *Pp = get_plan(kresol);
   if (!Pp) EMI_FAIL(EMI_ERR_STATE, "DIR_TRANS: unknown resolution %d", kresol);
   if (!ap) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS: null argument block");
@@ -1695,9 +1702,9 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
       int f = b[i];
       if (f < nuv) {  // u_i -> vor_i and div_i outputs
         SpecDst v{};
-        v.dst = d_vor; v.stride = a.nf_uv; v.idx = f; v.kind = SPO_VOR; v.src0 = loc[f]; v.src1 = loc[nuv + f];
+        v.dst = d_vor; v.stride = a.nf_uv; v.idx = f; v.kind = adj ? SPO_VOR_AD : SPO_VOR; v.src0 = loc[f]; v.src1 = loc[nuv + f];
         bo.push_back(v);
-        v.dst = d_div; v.kind = SPO_DIV;
+        v.dst = d_div; v.kind = adj ? SPO_DIV_AD : SPO_DIV;
         bo.push_back(v);
       } else if (f >= 2 * nuv) {
         const ScalarRef &r = sc[f - 2 * nuv];
@@ -1746,7 +1753,7 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *ap) {
     // stream B: FFTs (need FB[ib&1] released by the Legendre transform of batch ib-2)
     if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sB);
     int iv = g_pt.start(2, sB);
-    launch_fft(P, false, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    launch_fft(P, false, adj, d_bg, bt.ng, FBf, ldw, nproma, sB);
     g_pt.stop(iv, sB);
     if (piped) g_pipe.signal(2 * ib, sB);
     if (exchange(P, false, ldw, st)) return EMI_ERR_RUNTIME;  // TRLTOM (several tasks: never piped)
@@ -1842,4 +1849,43 @@ extern "C" int emi_set_profile(int on) {
 extern "C" int emi_set_max_batch(int max_fields) {
   G.max_batch = max_fields;
   return EMI_SUCCESS;
+}
+
+extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *args) { return inv_trans_impl(kresol, args, false); }
+extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *args) { return dir_trans_impl(kresol, args, false); }
+
+// INV_TRANSAD (include/ectrans/inv_transad.h): arguments of INV_TRANS with the intents swapped
+extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {
+  if (!ap) EMI_FAIL(EMI_ERR_ARG, "INV_TRANSAD: null argument block");
+  const emi_invtrans_t &a = *ap;
+  if (a.ldscders || a.ldvorgp || a.lddivgp || a.lduvder)
+    EMI_FAIL(EMI_ERR_UNSUPPORTED, "INV_TRANSAD: LDSCDERS/LDVORGP/LDDIVGP/LDUVDER are not supported by the adjoint");
+  emi_dirtrans_t d{};
+  d.mem_space = a.mem_space;
+  d.spvor = (void *)a.spvor, d.spdiv = (void *)a.spdiv, d.nf_uv = a.nf_uv;
+  d.spscalar = (void *)a.spscalar, d.nf_scalar = a.nf_scalar;
+  d.spsc3a = (void *)a.spsc3a, d.sc3a_nlev = a.sc3a_nlev, d.sc3a_nvar = a.sc3a_nvar;
+  d.spsc3b = (void *)a.spsc3b, d.sc3b_nlev = a.sc3b_nlev, d.sc3b_nvar = a.sc3b_nvar;
+  d.spsc2 = (void *)a.spsc2, d.nf_sc2 = a.nf_sc2;
+  d.kproma = a.kproma;
+  d.gp = a.gp, d.gp_nfld = a.gp_nfld, d.gpuv = a.gpuv, d.gp3a = a.gp3a, d.gp3b = a.gp3b, d.gp2 = a.gp2;
+  d.stream = a.stream;
+  return dir_trans_impl(kresol, &d, true);
+}
+// DIR_TRANSAD (include/ectrans/dir_transad.h): arguments of DIR_TRANS with the intents swapped
+extern "C" int emi_dir_transad(int kresol, const emi_dirtrans_t *ap) {
+  if (!ap) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANSAD: null argument block");
+  const emi_dirtrans_t &d = *ap;
+  emi_invtrans_t a{};
+  a.mem_space = d.mem_space;
+  a.spvor = d.spvor, a.spdiv = d.spdiv, a.nf_uv = d.nf_uv;
+  a.spscalar = d.spscalar, a.nf_scalar = d.nf_scalar;
+  a.spsc3a = d.spsc3a, a.sc3a_nlev = d.sc3a_nlev, a.sc3a_nvar = d.sc3a_nvar;
+  a.spsc3b = d.spsc3b, a.sc3b_nlev = d.sc3b_nlev, a.sc3b_nvar = d.sc3b_nvar;
+  a.spsc2 = d.spsc2, a.nf_sc2 = d.nf_sc2;
+  a.kproma = d.kproma;
+  a.gp = (void *)d.gp, a.gp_nfld = d.gp_nfld, a.gpuv = (void *)d.gpuv, a.gp3a = (void *)d.gp3a, a.gp3b = (void *)d.gp3b,
+  a.gp2 = (void *)d.gp2;
+  a.stream = d.stream;
+  return inv_trans_impl(kresol, &a, true);
 }

@@ -92,18 +92,22 @@ EMI_KERNEL_LB(256) void k_prepack_inv(EmiGeomDev g, const SpecSrc *flds, int nfl
             out.x = -zn_m1 * e_n * fm.x + zn_p2 * e_np1 * fp.x;
             out.y = -zn_m1 * e_n * fm.y + zn_p2 * e_np1 * fp.y;
           } else {
-            // a = vorticity, b = divergence
-            const void *pa = (s.kind == SPK_U) ? s.a : s.b;  // the field entering the +-(n-1),(n+2) terms
-            const void *pb = (s.kind == SPK_U) ? s.b : s.a;  // the field entering the i*m term
-            int sa = (s.kind == SPK_U) ? s.sa : s.sb, ia = (s.kind == SPK_U) ? s.ia : s.ib;
-            int sb = (s.kind == SPK_U) ? s.sb : s.sa, ib = (s.kind == SPK_U) ? s.ib : s.ia;
-            real_t l_n = (real_t)g.lapin[n + 1], l_nm1 = (real_t)g.lapin[n], l_np1 = (real_t)g.lapin[n + 2];
-            real2 xm = (n - 1 >= m) ? spec_get(pa, sa, ia, isp - 2, m) : mk2(0, 0);
+            // a = vorticity, b = divergence.  SPK_U_AD / SPK_V_AD: the adjoint of UVTVD (uvtvdad_mod.F90) is
+            // VDTUV with the inverse Laplacian replaced by -1 and the (0,0) coefficients, which UVTVD
+            // never produces, read as zero
+            const bool ad = s.kind >= SPK_U_AD, isu = (s.kind == SPK_U || s.kind == SPK_U_AD);
+            const void *pa = isu ? s.a : s.b;  // the field entering the +-(n-1),(n+2) terms
+            const void *pb = isu ? s.b : s.a;  // the field entering the i*m term
+            int sa = isu ? s.sa : s.sb, ia = isu ? s.ia : s.ib;
+            int sb = isu ? s.sb : s.sa, ib = isu ? s.ib : s.ia;
+            real_t l_n = ad ? (real_t)-1.0 : (real_t)g.lapin[n + 1], l_nm1 = ad ? (real_t)-1.0 : (real_t)g.lapin[n],
+                   l_np1 = ad ? (real_t)-1.0 : (real_t)g.lapin[n + 2];
+            real2 xm = (n - 1 >= m && !(ad && n - 1 == 0)) ? spec_get(pa, sa, ia, isp - 2, m) : mk2(0, 0);
             real2 xp = (n + 1 <= N) ? spec_get(pa, sa, ia, isp + 2, m) : mk2(0, 0);
-            real2 y0 = (n <= N) ? spec_get(pb, sb, ib, isp, m) : mk2(0, 0);
+            real2 y0 = (n <= N && !(ad && n == 0)) ? spec_get(pb, sb, ib, isp, m) : mk2(0, 0);
             real_t zkm = (real_t)m;
             real_t c1 = zn_m1 * e_n * l_nm1, c2 = zn_p2 * e_np1 * l_np1;
-            real_t sg = (s.kind == SPK_U) ? 1.0 : -1.0;
+            real_t sg = isu ? 1.0 : -1.0;
             // U = i m L_n D_n + c1 vor_{n-1} - c2 vor_{n+1};  V = i m L_n vor_n - c1 D_{n-1} + c2 D_{n+1}
             out.x = -zkm * l_n * y0.y + sg * (c1 * xm.x - c2 * xp.x);
             out.y = zkm * l_n * y0.x + sg * (c1 * xm.y - c2 * xp.y);
@@ -141,9 +145,10 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
     } else {
       const double *eps = g.eps + g.ebase[ml] - m;
       // vor: x=V (i m term), y=U ; div: x=U, y=V with opposite sign on the n-terms
-      int fx = (s.kind == SPO_VOR) ? s.src1 : s.src0;
-      int fy = (s.kind == SPO_VOR) ? s.src0 : s.src1;
-      real_t sg = (s.kind == SPO_VOR) ? 1.0 : -1.0;
+      const bool isvor = (s.kind == SPO_VOR || s.kind == SPO_VOR_AD);
+      int fx = isvor ? s.src1 : s.src0;
+      int fy = isvor ? s.src0 : s.src1;
+      real_t sg = isvor ? 1.0 : -1.0;
       real2 x0 = *(const real2 *)(W + row * ldw + 2 * fx);
       real2 yp = *(const real2 *)(W + (row + 1) * ldw + 2 * fy);                        // n+1 (<= N+1 stored)
       real2 ym = (n - 1 >= m) ? *(const real2 *)(W + (row - 1) * ldw + 2 * fy) : mk2(0, 0);  // n-1
@@ -153,6 +158,8 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
       out.x = -zkm * x0.y + sg * (-c1 * yp.x + c2 * ym.x);
       out.y = zkm * x0.x + sg * (-c1 * yp.y + c2 * ym.y);
       if (m == 0 && n == 0) out = mk2(0, 0);  // updsp_mod.F90:113-126
+      // adjoint of VDTUV (vdtuvad_mod.F90) = -RLAPIN(n) x the UVTVD stencil
+      if (s.kind >= SPO_VOR_AD) out = cscale(out, -(real_t)g.lapin[n + 1]);
     }
     if (m == 0) out.y = 0.0;  // updspb_mod.F90:106,117
     long long isp = g.nasm0[ml] + 2LL * r;
@@ -809,6 +816,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
   const int n = pl.n, sz = pl.sz, S = pl.S, nmen = g.nmen[lat];
   const int fs = FFT_LDS_ELEMS(S);
   const real_t racthe = (real_t)g.racthe[lat];
+  const real_t adjw = (real_t)(g.rw[lat] / (double)pl.n);  // DIR_TRANSAD only (Lc.adj)
   // row of (lat, m=k) in the FFT-side buffer: affine for one task (no table load in front of the
   // data load), through the exchange-order table otherwise
   const int fb0 = g.fbase[lat];
@@ -829,6 +837,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
         const int k2 = sz - k;
         real2 xa = (k <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
         real2 xb = (k2 <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
+        if (Lc.adj) xa = cscale(xa, adjw), xb = cscale(xb, adjw);
         // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
         real2 wk = cconj(rtw[k]);
         real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
@@ -851,6 +860,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
         } else {
           z = (n - k <= nmen) ? cconj(fsc_load(FB, FROW(n - k), ldf, gf, n - k, racthe)) : mk2(0, 0);
         }
+        if (Lc.adj) z = cscale(z, adjw);
         af[FPAD(pl.blue ? k : (int)perm[k])] = pl.blue ? cmulc(z, chirp[k]) : z;
       }
     }
@@ -953,7 +963,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
     run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac, 1, -1);
   // ---- stage 3: X_k, k = 0..NMEN
   const real_t invL = pl.blue ? (real_t)(1.0 / (double)S) : (real_t)1.0;
-  const real_t base_scale = (real_t)(g.rw[lat] / (double)n);
+  const real_t base_scale = Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n);
   for (int fl = 0; fl < nfl; fl++) {
     const GridFld gf = flds[f0 + fl];
     const real2 *af = a + (long long)fl * fs;
@@ -1054,6 +1064,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
   constexpr int fs = FFT_LDS_ELEMS(H.S);
   const real_t racthe = (real_t)g.racthe[lat];
+  const real_t adjw = (real_t)(g.rw[lat] / (double)pl.n);  // DIR_TRANSAD only (Lc.adj)
   const int fb0 = g.fbase[lat];
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
   const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
@@ -1066,6 +1077,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
       const int k2 = sz - k;
       real2 xa = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
       real2 xb = (k2 <= nmen) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
+      if (Lc.adj) xa = cscale(xa, adjw), xb = cscale(xb, adjw);
       real2 wk = cconj(rtw[k]);
       real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
       real2 zk = cadd(s1, cmuli(cmul(wk, d1)));
@@ -1124,7 +1136,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
   hot_conv<PC, 1>(a, fs, pl, T, 0, sz);
   // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
   const real_t invL = (real_t)(1.0 / (double)H.S);
-  const real_t sc = (real_t)(g.rw[lat] / (double)n) * ((gf.mode == GM_ACOS) ? (real_t)g.racthe[lat] : (real_t)1.0);
+  const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * ((gf.mode == GM_ACOS) ? (real_t)g.racthe[lat] : (real_t)1.0);
   for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
     const int kb = (k == 0) ? 0 : sz - k;
     real2 za = a[FPAD(k)], zb = a[FPAD(kb)];

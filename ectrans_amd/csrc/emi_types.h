@@ -45,13 +45,13 @@ struct LegPolDev {  // SETUP_TRANS on the device: inputs of k_legpol
   int ndgnh, nmax;
 };
 
-enum { SPK_COPY = 0, SPK_U = 1, SPK_V = 2, SPK_NSD = 3 };
+enum { SPK_COPY = 0, SPK_U = 1, SPK_V = 2, SPK_NSD = 3, SPK_U_AD = 4, SPK_V_AD = 5 };  // *_AD: adjoint of UVTVD (DIR_TRANSAD)
 struct SpecSrc {  // one Legendre-space input field of the inverse transform
   const void *a, *b;  // real_t arrays; element (ispec) of field = a[ispec*sa + ia]
   int sa, ia, sb, ib;
   int kind, pad_;
 };
-enum { SPO_COPY = 0, SPO_VOR = 1, SPO_DIV = 2 };
+enum { SPO_COPY = 0, SPO_VOR = 1, SPO_DIV = 2, SPO_VOR_AD = 3, SPO_DIV_AD = 4 };  // *_AD: adjoint of VDTUV (INV_TRANSAD)
 struct SpecDst {  // one spectral output field of the direct transform
   void *dst;  // real_t array
   int stride, idx;
@@ -94,6 +94,8 @@ struct FftLaunchDev {
   int nlat;
   int nchunk;       // field chunks per latitude: block b works on latitude b / nchunk, chunk b % nchunk
   long long nblocks;
+  int adj;  // adjoint transforms: k_fft_dir* drop the Gaussian weight and 1/NLOEN (INV_TRANSAD, ftinvad_mod.F90:77-83),
+            // k_fft_inv* apply them (DIR_TRANSAD, ledirad_mod.F90:151,183 + ftdirad_mod.F90:84-89)
   int dbg;  // EMI_FFT_DBG (timing experiments only): 1 skip global input loads, 2 skip the LDS passes, 4 skip the output stage
 };
 

@@ -209,6 +209,52 @@ int trans_invtrans(struct InvTrans_t *v) {
   return emi_inv_trans(v->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
 }
 
+/* ---- adjoints ---- */
+struct DirTransAdj_t new_dirtrans_adj(struct Trans_t *t) {
+  struct DirTransAdj_t d;
+  memset(&d, 0, sizeof(d));
+  d.trans = t;
+  return d;
+}
+int trans_dirtrans_adj(struct DirTransAdj_t *d) {
+  if (d->count++ > 0) return TRANS_STALE_ARG;
+  if (!d->trans || !d->rgp) return TRANS_MISSING_ARG;
+  if (d->nscalar > 0 && !d->rspscalar) return TRANS_MISSING_ARG;
+  if (d->nvordiv > 0 && (!d->rspvor || !d->rspdiv)) return TRANS_MISSING_ARG;
+  if (d->rmeanu || d->rmeanv) return TRANS_NOTIMPL;
+  emi_dirtrans_t a;
+  memset(&a, 0, sizeof(a));
+  a.mem_space = EMI_MEM_HOST;
+  if (d->nvordiv > 0) a.spvor = d->rspvor, a.spdiv = d->rspdiv, a.nf_uv = d->nvordiv;
+  if (d->nscalar > 0) a.spscalar = d->rspscalar, a.nf_scalar = d->nscalar;
+  a.kproma = (d->nproma > 0 && !d->lglobal) ? d->nproma : d->trans->ngptot;
+  a.gp = d->rgp; /* written */
+  a.gp_nfld = 2 * d->nvordiv + d->nscalar;
+  return emi_dir_transad(d->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+struct InvTransAdj_t new_invtrans_adj(struct Trans_t *t) {
+  struct InvTransAdj_t v;
+  memset(&v, 0, sizeof(v));
+  v.trans = t;
+  return v;
+}
+int trans_invtrans_adj(struct InvTransAdj_t *v) {
+  if (v->count++ > 0) return TRANS_STALE_ARG;
+  if (!v->trans || !v->rgp) return TRANS_MISSING_ARG;
+  if (v->nscalar > 0 && !v->rspscalar) return TRANS_MISSING_ARG;
+  if (v->nvordiv > 0 && (!v->rspvor || !v->rspdiv)) return TRANS_MISSING_ARG;
+  if (v->rmeanu || v->rmeanv || v->lscalarders || v->luvder_EW || v->lvordivgp) return TRANS_NOTIMPL;
+  emi_invtrans_t a;
+  memset(&a, 0, sizeof(a));
+  a.mem_space = EMI_MEM_HOST;
+  if (v->nvordiv > 0) a.spvor = v->rspvor, a.spdiv = v->rspdiv, a.nf_uv = v->nvordiv; /* written */
+  if (v->nscalar > 0) a.spscalar = v->rspscalar, a.nf_scalar = v->nscalar;
+  a.kproma = (v->nproma > 0 && !v->lglobal) ? v->nproma : v->trans->ngptot;
+  a.gp = v->rgp;
+  a.gp_nfld = 2 * v->nvordiv + v->nscalar;
+  return emi_inv_transad(v->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+
 /* ---- global <-> distributed arrays (one task: re-layouts) ---- */
 static int only_task_one(const int *v, int n) {
   for (int i = 0; v && i < n; i++)

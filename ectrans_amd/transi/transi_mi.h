@@ -7,7 +7,7 @@
  * (TRANS_SUCCESS = 0, negative error codes, trans_error_msg()).
  *
  * Not provided (outside SURVEY.md section 8): vordiv_to_UV,
- * adjoints, LAM, lonlat, legendre-cache I/O, rmeanu/rmeanv (lglobal is honoured: one task, global == local).  They return
+ * LAM, lonlat, legendre-cache I/O, rmeanu/rmeanv (lglobal is honoured: one task, global == local).  They return
  * TRANS_NOTIMPL instead of being silently ignored.
  */
 #ifndef TRANSI_MI_H
@@ -71,6 +71,33 @@ struct InvTrans_t {
   struct Trans_t *trans;
   int count;
 };
+
+/* Adjoints (transi.h:946-1076): the structs repeat the field declarations of DirTrans_t / InvTrans_t,
+ * as the reference does, although the data flows the other way: trans_dirtrans_adj READS rsp* and
+ * WRITES rgp (DIR_TRANSAD, transi_module.F90), trans_invtrans_adj reads rgp and writes rsp* (INV_TRANSAD;
+ * lscalarders / luvder_EW / lvordivgp must be 0). */
+struct DirTransAdj_t {
+  const double *rgp;
+  double *rspscalar, *rspvor, *rspdiv;
+  const double *rmeanu, *rmeanv;
+  int nproma, nscalar, nvordiv, ngpblks, lglobal;
+  struct Trans_t *trans;
+  int count;
+};
+struct InvTransAdj_t {
+  const double *rspscalar, *rspvor, *rspdiv;
+  const double *rmeanu, *rmeanv;
+  double *rgp;
+  int nproma, nscalar, nvordiv;
+  int lscalarders, luvder_EW, lvordivgp;
+  int ngpblks, lglobal;
+  struct Trans_t *trans;
+  int count;
+};
+struct DirTransAdj_t new_dirtrans_adj(struct Trans_t *);
+int trans_dirtrans_adj(struct DirTransAdj_t *);
+struct InvTransAdj_t new_invtrans_adj(struct Trans_t *);
+int trans_invtrans_adj(struct InvTransAdj_t *);
 
 struct SpecNorm_t {
   const double *rspec; /* [nspec2][nfld] */

@@ -129,6 +129,18 @@ typedef struct {
 } emi_dirtrans_t;
 int emi_dir_trans(int kresol, const emi_dirtrans_t *args);
 
+/* ---- INV_TRANSAD / DIR_TRANSAD (trans/include/ectrans/inv_transad.h:12, dir_transad.h:12) ------
+ * Adjoints with respect to the inner products of the reference's own adjoint tests
+ * (tests/trans/test_invtrans_adjoint.F90:243-315): plain sum over grid points; in spectral space the
+ * SPECNORM weights (1 for m = 0, 2 for m > 0, imaginary parts of m = 0 excluded).  Same argument
+ * blocks as the transforms they are the adjoints of, with the intents swapped: emi_inv_transad READS
+ * the gp* arrays and WRITES the sp* arrays (it overwrites them; the reference adds to them, callers
+ * zero them first -- test_invtrans_adjoint.F90:192-198), emi_dir_transad reads sp*, writes gp*.
+ * The derivative / vorticity / divergence outputs of INV_TRANS have no adjoint here: those flags
+ * must be 0 (EMI_ERR_UNSUPPORTED otherwise).                                                       */
+int emi_inv_transad(int kresol, const emi_invtrans_t *args);
+int emi_dir_transad(int kresol, const emi_dirtrans_t *args);
+
 /* ---- SPECNORM (trans/include/ectrans/specnorm.h:12) --------------------------------- */
 int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms /* host */);
 

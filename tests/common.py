@@ -84,3 +84,62 @@ def run_case(et, Oracle, xp, nsmax, nloen, nuv, nsc, flags=None, nproma=None, se
         return e_inv, e_dir
     finally:
         et.trans_release(r)
+
+
+def spec_weights(nasm0, nsmax, nspec2):
+    """Weights of the spectral inner product of the reference's adjoint tests
+    (tests/trans/test_invtrans_adjoint.F90:276-315): 1 for m = 0 real parts, 0 for m = 0 imaginary
+    parts, 2 for m > 0."""
+    w = np.full(nspec2, 2.0)
+    w[0:2 * (nsmax + 1):2] = 1.0
+    w[1:2 * (nsmax + 1):2] = 0.0
+    return w
+
+
+def adjoint_case(et, xp, nsmax, nloen, nuv, nsc, nproma=None, seed=7, precision=8):
+    """Dot-product tests of INV_TRANSAD and DIR_TRANSAD against INV_TRANS and DIR_TRANS (the
+    reference's test_invtrans_adjoint.F90 / test_dirtrans_adjoint.F90): returns the two relative errors
+    |<A x, y> - <x, A* y>| / |<A x, y>|."""
+    to0, back0 = xp
+    dt = np.float32 if precision == 4 else np.float64
+    to = lambda a: to0(np.ascontiguousarray(a, dtype=dt))
+    back = lambda a: np.asarray(back0(a), dtype=np.float64)
+    nloen = np.asarray(nloen, dtype=np.int32)
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        nasm0 = et.trans_inq(r, "nasm0")
+        w = spec_weights(nasm0, nsmax, ns2)[:, None]
+        rng = np.random.default_rng(seed)
+        npr = nproma or ng
+        nb = (ng - 1) // npr + 1
+        nf = 2 * nuv + nsc
+        kw = lambda v, d, s: dict(pspvor=v if nuv else None, pspdiv=d if nuv else None, pspscalar=s if nsc else None)
+        rs = lambda n: rng.uniform(-1, 1, (ns2, max(n, 1)))
+        rg = lambda: block(rng.uniform(-1, 1, (nf, ng)), npr)
+        dot_sp = lambda a, b: sum(float((w * back(x) * back(y)).sum()) for x, y in zip(a, b) if x is not None)
+        dot_gp = lambda a, b: float((back(a) * back(b)).sum())
+        # ---- INV_TRANS vs INV_TRANSAD
+        x = [to(rs(nuv)), to(rs(nuv)), to(rs(nsc))]
+        for i in (0, 1):  # the reference's forward model ignores vor/div (0,0)
+            t = back(x[i]); t[0:2] = 0.0; x[i] = to(t)
+        y = to(rg())
+        ax = to(np.zeros((nb, nf, npr)))
+        et.inv_trans(r, pgp=ax, kproma=npr, **kw(*x))
+        aty = [to(np.zeros((ns2, max(nuv, 1)))), to(np.zeros((ns2, max(nuv, 1)))), to(np.zeros((ns2, max(nsc, 1))))]
+        et.inv_transad(r, pgp=y, kproma=npr, **kw(*aty))
+        sel = lambda l: [l[0] if nuv else None, l[1] if nuv else None, l[2] if nsc else None]
+        lhs, rhs = dot_gp(ax, y), dot_sp(sel(x), sel(aty))
+        e_inv = abs(lhs - rhs) / abs(lhs)
+        # ---- DIR_TRANS vs DIR_TRANSAD
+        xg = to(rg())
+        ys = [to(rs(nuv)), to(rs(nuv)), to(rs(nsc))]
+        bx = [to(np.zeros((ns2, max(nuv, 1)))), to(np.zeros((ns2, max(nuv, 1)))), to(np.zeros((ns2, max(nsc, 1))))]
+        et.dir_trans(r, pgp=xg, kproma=npr, **kw(*bx))
+        bty = to(np.zeros((nb, nf, npr)))
+        et.dir_transad(r, pgp=bty, kproma=npr, **kw(*ys))
+        lhs, rhs = dot_sp(sel(bx), sel(ys)), dot_gp(xg, bty)
+        e_dir = abs(lhs - rhs) / abs(lhs)
+        return e_inv, e_dir
+    finally:
+        et.trans_release(r)

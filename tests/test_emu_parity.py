@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
-from tests.common import octahedral, run_case
+from tests.common import adjoint_case, octahedral, run_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-12  # fp64: observed ~1e-15
@@ -89,6 +89,25 @@ def test_dist_and_gath_routines_single_task(et):
         assert np.array_equal(et.gath_grid(r, blk, 4), gg)
         with pytest.raises(et.TransError, match="task numbers"):
             et.dist_spec(r, g, 4, kfrom=2)
+    finally:
+        et.trans_release(r)
+
+
+@pytest.mark.parametrize("nuv,nsc,nproma", [(0, 2, None), (2, 1, None), (1, 1, 37)])
+def test_adjoint_transforms_dot_product(et, nuv, nsc, nproma):
+    """INV_TRANSAD / DIR_TRANSAD: <A x, y> = <x, A* y> (tests/trans/test_invtrans_adjoint.F90,
+    test_dirtrans_adjoint.F90; the reference accepts 2000 eps ... 20000 eps)."""
+    e_inv, e_dir = adjoint_case(et, XP, 10, octahedral(10), nuv, nsc, nproma)
+    assert e_inv < 1e-13 and e_dir < 1e-13, (e_inv, e_dir)
+
+
+def test_adjoint_refuses_derivative_options(et):
+    nloen = octahedral(7)
+    r = et.setup_trans(7, len(nloen), nloen)
+    try:
+        a = et._Inv()
+        a.ldscders = 1
+        assert et.lib().emi_inv_transad(r, a) != 0 and b"not supported by the adjoint" in et.lib().emi_last_error()
     finally:
         et.trans_release(r)
 

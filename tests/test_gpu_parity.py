@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.common import block, octahedral, random_spectrum, rel_err, run_case, unblock
+from tests.common import adjoint_case, block, octahedral, random_spectrum, rel_err, run_case, unblock
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -169,6 +169,17 @@ def test_device_legendre_setup_matches_host_and_oracle(et, monkeypatch):
         finally:
             et.trans_release(r)
             et.trans_release(rh)
+
+
+@pytest.mark.parametrize("case", [(21, 0, 3, None, 8), (63, 2, 2, None, 8), (63, 1, 1, 1000, 8), (159, 2, 3, None, 8), (63, 2, 2, None, 4)])
+def test_adjoint_transforms_dot_product(et, dev, case):
+    """INV_TRANSAD / DIR_TRANSAD: <A x, y> = <x, A* y> with the inner products of the reference's
+    tests/trans/test_invtrans_adjoint.F90 and test_dirtrans_adjoint.F90 (tolerance there: 2000 ...
+    20000 machine epsilons), scalars and wind fields."""
+    nsmax, nuv, nsc, nproma, prec = case
+    e_inv, e_dir = adjoint_case(et, dev, nsmax, octahedral(nsmax), nuv, nsc, nproma, precision=prec)
+    tol = 2000 * (np.finfo(np.float32).eps if prec == 4 else np.finfo(np.float64).eps)
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
 def test_host_arrays_match_oracle(et):

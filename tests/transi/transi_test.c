@@ -110,6 +110,44 @@ int main(void) {
     if (trans_gathspec(&bad) == TRANS_SUCCESS) return 11; /* no task 2 */
     free(rgpg), free(rblk), free(one), free(rspg);
   }
+  /* adjoints (transi.h:299-352): <dirtrans(invtrans(x)), y> = <x, invtrans_adj(dirtrans_adj(y))> for the
+   * spectral inner product with weights 1 (m = 0) and 2 (m > 0), as tests/trans/test_adjoint.F90 */
+  {
+    const int ns2 = trans.nspec2, nf = nscalar;
+    double *x = malloc(sizeof(double) * ns2 * nf), *y = malloc(sizeof(double) * ns2 * nf), *p = calloc((size_t)ns2 * nf, sizeof(double));
+    double *g = malloc(sizeof(double) * (size_t)nf * trans.ngptot), *w = malloc(sizeof(double) * ns2);
+    unsigned s = 12345u;
+    for (int i = 0; i < ns2 * nf; i++) {
+      s = s * 1664525u + 1013904223u;
+      x[i] = (double)(s >> 8) / 8388608.0 - 1.0;
+      s = s * 1664525u + 1013904223u;
+      y[i] = (double)(s >> 8) / 8388608.0 - 1.0;
+    }
+    for (int i = 0; i < ns2; i++) w[i] = 2.0;
+    for (int n = 0; n <= trans.nsmax; n++) w[trans.nasm0[0] - 1 + 2 * n] = 1.0, w[trans.nasm0[0] + 2 * n] = 0.0;
+    struct InvTrans_t v2 = new_invtrans(&trans);
+    v2.nscalar = nf, v2.rspscalar = x, v2.rgp = g;
+    CHECK(trans_invtrans(&v2));
+    struct DirTrans_t d5 = new_dirtrans(&trans);
+    d5.nscalar = nf, d5.rgp = g, d5.rspscalar = p;
+    CHECK(trans_dirtrans(&d5));
+    double s1 = 0, s2 = 0;
+    for (int i = 0; i < ns2; i++)
+      for (int f = 0; f < nf; f++) s1 += w[i] * p[i * nf + f] * y[i * nf + f];
+    struct DirTransAdj_t da = new_dirtrans_adj(&trans);
+    da.nscalar = nf, da.rspscalar = y, da.rgp = g;
+    CHECK(trans_dirtrans_adj(&da));
+    struct InvTransAdj_t va = new_invtrans_adj(&trans);
+    va.nscalar = nf, va.rspscalar = p, va.rgp = g;
+    CHECK(trans_invtrans_adj(&va));
+    for (int i = 0; i < ns2; i++)
+      for (int f = 0; f < nf; f++) s2 += w[i] * x[i * nf + f] * p[i * nf + f];
+    if (fabs(s1 - s2) / fabs(s1) > 2000 * 2.220446049250313e-16) {
+      fprintf(stderr, "adjoint test: %g vs %g\n", s1, s2);
+      return 12;
+    }
+    free(x), free(y), free(p), free(g), free(w);
+  }
   CHECK(trans_delete(&trans));
   CHECK(trans_finalize());
   printf("TRANSI API OK\n");
