@@ -68,6 +68,11 @@ def make_alltoallv_hook(group=None, device=None):
                 dist.all_to_all_single(hr, hs, output_split_sizes=osz, input_split_sizes=isz, group=group)
                 recv.copy_(hr)
                 torch.cuda.synchronize(device)
+            elif device.type == "cuda" and stream:
+                # the transform runs on a caller-supplied HIP stream: make it torch's current stream so
+                # that the collective is ordered behind the kernels queued on it and ahead of the next ones
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device)):
+                    dist.all_to_all_single(recv, send, output_split_sizes=osz, input_split_sizes=isz, group=group)
             else:
                 dist.all_to_all_single(recv, send, output_split_sizes=osz, input_split_sizes=isz, group=group)
             return 0

@@ -346,4 +346,16 @@ def test_alltoallv_hook_over_rccl_single_rank(dev):
     rc = hook(None, src.data_ptr(), cnt, dsp, dst.data_ptr(), cnt, dsp, 1, None)
     torch.cuda.synchronize()
     assert rc == 0 and torch.equal(src, dst)
+    # a caller-supplied HIP stream: the collective must be ordered on it (producer kernel before, consumer after)
+    side = torch.cuda.Stream(device="cuda:0")
+    with torch.cuda.stream(side):
+        src2 = torch.zeros(1 << 22, dtype=torch.float64, device="cuda:0")
+        for _ in range(20):
+            src2 += 1.0  # still running when the hook is called
+        dst2 = torch.zeros_like(src2)
+        cnt2 = (C.c_longlong * 1)(src2.numel() * 8)
+        rc = hook(None, src2.data_ptr(), cnt2, dsp, dst2.data_ptr(), cnt2, dsp, 1, side.cuda_stream)
+        out = dst2 * 2.0
+    side.synchronize()
+    assert rc == 0 and float(out.min()) == 40.0 and float(out.max()) == 40.0
     dist.destroy_process_group()
