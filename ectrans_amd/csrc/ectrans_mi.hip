@@ -1095,15 +1095,15 @@ static int ensure_work(Plan &P, int bfpad, int nfb) {
     P.d_FBF = P.d_FBL;
     P.cap_FBF = P.cap_FBL;
   } else {
-    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)P.lrows * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
-    if (grow(&P.d_FBF, &P.cap_FBF, (size_t)P.frows * rowb, "Fourier (FFT-side) exchange buffer")) return -1;
+    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * P.lrows * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
+    if (grow(&P.d_FBF, &P.cap_FBF, (size_t)nfb * P.frows * rowb, "Fourier (FFT-side) exchange buffer")) return -1;
   }
   return 0;
 }
 
 // TRLTOM / TRMTOL (trltom_mod.F90:96-136, trmtol_mod.F90:101-141): one all-to-all-v of whole
 // row blocks of the Fourier buffers.  to_fft: Legendre-side -> FFT-side (inverse transform).
-static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st) {
+static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st, char *FBl, char *FBf) {
   if (P.nproc == 1) return 0;
   const int NP = P.nproc;
   std::vector<long long> sc(NP), sd(NP), rc(NP), rd(NP);
@@ -1115,8 +1115,8 @@ static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st) {
     rc[r] = to_fft ? fr : lr;
     rd[r] = to_fft ? fd : ld;
   }
-  const void *sb = to_fft ? P.d_FBL : P.d_FBF;
-  void *rb = to_fft ? P.d_FBF : P.d_FBL;
+  const void *sb = to_fft ? FBl : FBf;
+  void *rb = to_fft ? FBf : FBl;
   if (G.a2a(G.a2a_user, sb, sc.data(), sd.data(), rb, rc.data(), rd.data(), NP, (void *)st) != 0)
     EMI_FAIL(EMI_ERR_RUNTIME, "all-to-all-v hook failed");
   return 0;
@@ -1274,16 +1274,18 @@ static void launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, i
 // caller's stream with events, so the call keeps ordinary stream semantics.
 struct Pipeline {
 #ifndef EMI_CPU_EMU
-  hipStream_t sA = nullptr, sB = nullptr;
+  hipStream_t sA = nullptr, sB = nullptr, sX = nullptr;  // Legendre, FFT, exchange
   std::vector<hipEvent_t> ev;
-  hipEvent_t fork = nullptr, joinA = nullptr, joinB = nullptr;
+  hipEvent_t fork = nullptr, joinA = nullptr, joinB = nullptr, joinX = nullptr;
   int init() {
     if (sA) return 0;
     EMI_CHECK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
     EMI_CHECK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+    EMI_CHECK(hipStreamCreateWithFlags(&sX, hipStreamNonBlocking));
     EMI_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     EMI_CHECK(hipEventCreateWithFlags(&joinA, hipEventDisableTiming));
     EMI_CHECK(hipEventCreateWithFlags(&joinB, hipEventDisableTiming));
+    EMI_CHECK(hipEventCreateWithFlags(&joinX, hipEventDisableTiming));
     return 0;
   }
   hipEvent_t event(size_t i) {
@@ -1298,17 +1300,20 @@ struct Pipeline {
     (void)hipEventRecord(fork, user);
     (void)hipStreamWaitEvent(sA, fork, 0);
     (void)hipStreamWaitEvent(sB, fork, 0);
+    (void)hipStreamWaitEvent(sX, fork, 0);
   }
   void end(emi_stream_t user) {
     (void)hipEventRecord(joinA, sA);
     (void)hipEventRecord(joinB, sB);
+    (void)hipEventRecord(joinX, sX);
     (void)hipStreamWaitEvent(user, joinA, 0);
     (void)hipStreamWaitEvent(user, joinB, 0);
+    (void)hipStreamWaitEvent(user, joinX, 0);
   }
   void signal(size_t i, emi_stream_t s) { (void)hipEventRecord(event(i), s); }
   void wait(size_t i, emi_stream_t s) { (void)hipStreamWaitEvent(s, event(i), 0); }
 #else
-  void *sA = nullptr, *sB = nullptr;
+  void *sA = nullptr, *sB = nullptr, *sX = nullptr;
   int init() { return 0; }
   void begin(emi_stream_t) {}
   void end(emi_stream_t) {}
@@ -1334,7 +1339,20 @@ static int pipeline_depth(const Plan &P, int nfields) {
   (void)nfields;
   return 1;
 #else
-  if (P.nproc > 1 || nfields < 256) return 1;  // the exchange hook is ordered on the caller's stream
+  if (nfields < 256) return 1;
+  if (P.nproc > 1) {
+    // several tasks: the all-to-all-v of batch b (xGMI) runs on its own stream under the Legendre kernels
+    // of batch b+1 and the FFT kernels of batch b-1 -- with 2 or 4 GPUs the exchange is as long as the
+    // compute (one or three links per GPU), so hiding it is worth more than the co-running penalty.
+    // EMI_PIPELINE_DIST: batches per call (1 = sequential), default 4
+    static int dcfg = -1;
+    if (dcfg < 0) {
+      const char *e = getenv("EMI_PIPELINE_DIST");
+      dcfg = e ? atoi(e) : 4;
+      if (dcfg < 1) dcfg = 1;
+    }
+    return dcfg;
+  }
   return cfg;
 #endif
 }
@@ -1550,25 +1568,30 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
   emi_h2d(P.d_desc, hdesc.data(), hdesc.size(), st);
   emi_stream_sync(st);  // hdesc is a stack vector
-  emi_stream_t sA = st, sB = st;
+  emi_stream_t sA = st, sB = st, sX = st;
   if (piped) {
     if (g_pipe.init()) return EMI_ERR_RUNTIME;
     sA = (emi_stream_t)g_pipe.sA;
     sB = (emi_stream_t)g_pipe.sB;
+    sX = (emi_stream_t)g_pipe.sX;
     g_pipe.begin(st);
   }
   LegMaps *lmaps = nullptr;
   if (leg_tilemaps(P, ldw / LG_BN, &lmaps)) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile);
-  const size_t fbstride = (size_t)P.frows * ldw;
+  // Events of batch ib: 3 ib = Legendre done, 3 ib + 1 = FFT done, 3 ib + 2 = exchange done.  Both
+  // Fourier buffers are double buffered ([ib & 1]); one task: FBf == FBl and there is no exchange.
+  const bool dist = P.nproc > 1;
+  const size_t lstride = (size_t)(dist ? P.lrows : P.frows) * ldw * P.esz, fstride = (size_t)P.frows * ldw * P.esz;
   for (int ib = 0; ib < nbat; ib++) {
     const Bat &bt = bats[ib];
     const SpecSrc *d_bl = (const SpecSrc *)((char *)P.d_desc + bt.off_l);
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
-    char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride * P.esz : 0);
-    char *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
-    // stream A: spectral pack + Legendre (needs FB[ib&1] released by the FFT of batch ib-2)
-    if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sA);
+    char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * lstride : 0);
+    char *FBf = dist ? P.d_FBF + (piped ? (size_t)(ib & 1) * fstride : 0) : FBl;
+    // stream A: spectral pack + Legendre; FBl[ib&1] was last read by the FFT (one task) or by the
+    // exchange (several tasks) of batch ib-2
+    if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + (dist ? 2 : 1), sA);
     int iv = g_pt.start(0, sA);
     {
       long long total = (long long)P.wrows_total * bfpad;
@@ -1579,14 +1602,20 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     iv = g_pt.start(1, sA);
     EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
     g_pt.stop(iv, sA);
-    if (piped) g_pipe.signal(2 * ib, sA);
-    if (exchange(P, true, ldw, st)) return EMI_ERR_RUNTIME;  // TRMTOL (several tasks: never piped)
+    if (piped) g_pipe.signal(3 * ib, sA);
+    if (dist) {
+      // stream X: TRMTOL; FBf[ib&1] was last read by the FFT of batch ib-2
+      if (piped) g_pipe.wait(3 * ib, sX);
+      if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + 1, sX);
+      if (exchange(P, true, ldw, sX, FBl, FBf)) return EMI_ERR_RUNTIME;
+      if (piped) g_pipe.signal(3 * ib + 2, sX);
+    }
     // stream B: FFTs
-    if (piped) g_pipe.wait(2 * ib, sB);
+    if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sB);
     iv = g_pt.start(2, sB);
     launch_fft(P, true, adj, d_bg, bt.ng, FBf, ldw, nproma, sB);
     g_pt.stop(iv, sB);
-    if (piped) g_pipe.signal(2 * ib + 1, sB);
+    if (piped) g_pipe.signal(3 * ib + 1, sB);
   }
   if (piped) g_pipe.end(st);
   if (host) hs.flush(st);
@@ -1733,36 +1762,46 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
   emi_h2d(P.d_desc, hdesc.data(), hdesc.size(), st);
   emi_stream_sync(st);
-  emi_stream_t sA = st, sB = st;
+  emi_stream_t sA = st, sB = st, sX = st;
   if (piped) {
     if (g_pipe.init()) return EMI_ERR_RUNTIME;
     sA = (emi_stream_t)g_pipe.sA;
     sB = (emi_stream_t)g_pipe.sB;
+    sX = (emi_stream_t)g_pipe.sX;
     g_pipe.begin(st);
   }
   LegMaps *lmaps = nullptr;
   if (leg_tilemaps(P, ldw / LG_BN, &lmaps)) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile);
-  const size_t fbstride = (size_t)P.frows * ldw;
+  // events of batch ib: 3 ib = FFT done, 3 ib + 1 = Legendre done, 3 ib + 2 = exchange done (as INV_TRANS)
+  const bool dist = P.nproc > 1;
+  const size_t lstride = (size_t)(dist ? P.lrows : P.frows) * ldw * P.esz, fstride = (size_t)P.frows * ldw * P.esz;
   for (int ib = 0; ib < nbat; ib++) {
     const Bat &bt = bats[ib];
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
     const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + bt.off_o);
-    char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * fbstride * P.esz : 0);
-    char *FBf = (P.nproc == 1) ? FBl : P.d_FBF;
-    // stream B: FFTs (need FB[ib&1] released by the Legendre transform of batch ib-2)
-    if (piped && ib >= 2) g_pipe.wait(2 * (ib - 2) + 1, sB);
+    char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * lstride : 0);
+    char *FBf = dist ? P.d_FBF + (piped ? (size_t)(ib & 1) * fstride : 0) : FBl;
+    // stream B: FFTs; FBf[ib&1] was last read by the Legendre transform (one task) or by the exchange
+    // (several tasks) of batch ib-2
+    if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + (dist ? 2 : 1), sB);
     int iv = g_pt.start(2, sB);
     launch_fft(P, false, adj, d_bg, bt.ng, FBf, ldw, nproma, sB);
     g_pt.stop(iv, sB);
-    if (piped) g_pipe.signal(2 * ib, sB);
-    if (exchange(P, false, ldw, st)) return EMI_ERR_RUNTIME;  // TRLTOM (several tasks: never piped)
+    if (piped) g_pipe.signal(3 * ib, sB);
+    if (dist) {
+      // stream X: TRLTOM; FBl[ib&1] was last read by the Legendre transform of batch ib-2
+      if (piped) g_pipe.wait(3 * ib, sX);
+      if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + 1, sX);
+      if (exchange(P, false, ldw, sX, FBl, FBf)) return EMI_ERR_RUNTIME;
+      if (piped) g_pipe.signal(3 * ib + 2, sX);
+    }
     // stream A: Legendre + spectral unpack
-    if (piped) g_pipe.wait(2 * ib, sA);
+    if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sA);
     iv = g_pt.start(1, sA);
     EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, ldw, (RT *)P.d_W, ldw);
     g_pt.stop(iv, sA);
-    if (piped) g_pipe.signal(2 * ib + 1, sA);
+    if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);
     {
       long long total = (long long)P.wrows_total * (long long)bt.no;

@@ -62,12 +62,18 @@ def make_alltoallv_hook(group=None, device=None):
             osz, isz = [c // 8 for c in rcl], [c // 8 for c in scl]
             if staged:
                 # test configuration only (several ranks sharing one GPU, gloo has no device
-                # all-to-all): stage through the host, fully synchronised
-                torch.cuda.synchronize(device)
-                hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+                # all-to-all): stage through the host, ordered on the stream the library passed -- only
+                # that stream is synchronised, so the library's event dependencies between its Legendre,
+                # exchange and FFT streams are really exercised
+                es = torch.cuda.ExternalStream(int(stream), device=device) if stream else torch.cuda.current_stream(device)
+                es.synchronize()
+                with torch.cuda.stream(es):
+                    hs = send.cpu()
+                hr = torch.empty(recv.shape, dtype=recv.dtype)
                 dist.all_to_all_single(hr, hs, output_split_sizes=osz, input_split_sizes=isz, group=group)
-                recv.copy_(hr)
-                torch.cuda.synchronize(device)
+                with torch.cuda.stream(es):
+                    recv.copy_(hr)
+                es.synchronize()
             elif device.type == "cuda" and stream:
                 # the transform runs on a caller-supplied HIP stream: make it torch's current stream so
                 # that the collective is ordered behind the kernels queued on it and ahead of the next ones

@@ -34,7 +34,7 @@ def main():
     r = et.setup_trans(N, len(nloen), nloen)
     o = Oracle(N, nloen)
     rng = np.random.default_rng(11)  # same global fields on every task
-    nuv, nsc = 1, 2
+    nuv, nsc = 1, int(os.environ.get("EMI_TEST_NSC", "2"))
     vor = random_spectrum(rng, o.nasm0, N, o.nspec2, nuv, True)
     div = random_spectrum(rng, o.nasm0, N, o.nspec2, nuv, True)
     sc = random_spectrum(rng, o.nasm0, N, o.nspec2, nsc, False)
@@ -66,7 +66,7 @@ def main():
     assert e_inv < 1e-12 and e_dir < 1e-12 and e_norm < 1e-13, (e_inv, e_dir, e_norm)
     # ---- DIST_SPEC / GATH_SPEC / DIST_GRID / GATH_GRID: fields 0,1 live on the last task, field 2 on task 1
     roots = np.array([world, world, 1])
-    glob = np.concatenate([vor, sc], axis=1)  # (nspec2g, 3), identical on every task by construction
+    glob = np.concatenate([vor, sc[:, :2]], axis=1)  # (nspec2g, 3), identical on every task by construction
     src = glob.copy()
     src[:, roots != rank + 1] = np.nan  # a task only has to provide the fields it is the source of
     locsp = et.dist_spec(r, src, 3, kfrom=roots)
