@@ -1178,7 +1178,7 @@ static int pick_batch(Plan &P, int nfields, int depth) {
   emi_mem_info(&fr, &tot);
   size_t have = fr + P.cap_W + P.cap_FBL + (P.nproc > 1 ? P.cap_FBF : 0);
   const int nfb = depth > 1 ? 2 : 1;
-  double per_field = (double)(P.wrows_total + nfb * P.frows + (P.nproc > 1 ? P.lrows : 0)) * 2.0 * P.esz;
+  double per_field = (double)(P.wrows_total + nfb * P.frows + (P.nproc > 1 ? nfb * P.lrows : 0)) * 2.0 * P.esz;
   long long cap = (long long)((double)have * 0.85 / per_field);
   cap = cap / 64 * 64;
   if (cap < 64) cap = 64;
