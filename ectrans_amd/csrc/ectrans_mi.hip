@@ -1594,8 +1594,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + (dist ? 2 : 1), sA);
     int iv = g_pt.start(0, sA);
     {
-      long long total = (long long)P.wrows_total * bfpad;
-      long long nblk = (total + 255) / 256;
+      long long nblk = (long long)P.wrows_total * ((bfpad + 255) / 256);
       EMI_LAUNCH_P(P.esz, k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad, (RT *)P.d_W, ldw, (long long)P.wrows_total);
     }
     g_pt.stop(iv, sA);
@@ -1804,8 +1803,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);
     {
-      long long total = (long long)P.wrows_total * (long long)bt.no;
-      long long nblk = (total + 255) / 256;
+      long long nblk = (long long)P.wrows_total * ((bt.no + 255) / 256);
       EMI_LAUNCH_P(P.esz, k_postpack_dir, nblk, 256, 0, sA, P.g, d_bo, bt.no, (const RT *)P.d_W, ldw, (long long)P.wrows_total);
     }
     g_pt.stop(iv, sA);

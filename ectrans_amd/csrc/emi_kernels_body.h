@@ -65,12 +65,12 @@ EMI_DEVFN real2 spec_get(const void *av, int sa, int ia, long long isp, int m) {
 EMI_KERNEL_LB(256) void k_prepack_inv(EmiGeomDev g, const SpecSrc *flds, int nfld, int nfld_pad, real_t *W, int ldw,
                               long long nrows) {
   const int N = g.nsmax;
-  long long total = nrows * nfld_pad;
   {
-    const long long idx = (long long)EMI_BID * EMI_NTHREADS + EMI_TID;
-    if (idx >= total) return;
-    long long row = idx / nfld_pad;
-    int f = (int)(idx - row * nfld_pad);
+    // block -> (packed row, chunk of 256 fields): 32-bit arithmetic only
+    const int nchunk = (nfld_pad + EMI_NTHREADS - 1) / EMI_NTHREADS;
+    const long long row = EMI_BID / nchunk;
+    const int f = (int)(EMI_BID - row * nchunk) * EMI_NTHREADS + EMI_TID;
+    if (row >= nrows || f >= nfld_pad) return;
     real2 out = mk2(0.0, 0.0);
     if (f < nfld) {
       const int ml = g.rowm[row];
@@ -127,12 +127,11 @@ EMI_KERNEL_LB(256) void k_prepack_inv(EmiGeomDev g, const SpecSrc *flds, int nfl
 EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nfld, const real_t *W, int ldw,
                                long long nrows) {
   const int N = g.nsmax;
-  long long total = nrows * nfld;
   {
-    const long long idx = (long long)EMI_BID * EMI_NTHREADS + EMI_TID;
-    if (idx >= total) return;
-    long long row = idx / nfld;
-    int f = (int)(idx - row * nfld);
+    const int nchunk = (nfld + EMI_NTHREADS - 1) / EMI_NTHREADS;
+    const long long row = EMI_BID / nchunk;
+    const int f = (int)(EMI_BID - row * nchunk) * EMI_NTHREADS + EMI_TID;
+    if (row >= nrows || f >= nfld) return;
     const int ml = g.rowm[row];
     const int m = g.mval[ml];
     int r = (int)(row - g.wbase[ml]);
