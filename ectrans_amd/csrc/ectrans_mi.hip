@@ -1244,10 +1244,9 @@ static void launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, i
   for (size_t c = 0; c < P.fclass.size(); c++) {
     FftClass &fc = P.fclass[c];
     if (fc.lats.empty() || nfld <= 0) continue;
-    static const int fft_dbg = getenv("EMI_FFT_DBG") ? atoi(getenv("EMI_FFT_DBG")) : 0;
     const int nchunk = (nfld + fc.fbk - 1) / fc.fbk;
     const long long nblocks = (long long)fc.lats.size() * nchunk;
-    FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0, fft_dbg};
+    FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0};
     const int nthr = fc.nthr;
     switch (fc.hot) {
 #define EMI_HOT_LAUNCH(pc_, S_, nf_, a_, b_, c_, d_, e_)                                                                                       \

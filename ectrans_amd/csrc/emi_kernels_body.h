@@ -404,7 +404,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
 // FFT engine in LDS (v2): in-place mixed-radix Cooley-Tukey on `nfl` fields of S complex points.
 //   DIT: input at perm[] positions -> natural output.  DIF: natural input -> output at perm[].
 //   tw[k] = exp(-2 pi i k/S); sgn=+1 conjugates.
-//   * radices 2,3,4,5,8,16 are hard-coded register butterflies; 7,11,13 use the DFT matrix from tw
+//   * radices 2,3,4,5,8 are hard-coded register butterflies; 7 uses its DFT matrix from the twiddle table
 //   * the host orders the factors so that every pass stride (lenp) of a 2-3-5-smooth size is a power
 //     of two (odd radices last in DIT order) -> no integer divisions in those passes
 //   * logical element i lives at LDS slot FPAD(i) = i ^ ((i >> 3) & 15) (XOR swizzle inside aligned
@@ -482,41 +482,6 @@ EMI_DEVFN void butterfly(real2 *v, const real2 *tw, int S, int sgn) {
       v[2 * k2] = t0[k2];
       v[2 * k2 + 1] = t1[k2];
     }
-  } else if (R == 16) {
-    // n = 4 n1 + n2, k = k1 + 4 k2, computed in place: after step 1 register 4*k1+n2 holds
-    // t[n2][k1]; after step 3 register 4*k1+k2 holds X[k1 + 4*k2] (un-permuted by the caller-side
-    // index map OUT16 below, which is static)
-    const real_t c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) {
-      real2 a0 = v[n2], a1 = v[4 + n2], a2 = v[8 + n2], a3 = v[12 + n2];
-      bf4(a0, a1, a2, a3, sgn);
-      v[n2] = a0;       // k1 = 0
-      v[4 + n2] = a1;   // k1 = 1
-      v[8 + n2] = a2;   // k1 = 2
-      v[12 + n2] = a3;  // k1 = 3
-    }
-    const real_t wc[10] = {1.0, c1, h, s1, 0.0, -s1, -h, -c1, -1.0, -c1};
-    const real_t ws[10] = {0.0, s1, h, c1, 1.0, c1, h, s1, 0.0, -s1};
-#pragma unroll
-    for (int k1 = 1; k1 < 4; k1++)
-#pragma unroll
-      for (int n2 = 1; n2 < 4; n2++) {
-        const int e = n2 * k1;
-        v[4 * k1 + n2] = cmul(v[4 * k1 + n2], mk2(wc[e], (sgn < 0) ? -ws[e] : ws[e]));
-      }
-    real2 y[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) {
-      real2 a0 = v[4 * k1], a1 = v[4 * k1 + 1], a2 = v[4 * k1 + 2], a3 = v[4 * k1 + 3];
-      bf4(a0, a1, a2, a3, sgn);
-      y[k1] = a0;
-      y[k1 + 4] = a1;
-      y[k1 + 8] = a2;
-      y[k1 + 12] = a3;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) v[u] = y[u];
   } else {
     // generic small prime (7): DFT matrix rows from the twiddle table, fully unrolled
     real2 y[R], w[R];
@@ -834,8 +799,8 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
       const int npair = sz / 2 + 1;  // k = 0..sz/2 pairs with sz-k
       for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
         const int k2 = sz - k;
-        real2 xa = (k <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
-        real2 xb = (k2 <= nmen && !(Lc.dbg & 1)) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
+        real2 xa = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
+        real2 xb = (k2 <= nmen) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
         if (Lc.adj) xa = cscale(xa, adjw), xb = cscale(xb, adjw);
         // Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}),  w = exp(+2 pi i/n)
         real2 wk = cconj(rtw[k]);
@@ -884,9 +849,6 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
       }
       return;
     }
-    if (Lc.dbg & 2) {
-      lenp = S / pl.fac[pl.nfac - 1];
-    } else
     lenp = blue_conv(a, nfl, fs, pl, T, 1, sz, 1);
   } else {
     if (pl.nfac == 0) {  // sz == 1
@@ -901,7 +863,6 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
     lenp = run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac - 1, 1, +1);
   }
   const int rl = pl.fac[pl.nfac - 1];
-  if (Lc.dbg & 4) return;
   FFT_DISPATCH(dit_last_to_grid, rl, a, nfl, fs, S, lenp, tw, (const real2 *)T.ptw + pl.ptw_off[pl.nfac - 1], pl, chirp, flds, f0, gp0, nproma);
 }
 

@@ -96,7 +96,6 @@ struct FftLaunchDev {
   long long nblocks;
   int adj;  // adjoint transforms: k_fft_dir* drop the Gaussian weight and 1/NLOEN (INV_TRANSAD, ftinvad_mod.F90:77-83),
             // k_fft_inv* apply them (DIR_TRANSAD, ledirad_mod.F90:151,183 + ftdirad_mod.F90:84-89)
-  int dbg;  // EMI_FFT_DBG (timing experiments only): 1 skip global input loads, 2 skip the LDS passes, 4 skip the output stage
 };
 
 
@@ -107,7 +106,6 @@ struct FftLaunchDev {
 #define LG_LDB 144
 #define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)  // k_leg_inv, 8-row stages; sized for fp64 (fp32 uses half)
 #define LG_LDS_BYTES_DIR (2 * LG_LDS_BYTES)                  // k_leg_dir, 16-row stages (+ its row-number tables)
-#define FFT_MAXR 16
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 
