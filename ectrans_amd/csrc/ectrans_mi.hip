@@ -1004,7 +1004,13 @@ extern "C" int emi_inq_real_array(int kresol, const char *name, double *out, int
     v = &P->rw;
   else if (s == "racthe")
     v = &P->racthe;
-  else
+  else if (s == "rlapin" || s == "plapin") {
+    // RLAPIN(-1:NSMAX+2) (pre_suleg_mod.F90:64-69): eigenvalues of the inverse Laplacian, -a^2/(n(n+1)); 0 for n <= 0
+    if (len < P->nsmax + 4) EMI_FAIL(EMI_ERR_ARG, "TRANS_INQ: PLAPIN TOO SMALL");
+    out[0] = out[1] = 0.0;
+    for (int n = 1; n <= P->nsmax + 2; n++) out[n + 1] = -(P->ra * P->ra / (double)(n * (n + 1)));
+    return EMI_SUCCESS;
+  } else
     EMI_FAIL(EMI_ERR_ARG, "emi_inq_real_array: unknown name '%s'", s.c_str());
   if (len < (int)v->size()) EMI_FAIL(EMI_ERR_ARG, "TRANS_INQ: %s TOO SMALL", s.c_str());
   std::copy(v->begin(), v->end(), out);
