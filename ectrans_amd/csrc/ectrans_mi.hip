@@ -401,7 +401,7 @@ static int build_fft_plans(Plan &P) {
     }
     // filter b_j = conj(c_|j|) wrapped to length L; Bhat = DFT_L(b) (direct O(L*sz) sum in
     // long double: setup only, keeps the table accurate to ~1e-17), stored at the DIT positions
-    const int L = pl.S;
+    const int L = pl.S, r0 = pl.fac[0];
     const uint16_t *pm = perm.data() + pl.perm_off;
     std::vector<long double> cr(L);
     for (int k = 0; k < L; k++) cr[k] = cosl(2.0L * (long double)M_PIl * (long double)k / (long double)L);
@@ -417,7 +417,10 @@ static int build_fft_plans(Plan &P) {
         sr += (long double)c[jj].x * cs;
         si += -(long double)c[jj].y * cs;
       }
-      bh[pm[k]] = d2{(double)sr, (double)si};
+      // position p = pm[k] of the DIT-ordered spectrum belongs to the middle butterfly q = p / R0 as its
+      // element t = p % R0; stored [t][q] so that a wave reads its filter values coalesced
+      const int p = pm[k];
+      bh[(size_t)(p % r0) * (L / r0) + p / r0] = d2{(double)sr, (double)si};
     }
   });
   for (int j = 0; j < P.nlat; j++) {

@@ -641,7 +641,7 @@ EMI_DEVFN void blue_middle(real2 *a, int nfl, int fs, int S, const real2 *tw, co
       const int base = q * R;
       real2 v[R], b[R];
 #pragma unroll
-      for (int t = 0; t < R; t++) b[t] = bh[base + t];  // filter values: in flight with the LDS reads
+      for (int t = 0; t < R; t++) b[t] = bh[t * nb + q];  // filter values, table [t][q]: coalesced, in flight with the LDS reads
 #pragma unroll
       for (int t = 0; t < R; t++) v[t] = (base + t < nvalid) ? af[FPAD(base + t)] : mk2(0.0, 0.0);
       butterfly<R>(v, tw, S, -1);

@@ -83,7 +83,7 @@ struct FftTabDev {
   const unsigned short *perm;  // DIT input position of natural index
   const void *rtw;             // e^{-2 pi i k/n}, k=0..sz
   const void *chirp;           // e^{-i pi k^2/sz}
-  const void *bhat;            // DFT_L of the chirp filter, at perm positions
+  const void *bhat;            // DFT_L of the chirp filter in DIT order, laid out [t][q] for the fused middle pass (q = butterfly, t = element)
   const FftPlanDev *plans;
   const int *planid;           // [ndgl]
 };
