@@ -977,6 +977,26 @@ EMI_DEVFN constexpr int hot_lenp(int pc, int ip) {  // stride of factor ip = pro
 }
 
 // forward Bluestein chain on one field: DIF passes nfac-1..1, fused middle, DIT passes 1..last-1
+// Workgroup barriers are only needed where data crosses waves.  With the butterfly -> thread map
+// q = tid + i * nthreads used by every pass, the radix-8 butterflies q = 64 w .. 64 w + 63 of wave w
+// cover exactly the points 512 w .. 512 w + 511 in every pass whose span (lenp * 8) is <= 512 -- the
+// passes of the leading factors 8, 8, 8 (lenp 1, 8, 64) and the fused middle pass.  Between two such
+// passes a wave only reads what it wrote itself, LDS instructions of one wave execute in order, and the
+// workgroup barrier becomes a wave-level fence: 4 instead of 8 barriers per transform, and the waves of
+// a workgroup drift apart so that LDS traffic of one overlaps the butterflies of another.
+template <int PC>
+EMI_DEVFN constexpr bool hot_local(int ip) {  // is the pass of factor ip wave-local (see above)?
+  return hot_plan(PC).fac[ip] == 8 && hot_lenp(PC, ip) * 8 <= 512;
+}
+#define HOT_SYNC(ipa_, ipb_)                                        \
+  do {                                                              \
+    if constexpr (hot_local<PC>(ipa_) && hot_local<PC>(ipb_))       \
+      EMI_WAVE_SYNC();                                              \
+    else                                                            \
+      EMI_SYNC();                                                   \
+  } while (0)
+
+// forward Bluestein chain on one field: DIF passes nfac-1..1, fused middle, DIT passes 1..last-1
 template <int PC, int LASTDIT>
 EMI_DEVFN void hot_conv(real2 *a, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid) {
   constexpr HotPlanC H = hot_plan(PC);
@@ -984,22 +1004,22 @@ EMI_DEVFN void hot_conv(real2 *a, int fs, const FftPlanDev &pl, const FftTabDev 
   const real2 *ptw = (const real2 *)T.ptw;
   if constexpr (H.nfac == 5) {
     fft_pass_body<H.fac[4], 1, 1, 1>(a, 1, fs, H.S, hot_lenp(PC, 4), tw, ptw + pl.ptw_off[4], -1, nvalid);
-    EMI_SYNC();
+    HOT_SYNC(4, 3);
     fft_pass_body<H.fac[3], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], -1, H.S);
   } else {
     fft_pass_body<H.fac[3], 1, 1, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], -1, nvalid);
   }
-  EMI_SYNC();
+  HOT_SYNC(3, 2);
   fft_pass_body<H.fac[2], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 2), tw, ptw + pl.ptw_off[2], -1, H.S);
-  EMI_SYNC();
+  HOT_SYNC(2, 1);
   fft_pass_body<H.fac[1], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 1), tw, ptw + pl.ptw_off[1], -1, H.S);
-  EMI_SYNC();
+  HOT_SYNC(1, 0);
   blue_middle<H.fac[0]>(a, 1, fs, H.S, tw, bh, conj_b, H.S);
-  EMI_SYNC();
+  HOT_SYNC(0, 1);
   fft_pass_body<H.fac[1], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 1), tw, ptw + pl.ptw_off[1], +1, H.S);
-  EMI_SYNC();
+  HOT_SYNC(1, 2);
   fft_pass_body<H.fac[2], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 2), tw, ptw + pl.ptw_off[2], +1, H.S);
-  EMI_SYNC();
+  HOT_SYNC(2, 3);
   if constexpr (H.nfac == 5 || LASTDIT) {
     fft_pass_body<H.fac[3], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], +1, H.S);
     EMI_SYNC();
@@ -1009,6 +1029,7 @@ EMI_DEVFN void hot_conv(real2 *a, int fs, const FftPlanDev &pl, const FftTabDev 
     EMI_SYNC();
   }
 }
+#undef HOT_SYNC
 
 template <int PC>
 EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,

@@ -30,6 +30,14 @@
 #define EMI_BID ((int)blockIdx.x)
 #define EMI_NTHREADS ((int)blockDim.x)
 #define EMI_SYNC() __syncthreads()
+// ordering of LDS accesses WITHIN one wave (its LDS instructions execute in order): a compiler fence is
+// all that is needed between a pass that wrote and a pass that reads the same wave-private LDS block
+#define EMI_WAVE_SYNC()                                   \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
 #define EMI_LDS_DECL extern __shared__ __attribute__((aligned(16))) char emi_lds_raw[]
 #define EMI_LDS_PTR (emi_lds_raw)
 
@@ -84,6 +92,7 @@ static inline void emu_barrier() {
 #pragma omp barrier
 }
 #define EMI_SYNC() emu_barrier()
+#define EMI_WAVE_SYNC() emu_barrier()  // lanes are threads here: a real barrier
 #define EMI_LDS_DECL
 #define EMI_LDS_PTR (emu_ctx->lds)
 
