@@ -1,0 +1,177 @@
+// Where does k_leg_inv's main loop lose its MFMA throughput?  The loop of ectrans_amd/csrc/emi_kernels_body.h
+// (tile 64 x 128, both parities, 8-row stages, 32 MFMAs per wave and stage) rebuilt piece by piece:
+//   V0 MFMAs only | V1 + LDS fragment reads | V2 + the two barriers per stage | V3 + the LDS tile writes
+//   V4 + global prefetch of the next stage (coalesced reads of a 1 GiB buffer) | V5 the same, two stages ahead
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/probe tools/leg_loop_probe.hip && /tmp/probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+#define LDA 80
+#define LDB 144
+
+template <int V>
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(2, 2))) void probe(double *out, const double *src, int nst, long long stride) {
+  extern __shared__ double lds[];
+  double *As = lds, *Bs = lds + 2 * 8 * LDA;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
+  for (int i = tid; i < 2 * 8 * LDA + 2 * 8 * LDB; i += 256) lds[i] = 1.0 + 1e-9 * i;
+  __syncthreads();
+  v4d acc[2][2][4];
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) acc[p][i][j] = (v4d){0, 0, 0, 0};
+  const int arow = tid >> 5, ac2 = tid & 31, brow = tid >> 6, bc2 = tid & 63;
+  const double *g = src + (long long)blockIdx.x * 4096 + tid * 2;
+  d2 ra0 = {1, 2}, ra1 = {3, 4}, rb0 = {5, 6}, rb1 = {7, 8}, rb2 = {9, 10}, rb3 = {11, 12};
+  d2 qa0 = ra0, qa1 = ra1, qb0 = rb0, qb1 = rb1, qb2 = rb2, qb3 = rb3;
+  double a0 = 1.0 + 1e-9 * l, b0 = 1.0 - 1e-9 * l;
+  for (int s = 0; s < nst; s++) {
+    if (V >= 2 && s > 0) __syncthreads();
+    if (V >= 3) {
+      const bool alt = (V == 5) && !(s & 1);  // V5: store the set loaded two stages ago
+      *(d2 *)(As + (0 * 8 + arow) * LDA + 2 * ac2) = alt ? qa0 : ra0;
+      *(d2 *)(As + (1 * 8 + arow) * LDA + 2 * ac2) = alt ? qa1 : ra1;
+      *(d2 *)(Bs + (((brow + 0) & 1) * 8 + ((brow + 0) >> 1)) * LDB + 2 * bc2) = alt ? qb0 : rb0;
+      *(d2 *)(Bs + (((brow + 4) & 1) * 8 + ((brow + 4) >> 1)) * LDB + 2 * bc2) = alt ? qb1 : rb1;
+      *(d2 *)(Bs + (((brow + 8) & 1) * 8 + ((brow + 8) >> 1)) * LDB + 2 * bc2) = alt ? qb2 : rb2;
+      *(d2 *)(Bs + (((brow + 12) & 1) * 8 + ((brow + 12) >> 1)) * LDB + 2 * bc2) = alt ? qb3 : rb3;
+    }
+    if (V >= 2) __syncthreads();
+    if (V == 4 || V == 6) {
+      const double *q = g + (V == 6 ? 0 : (long long)s * stride);  // V6: the same lines every stage (cache hits)
+      ra0 = *(const d2 *)q, ra1 = *(const d2 *)(q + 512), rb0 = *(const d2 *)(q + 1024), rb1 = *(const d2 *)(q + 1536);
+      rb2 = *(const d2 *)(q + 2048), rb3 = *(const d2 *)(q + 2560);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads here, ahead of the MFMAs (the compiler would sink them)
+    }
+    if (V == 5) {  // two stages ahead: two register sets used alternately (the store above takes the older one)
+      const double *q = g + (long long)s * stride;
+      if (s & 1) {
+        qa0 = *(const d2 *)q, qa1 = *(const d2 *)(q + 512), qb0 = *(const d2 *)(q + 1024), qb1 = *(const d2 *)(q + 1536);
+        qb2 = *(const d2 *)(q + 2048), qb3 = *(const d2 *)(q + 2560);
+      } else {
+        ra0 = *(const d2 *)q, ra1 = *(const d2 *)(q + 512), rb0 = *(const d2 *)(q + 1024), rb1 = *(const d2 *)(q + 1536);
+        rb2 = *(const d2 *)(q + 2048), rb3 = *(const d2 *)(q + 2560);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int kk = 4 * ks + (l >> 4);
+        double a[2], b[4];
+        if (V >= 1) {
+#pragma unroll
+          for (int i = 0; i < 2; i++) a[i] = As[(p * 8 + kk) * LDA + wm * 32 + i * 16 + (l & 15)];
+#pragma unroll
+          for (int j = 0; j < 4; j++) b[j] = Bs[(p * 8 + kk) * LDB + wn * 64 + j * 16 + (l & 15)];
+        } else {
+          a[0] = a[1] = a0;
+          b[0] = b[1] = b[2] = b[3] = b0;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[p][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[p][i][j], 0, 0, 0);
+      }
+  }
+  double sum = ra0.x + rb3.y + qa0.x + qb3.y;
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
+  out[(long long)blockIdx.x * 256 + tid] = sum;
+}
+
+
+// two-stage-ahead prefetch done properly: the stage loop unrolled by two, register sets X and Y used
+// alternately (stage s stores the set loaded during stage s-2 and reloads it for stage s+2)
+#define PROBE_STAGE(SA0, SA1, SB0, SB1, SB2, SB3)                                                         \
+  {                                                                                                       \
+    if (s > 0) __syncthreads();                                                                           \
+    *(d2 *)(As + (0 * 8 + arow) * LDA + 2 * ac2) = SA0;                                                   \
+    *(d2 *)(As + (1 * 8 + arow) * LDA + 2 * ac2) = SA1;                                                   \
+    *(d2 *)(Bs + (((brow + 0) & 1) * 8 + ((brow + 0) >> 1)) * LDB + 2 * bc2) = SB0;                       \
+    *(d2 *)(Bs + (((brow + 4) & 1) * 8 + ((brow + 4) >> 1)) * LDB + 2 * bc2) = SB1;                       \
+    *(d2 *)(Bs + (((brow + 8) & 1) * 8 + ((brow + 8) >> 1)) * LDB + 2 * bc2) = SB2;                       \
+    *(d2 *)(Bs + (((brow + 12) & 1) * 8 + ((brow + 12) >> 1)) * LDB + 2 * bc2) = SB3;                     \
+    __syncthreads();                                                                                      \
+    {                                                                                                     \
+      const double *q = g + (long long)s * stride;                                                        \
+      SA0 = *(const d2 *)q, SA1 = *(const d2 *)(q + 512), SB0 = *(const d2 *)(q + 1024), SB1 = *(const d2 *)(q + 1536); \
+      SB2 = *(const d2 *)(q + 2048), SB3 = *(const d2 *)(q + 2560);                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < 2; p++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {      \
+      const int kk = 4 * ks + (l >> 4);                                                                   \
+      double a[2], b[4];                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 2; i++) a[i] = As[(p * 8 + kk) * LDA + wm * 32 + i * 16 + (l & 15)];   \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) b[j] = Bs[(p * 8 + kk) * LDB + wn * 64 + j * 16 + (l & 15)];   \
+      _Pragma("unroll") for (int i = 0; i < 2; i++) _Pragma("unroll") for (int j = 0; j < 4; j++)         \
+        acc[p][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[p][i][j], 0, 0, 0);           \
+    }                                                                                                     \
+  }
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(2, 2))) void probe2(double *out, const double *src, int nst, long long stride) {
+  extern __shared__ double lds[];
+  double *As = lds, *Bs = lds + 2 * 8 * LDA;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
+  for (int i = tid; i < 2 * 8 * LDA + 2 * 8 * LDB; i += 256) lds[i] = 1.0 + 1e-9 * i;
+  __syncthreads();
+  v4d acc[2][2][4];
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) acc[p][i][j] = (v4d){0, 0, 0, 0};
+  const int arow = tid >> 5, ac2 = tid & 31, brow = tid >> 6, bc2 = tid & 63;
+  const double *g = src + (long long)blockIdx.x * 4096 + tid * 2;
+  d2 xa0 = {1, 2}, xa1 = {3, 4}, xb0 = {5, 6}, xb1 = {7, 8}, xb2 = {9, 10}, xb3 = {11, 12};
+  d2 ya0 = xa0, ya1 = xa1, yb0 = xb0, yb1 = xb1, yb2 = xb2, yb3 = xb3;
+  for (int s = 0; s < nst; s += 2) {
+    PROBE_STAGE(xa0, xa1, xb0, xb1, xb2, xb3)
+    s++;
+    PROBE_STAGE(ya0, ya1, yb0, yb1, yb2, yb3)
+    s--;
+  }
+  double sum = xa0.x + xb3.y + ya0.x + yb3.y;
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
+  out[(long long)blockIdx.x * 256 + tid] = sum;
+}
+
+template <int V>
+static void run(double *out, const double *src, const char *what) {
+  const int nblk = 256 * 2 * 8, nst = 80;  // 16 tiles per CU-slot, K = 640 n-pairs
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; rep++) {
+    hipEventRecord(e0, 0);
+    if (V == 7)
+      hipLaunchKernelGGL(probe2, dim3(nblk), dim3(256), (2 * 8 * LDA + 2 * 8 * LDB) * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
+    else
+      hipLaunchKernelGGL(probe<V>, dim3(nblk), dim3(256), (2 * 8 * LDA + 2 * 8 * LDB) * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  double flops = (double)nblk * 4 * nst * 32 * 2048.0;
+  printf("V%d %-44s %6.1f TFLOP/s  (%.1f %% of 78.6)\n", V, what, flops / best / 1e9, 100 * flops / best / 1e9 / 78.6);
+}
+
+int main() {
+  double *out, *src;
+  hipMalloc((void **)&out, (size_t)4096 * 256 * 8);
+  hipMalloc((void **)&src, (size_t)1 << 30);
+  hipMemset(src, 0, (size_t)1 << 30);
+  run<0>(out, src, "MFMAs only");
+  run<1>(out, src, "+ LDS fragment reads");
+  run<2>(out, src, "+ two barriers per stage");
+  run<3>(out, src, "+ LDS tile writes");
+  run<4>(out, src, "+ global prefetch of the next stage");
+  run<5>(out, src, "+ global prefetch two stages ahead");
+  run<6>(out, src, "V4 with the same lines every stage (hits)");
+  run<7>(out, src, "V4 two stages ahead, loop unrolled by two");
+  return 0;
+}
