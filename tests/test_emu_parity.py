@@ -112,6 +112,22 @@ def test_adjoint_refuses_derivative_options(et):
         et.trans_release(r)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_reduced_grids_match_oracle(et, seed):
+    """Random reduced grids (row lengths of any parity and factorisation), truncations, field counts, options
+    and NPROMA against the oracle (the GPU tier runs 40 of these)."""
+    rng = np.random.default_rng(2000 + seed)
+    nh = int(rng.integers(3, 7))
+    half = np.sort(rng.integers(8, 120, nh))
+    nloen = np.concatenate([half, half[::-1]]).astype(np.int32)
+    nsmax = int(rng.integers(2, 2 * nh))
+    nuv, nsc = int(rng.integers(0, 2)), int(rng.integers(1, 3))
+    flags = dict(scders=bool(rng.integers(2)), uvder=bool(rng.integers(2)) and nuv > 0, vorgp=bool(rng.integers(2)) and nuv > 0)
+    nproma = [None, 17, 100][int(rng.integers(3))]
+    e_inv, e_dir = run_case(et, Oracle, XP, nsmax, nloen, nuv, nsc, flags, nproma, seed=seed)
+    assert e_inv < TOL and e_dir < TOL, (nloen.tolist(), nsmax, nuv, nsc, flags, nproma, e_inv, e_dir)
+
+
 def test_fp32_library_rejects_double_arrays(et):
     nloen = octahedral(7)
     r = et.setup_trans(7, len(nloen), nloen, precision=4)

@@ -182,6 +182,26 @@ def test_adjoint_transforms_dot_product(et, dev, case):
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_reduced_grids_match_oracle(et, dev, seed):
+    """Random reduced grids (row lengths of any parity and factorisation, 8 ... 700 points, symmetric
+    about the equator), truncations, field counts, options and NPROMA against the oracle."""
+    from oracle.oracle import Oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    nh = int(rng.integers(4, 14))
+    half = np.sort(rng.integers(8, 700, nh))
+    nloen = np.concatenate([half, half[::-1]]).astype(np.int32)
+    nsmax = int(rng.integers(2, 2 * nh))
+    nuv, nsc = int(rng.integers(0, 3)), int(rng.integers(0, 4))
+    if nuv + nsc == 0:
+        nsc = 1
+    flags = dict(scders=bool(rng.integers(2)) and nsc > 0, uvder=bool(rng.integers(2)) and nuv > 0,
+                 vorgp=bool(rng.integers(2)) and nuv > 0, divgp=bool(rng.integers(2)) and nuv > 0)
+    nproma = [None, 17, 100, 1000][int(rng.integers(4))]
+    e_inv, e_dir = run_case(et, O, dev, nsmax, nloen, nuv, nsc, flags, nproma, seed=seed)
+    assert e_inv < TOL and e_dir < TOL, (nloen.tolist(), nsmax, nuv, nsc, flags, nproma, e_inv, e_dir)
+
+
 def test_host_arrays_match_oracle(et):
     """EMI_MEM_HOST: numpy arrays staged over PCIe, as a Fortran/C caller would pass them."""
     from oracle.oracle import Oracle as O
