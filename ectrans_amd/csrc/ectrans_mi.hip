@@ -325,14 +325,14 @@ static int build_fft_plans(Plan &P) {
     if (ft && atoi(ft) >= 64) nthr = std::min(1024, roundup(atoi(ft), 64));
     // specialised kernel for this work length?  (Bluestein, even NLOEN, one field per workgroup)
     int hot = 0;
-    if (pl.blue && !pl.cmode && fbk == 1 && !getenv("EMI_FFT_NO_HOT")) {
-      static const int hp[][8] = {
-#define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_) {pc_, S_, nf_, a_, b_, c_, d_, e_},
+    if (pl.blue && !pl.cmode && !getenv("EMI_FFT_NO_HOT")) {
+      static const int hp[][9] = {
+#define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_) {pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_},
           EMI_HOT_PLAN_LIST(EMI_HOT_ROW)
 #undef EMI_HOT_ROW
       };
       for (const auto &r : hp) {
-        bool same = r[1] == pl.S && r[2] == pl.nfac;
+        bool same = r[1] == pl.S && r[2] == pl.nfac && r[8] == fbk;
         for (int i = 0; same && i < pl.nfac; i++) same = r[3 + i] == pl.fac[i];
         if (same) hot = r[0];
       }
@@ -1258,7 +1258,7 @@ static void launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, i
     FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0};
     const int nthr = fc.nthr;
     switch (fc.hot) {
-#define EMI_HOT_LAUNCH(pc_, S_, nf_, a_, b_, c_, d_, e_)                                                                                       \
+#define EMI_HOT_LAUNCH(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_)                                                                                       \
   case pc_:                                                                                                                                    \
     if (inverse)                                                                                                                               \
       EMI_LAUNCH_P(P.esz, k_fft_inv_hot<pc_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);         \
@@ -1371,7 +1371,7 @@ static int set_lds_attrs() {
   if (done) return 0;
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_leg_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_leg_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-#define EMI_HOT_ATTR(pc_, S_, nf_, a_, b_, c_, d_, e_)                                                                                  \
+#define EMI_HOT_ATTR(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_)                                                                                  \
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv_hot<pc_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir_hot<pc_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv_hot<pc_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \

@@ -959,15 +959,15 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
 // dispatch, no plan loops, a fraction of the scalar registers -- so nothing spills.
 // ==========================================================================================
 struct HotPlanC {
-  int S, nfac, fac[5];
+  int S, nfac, fac[5], nfl;
 };
 EMI_DEVFN constexpr HotPlanC hot_plan(int pc) {
   switch (pc) {
-#define EMI_HOT_CASE(pc_, S_, nf_, a_, b_, c_, d_, e_) \
-  case pc_: return {S_, nf_, {a_, b_, c_, d_, e_}};
+#define EMI_HOT_CASE(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_) \
+  case pc_: return {S_, nf_, {a_, b_, c_, d_, e_}, nfl_};
     EMI_HOT_PLAN_LIST(EMI_HOT_CASE)
 #undef EMI_HOT_CASE
-    default: return {0, 0, {1, 1, 1, 1, 1}};
+    default: return {0, 0, {1, 1, 1, 1, 1}, 1};
   }
 }
 EMI_DEVFN constexpr int hot_lenp(int pc, int ip) {  // stride of factor ip = product of the factors before it
@@ -996,38 +996,41 @@ EMI_DEVFN constexpr bool hot_local(int ip) {  // is the pass of factor ip wave-l
       EMI_SYNC();                                                   \
   } while (0)
 
-// forward Bluestein chain on one field: DIF passes nfac-1..1, fused middle, DIT passes 1..last-1
+// Bluestein convolution chain on the nfl fields of a workgroup: DIF passes nfac-1..1, fused middle, DIT
+// passes 1..nfac-2 (or all of them when LASTDIT), as compile-time recursions over the factor index
+template <int PC, int IP>
+EMI_DEVFN void hot_dif(real2 *a, int nfl, int fs, const FftPlanDev &pl, const real2 *tw, const real2 *ptw, int nvalid) {
+  constexpr HotPlanC H = hot_plan(PC);
+  if constexpr (IP >= 1) {
+    if constexpr (IP == H.nfac - 1)
+      fft_pass_body<H.fac[IP], 1, 1, 1>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, nvalid);
+    else
+      fft_pass_body<H.fac[IP], 1, 0, 1>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, H.S);
+    HOT_SYNC(IP, IP - 1);
+    hot_dif<PC, IP - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
+  }
+}
+template <int PC, int IP, int END>
+EMI_DEVFN void hot_dit(real2 *a, int nfl, int fs, const FftPlanDev &pl, const real2 *tw, const real2 *ptw) {
+  constexpr HotPlanC H = hot_plan(PC);
+  if constexpr (IP < END) {
+    fft_pass_body<H.fac[IP], 0, 0, 1>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], +1, H.S);
+    if constexpr (IP + 1 < H.nfac)
+      HOT_SYNC(IP, IP + 1);
+    else
+      EMI_SYNC();
+    hot_dit<PC, IP + 1, END>(a, nfl, fs, pl, tw, ptw);
+  }
+}
 template <int PC, int LASTDIT>
-EMI_DEVFN void hot_conv(real2 *a, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid) {
+EMI_DEVFN void hot_conv(real2 *a, int nfl, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid) {
   constexpr HotPlanC H = hot_plan(PC);
   const real2 *tw = (const real2 *)T.tw + pl.tw_off, *bh = (const real2 *)T.bhat + pl.bhat_off;
   const real2 *ptw = (const real2 *)T.ptw;
-  if constexpr (H.nfac == 5) {
-    fft_pass_body<H.fac[4], 1, 1, 1>(a, 1, fs, H.S, hot_lenp(PC, 4), tw, ptw + pl.ptw_off[4], -1, nvalid);
-    HOT_SYNC(4, 3);
-    fft_pass_body<H.fac[3], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], -1, H.S);
-  } else {
-    fft_pass_body<H.fac[3], 1, 1, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], -1, nvalid);
-  }
-  HOT_SYNC(3, 2);
-  fft_pass_body<H.fac[2], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 2), tw, ptw + pl.ptw_off[2], -1, H.S);
-  HOT_SYNC(2, 1);
-  fft_pass_body<H.fac[1], 1, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 1), tw, ptw + pl.ptw_off[1], -1, H.S);
-  HOT_SYNC(1, 0);
-  blue_middle<H.fac[0]>(a, 1, fs, H.S, tw, bh, conj_b, H.S);
+  hot_dif<PC, H.nfac - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
+  blue_middle<H.fac[0]>(a, nfl, fs, H.S, tw, bh, conj_b, H.S);
   HOT_SYNC(0, 1);
-  fft_pass_body<H.fac[1], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 1), tw, ptw + pl.ptw_off[1], +1, H.S);
-  HOT_SYNC(1, 2);
-  fft_pass_body<H.fac[2], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 2), tw, ptw + pl.ptw_off[2], +1, H.S);
-  HOT_SYNC(2, 3);
-  if constexpr (H.nfac == 5 || LASTDIT) {
-    fft_pass_body<H.fac[3], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 3), tw, ptw + pl.ptw_off[3], +1, H.S);
-    EMI_SYNC();
-  }
-  if constexpr (H.nfac == 5 && LASTDIT) {
-    fft_pass_body<H.fac[4], 0, 0, 1>(a, 1, fs, H.S, hot_lenp(PC, 4), tw, ptw + pl.ptw_off[4], +1, H.S);
-    EMI_SYNC();
-  }
+  hot_dit<PC, 1, LASTDIT ? H.nfac : H.nfac - 1>(a, nfl, fs, pl, tw, ptw);
 }
 #undef HOT_SYNC
 
@@ -1041,7 +1044,8 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   const int li = bid / Lc.nchunk;
   const int lat = Lc.lats[li];
   const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = bid - li * Lc.nchunk;  // one field per workgroup
+  const int f0 = (bid - li * Lc.nchunk) * H.nfl;  // H.nfl fields per workgroup
+  const int nfl = (nfld - f0) < H.nfl ? (nfld - f0) : H.nfl;
   const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
   constexpr int fs = FFT_LDS_ELEMS(H.S);
   const real_t racthe = (real_t)g.racthe[lat];
@@ -1050,9 +1054,10 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
   const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
   const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
-  const GridFld gf = flds[f0];
   // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times the chirp
-  {
+  for (int fl = 0; fl < nfl; fl++) {
+    const GridFld gf = flds[f0 + fl];
+    real2 *a = (real2 *)EMI_LDS_PTR + (long long)fl * fs;
     const int npair = sz / 2 + 1;
     for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
       const int k2 = sz - k;
@@ -1071,9 +1076,9 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
     }
   }
   EMI_SYNC();
-  hot_conv<PC, 0>(a, fs, pl, T, 1, sz);
+  hot_conv<PC, 0>(a, nfl, fs, pl, T, 1, sz);
   constexpr int last = H.nfac - 1;
-  dit_last_to_grid<H.fac[last]>(a, 1, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
+  dit_last_to_grid<H.fac[last]>(a, nfl, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
                                 (const real2 *)T.ptw + pl.ptw_off[last], pl, chirp, flds, f0, g.gpoff[lat], nproma);
   (void)n;
 }
@@ -1088,16 +1093,18 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
   const int li = bid / Lc.nchunk;
   const int lat = Lc.lats[li];
   const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = bid - li * Lc.nchunk;
+  const int f0 = (bid - li * Lc.nchunk) * H.nfl;
+  const int nfl = (nfld - f0) < H.nfl ? (nfld - f0) : H.nfl;
   const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
   constexpr int fs = FFT_LDS_ELEMS(H.S);
   const int fb0 = g.fbase[lat];
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
   const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
   const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
-  const GridFld gf = flds[f0];
   // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp
-  {
+  for (int fl = 0; fl < nfl; fl++) {
+    const GridFld gf = flds[f0 + fl];
+    real2 *a = (real2 *)EMI_LDS_PTR + (long long)fl * fs;
     const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
     for (int lz = EMI_TID; lz < sz; lz += EMI_NTHREADS) {
@@ -1114,9 +1121,12 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
     }
   }
   EMI_SYNC();
-  hot_conv<PC, 1>(a, fs, pl, T, 0, sz);
+  hot_conv<PC, 1>(a, nfl, fs, pl, T, 0, sz);
   // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
   const real_t invL = (real_t)(1.0 / (double)H.S);
+  for (int fl = 0; fl < nfl; fl++) {
+  const GridFld gf = flds[f0 + fl];
+  const real2 *a = (const real2 *)EMI_LDS_PTR + (long long)fl * fs;
   const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * ((gf.mode == GM_ACOS) ? (real_t)g.racthe[lat] : (real_t)1.0);
   for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
     const int kb = (k == 0) ? 0 : sz - k;
@@ -1126,7 +1136,8 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
     real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
     real2 t = cmuli(cmul(rtw[k], d1));
     real2 x = mk2((real_t)0.5 * (s1.x - t.x), (real_t)0.5 * (s1.y - t.y));
-    *(real2 *)(FB + (long long)FROW(k) * ldf + 2 * f0) = cscale(x, sc);
+    *(real2 *)(FB + (long long)FROW(k) * ldf + 2 * (f0 + fl)) = cscale(x, sc);
+  }
   }
 }
 

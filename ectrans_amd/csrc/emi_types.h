@@ -109,19 +109,30 @@ struct FftLaunchDev {
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 
-// Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors...); 1-8 carry
-// TCo1279, 9-12 the longer rows of TCo2559 (fp32: up to 10240 points fit the LDS).  The factor
-// lists are what emi::factorize_smooth yields for S (checked when a plan is matched).
-#define EMI_HOT_PLAN_LIST(X)      \
-  X(1, 2048, 4, 8, 8, 8, 4, 1)    \
-  X(2, 2560, 4, 8, 8, 8, 5, 1)    \
-  X(3, 3072, 5, 8, 8, 8, 2, 3)    \
-  X(4, 4096, 4, 8, 8, 8, 8, 1)    \
-  X(5, 4608, 5, 8, 8, 8, 3, 3)    \
-  X(6, 5120, 5, 8, 8, 8, 2, 5)    \
-  X(7, 1536, 4, 8, 8, 8, 3, 1)    \
-  X(8, 1280, 4, 8, 8, 4, 5, 1)    \
-  X(9, 6144, 5, 8, 8, 8, 4, 3)    \
-  X(10, 7680, 5, 8, 8, 8, 3, 5)   \
-  X(11, 8192, 5, 8, 8, 8, 8, 2)   \
-  X(12, 10240, 5, 8, 8, 8, 4, 5)
+// Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors[5], fields per
+// workgroup).  The factor lists are what emi::factorize_smooth yields for S and the field count what the
+// 40-KiB rule gives in fp64 (both checked when a plan is matched).  1-8: the rows that carry TCo1279;
+// 9-12: the longer rows of TCo2559 (fp32: up to 10240 points fit the LDS); 13-21: the short rows, several
+// fields per workgroup (most of TCo399).
+#define EMI_HOT_PLAN_LIST(X)          \
+  X(1, 2048, 4, 8, 8, 8, 4, 1, 1)     \
+  X(2, 2560, 4, 8, 8, 8, 5, 1, 1)     \
+  X(3, 3072, 5, 8, 8, 8, 2, 3, 1)     \
+  X(4, 4096, 4, 8, 8, 8, 8, 1, 1)     \
+  X(5, 4608, 5, 8, 8, 8, 3, 3, 1)     \
+  X(6, 5120, 5, 8, 8, 8, 2, 5, 1)     \
+  X(7, 1536, 4, 8, 8, 8, 3, 1, 1)     \
+  X(8, 1280, 4, 8, 8, 4, 5, 1, 2)     \
+  X(9, 6144, 5, 8, 8, 8, 4, 3, 1)     \
+  X(10, 7680, 5, 8, 8, 8, 3, 5, 1)    \
+  X(11, 8192, 5, 8, 8, 8, 8, 2, 1)    \
+  X(12, 10240, 5, 8, 8, 8, 4, 5, 1)   \
+  X(13, 1024, 4, 8, 8, 8, 2, 1, 2)    \
+  X(14, 960, 4, 8, 8, 3, 5, 1, 2)     \
+  X(15, 768, 4, 8, 8, 4, 3, 1, 2)     \
+  X(16, 640, 4, 8, 8, 2, 5, 1, 4)     \
+  X(17, 576, 4, 8, 8, 3, 3, 1, 4)     \
+  X(18, 512, 3, 8, 8, 8, 1, 1, 4)     \
+  X(19, 384, 4, 8, 8, 2, 3, 1, 4)     \
+  X(20, 320, 3, 8, 8, 5, 1, 1, 8)     \
+  X(21, 256, 3, 8, 8, 4, 1, 1, 8)

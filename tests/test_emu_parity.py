@@ -61,13 +61,16 @@ HOT_B = [1276, 1532, 2044, 2556, 3068, 4092, 4604, 5116]  # ... and the last one
 
 
 HOT_C = [5124, 6140, 6148, 7676, 7684, 8188, 8196, 10236]  # TCo2559 rows: work lengths 6144 ... 10240
+HOT_D = [194, 258, 322, 386, 514, 578, 642, 770, 962, 1026]  # short rows, 2 ... 8 fields per workgroup: work lengths 256 ... 1280
+HOT_E = [254, 318, 382, 510, 574, 638, 766, 958, 1022, 1278]  # ... and the last row length of each
 
 
-@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4), (HOT_C, 4)])
+@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4), (HOT_C, 4), (HOT_D, 8), (HOT_E, 8)])
 def test_specialised_fft_kernels_match_oracle(et, half, precision):
     """k_fft_inv_hot / k_fft_dir_hot (work lengths 1280 ... 5120, the rows that carry TCo1279): a
     16-latitude grid whose rows select each of them, against the oracle."""
-    e_inv, e_dir = run_case(et, Oracle, XP, 15, half + half[::-1], 1, 1, dict(scders=True), None, precision=precision)
+    nuv, nsc = (1, 1) if half[0] > 1000 else (2, 7)  # short rows: 13 Fourier fields = ragged chunks of 2, 4 and 8
+    e_inv, e_dir = run_case(et, Oracle, XP, 15, half + half[::-1], nuv, nsc, dict(scders=True), None, precision=precision)
     tol = TOL if precision == 8 else 2e-5
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
