@@ -517,52 +517,66 @@ EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_cl
 // The R-1 twiddles W_len^{j t} are fetched into registers first -- coalesced reads of the per-pass
 // table [t-1][j], all in flight together with the LDS reads -- and applied before (DIT) or after
 // (DIF) the butterfly.
+// one butterfly q of one field
 template <int R, int DIF, int MASK, int TW>
+EMI_DEVFN void fft_bfly_at(real2 *af, int q, int S, int lenp, int sh, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
+  const int len = lenp * R;
+  int blk, j;
+  if (R == 2 || R == 4 || R == 8) {  // power-of-two radices come first: their lenp is a power of two
+    blk = q >> sh;
+    j = q & (lenp - 1);
+  } else {
+    split_q(q, lenp, sh, blk, j);
+  }
+  const int base = blk * len + j;
+  real2 w[R];
+  if (TW) {
+    const real2 *pw_ = ptw + j;
+#pragma unroll
+    for (int t = 1; t < R; t++) w[t] = pw_[(t - 1) * lenp];
+  }
+  real2 v[R];
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+    const int i = base + t * lenp;
+    if (MASK)
+      v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
+    else
+      v[t] = af[FPAD(i)];
+  }
+  if (TW) {
+    if (sgn > 0) {
+#pragma unroll
+      for (int t = 1; t < R; t++) w[t].y = -w[t].y;
+    }
+  }
+  if (TW && !DIF) {
+#pragma unroll
+    for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
+  }
+  butterfly<R>(v, tw, S, sgn);
+  if (TW && DIF) {
+#pragma unroll
+    for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
+}
+// FLAT = 0: field after field, butterfly q = tid + i * nthreads of each (long rows: every sweep is full
+// anyway).  FLAT = 1: the (field, butterfly) pairs of the workgroup are dealt to the threads as one list,
+// so short rows (fewer butterflies than threads) still fill the sweeps.
+template <int R, int DIF, int MASK, int TW, int FLAT = 0>
 EMI_DEVFN void fft_pass_body(real2 *a, int nfl, int fstride, int S, int lenp, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
-  const int len = lenp * R, nb = S / R, sh = log2_exact(lenp);
-  for (int fl = 0; fl < nfl; fl++) {
-    real2 *af = a + (long long)fl * fstride;
-    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
-      int blk, j;
-      if (R == 2 || R == 4 || R == 8) {  // power-of-two radices come first: their lenp is a power of two
-        blk = q >> sh;
-        j = q & (lenp - 1);
-      } else {
-        split_q(q, lenp, sh, blk, j);
-      }
-      const int base = blk * len + j;
-      real2 w[R];
-      if (TW) {
-        const real2 *pw_ = ptw + j;
-#pragma unroll
-        for (int t = 1; t < R; t++) w[t] = pw_[(t - 1) * lenp];
-      }
-      real2 v[R];
-#pragma unroll
-      for (int t = 0; t < R; t++) {
-        const int i = base + t * lenp;
-        if (MASK)
-          v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
-        else
-          v[t] = af[FPAD(i)];
-      }
-      if (TW) {
-        if (sgn > 0) {
-#pragma unroll
-          for (int t = 1; t < R; t++) w[t].y = -w[t].y;
-        }
-      }
-      if (TW && !DIF) {
-#pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
-      }
-      butterfly<R>(v, tw, S, sgn);
-      if (TW && DIF) {
-#pragma unroll
-        for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
-      }
-#pragma unroll
-      for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
+  const int nb = S / R, sh = log2_exact(lenp);
+  if (FLAT) {
+    for (int idx = EMI_TID; idx < nfl * nb; idx += EMI_NTHREADS) {
+      const int fl = idx / nb, q = idx - fl * nb;
+      fft_bfly_at<R, DIF, MASK, TW>(a + (long long)fl * fstride, q, S, lenp, sh, tw, ptw, sgn, nvalid);
+    }
+  } else {
+    for (int fl = 0; fl < nfl; fl++) {
+      real2 *af = a + (long long)fl * fstride;
+      for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) fft_bfly_at<R, DIF, MASK, TW>(af, q, S, lenp, sh, tw, ptw, sgn, nvalid);
     }
   }
 }
@@ -633,23 +647,32 @@ EMI_DEVFN void run_dif(real2 *a, int nfl, int fs, int S, const FftPlanDev &pl, c
 
 // Bluestein middle: last DIF pass (radix fac[0], contiguous runs) * filter * first DIT pass
 template <int R>
+EMI_DEVFN void blue_middle_at(real2 *af, int q, int nb, int S, const real2 *tw, const real2 *bh, int conj_b, int nvalid) {
+  const int base = q * R;
+  real2 v[R], b[R];
+#pragma unroll
+  for (int t = 0; t < R; t++) b[t] = bh[t * nb + q];  // filter values, table [t][q]: coalesced, in flight with the LDS reads
+#pragma unroll
+  for (int t = 0; t < R; t++) v[t] = (base + t < nvalid) ? af[FPAD(base + t)] : mk2(0.0, 0.0);
+  butterfly<R>(v, tw, S, -1);
+#pragma unroll
+  for (int t = 0; t < R; t++) v[t] = conj_b ? cmulc(v[t], b[t]) : cmul(v[t], b[t]);
+  butterfly<R>(v, tw, S, +1);
+#pragma unroll
+  for (int t = 0; t < R; t++) af[FPAD(base + t)] = v[t];
+}
+template <int R, int FLAT = 0>
 EMI_DEVFN void blue_middle(real2 *a, int nfl, int fs, int S, const real2 *tw, const real2 *bh, int conj_b, int nvalid) {
   const int nb = S / R;
-  for (int fl = 0; fl < nfl; fl++) {
-    real2 *af = a + (long long)fl * fs;
-    for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
-      const int base = q * R;
-      real2 v[R], b[R];
-#pragma unroll
-      for (int t = 0; t < R; t++) b[t] = bh[t * nb + q];  // filter values, table [t][q]: coalesced, in flight with the LDS reads
-#pragma unroll
-      for (int t = 0; t < R; t++) v[t] = (base + t < nvalid) ? af[FPAD(base + t)] : mk2(0.0, 0.0);
-      butterfly<R>(v, tw, S, -1);
-#pragma unroll
-      for (int t = 0; t < R; t++) v[t] = conj_b ? cmulc(v[t], b[t]) : cmul(v[t], b[t]);
-      butterfly<R>(v, tw, S, +1);
-#pragma unroll
-      for (int t = 0; t < R; t++) af[FPAD(base + t)] = v[t];
+  if (FLAT) {
+    for (int idx = EMI_TID; idx < nfl * nb; idx += EMI_NTHREADS) {
+      const int fl = idx / nb, q = idx - fl * nb;
+      blue_middle_at<R>(a + (long long)fl * fs, q, nb, S, tw, bh, conj_b, nvalid);
+    }
+  } else {
+    for (int fl = 0; fl < nfl; fl++) {
+      real2 *af = a + (long long)fl * fs;
+      for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) blue_middle_at<R>(af, q, nb, S, tw, bh, conj_b, nvalid);
     }
   }
 }
@@ -986,7 +1009,9 @@ EMI_DEVFN constexpr int hot_lenp(int pc, int ip) {  // stride of factor ip = pro
 // a workgroup drift apart so that LDS traffic of one overlaps the butterflies of another.
 template <int PC>
 EMI_DEVFN constexpr bool hot_local(int ip) {  // is the pass of factor ip wave-local (see above)?
-  return hot_plan(PC).fac[ip] == 8 && hot_lenp(PC, ip) * 8 <= 512;
+  // with several fields per workgroup the (field, butterfly) list is dealt flat: a wave's 64 entries are
+  // one field's aligned block only if the butterflies per field are a multiple of 64
+  return hot_plan(PC).fac[ip] == 8 && hot_lenp(PC, ip) * 8 <= 512 && (hot_plan(PC).nfl == 1 || (hot_plan(PC).S / 8) % 64 == 0);
 }
 #define HOT_SYNC(ipa_, ipb_)                                        \
   do {                                                              \
@@ -1003,9 +1028,9 @@ EMI_DEVFN void hot_dif(real2 *a, int nfl, int fs, const FftPlanDev &pl, const re
   constexpr HotPlanC H = hot_plan(PC);
   if constexpr (IP >= 1) {
     if constexpr (IP == H.nfac - 1)
-      fft_pass_body<H.fac[IP], 1, 1, 1>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, nvalid);
+      fft_pass_body<H.fac[IP], 1, 1, 1, (H.nfl > 1)>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, nvalid);
     else
-      fft_pass_body<H.fac[IP], 1, 0, 1>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, H.S);
+      fft_pass_body<H.fac[IP], 1, 0, 1, (H.nfl > 1)>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, H.S);
     HOT_SYNC(IP, IP - 1);
     hot_dif<PC, IP - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
   }
@@ -1014,7 +1039,7 @@ template <int PC, int IP, int END>
 EMI_DEVFN void hot_dit(real2 *a, int nfl, int fs, const FftPlanDev &pl, const real2 *tw, const real2 *ptw) {
   constexpr HotPlanC H = hot_plan(PC);
   if constexpr (IP < END) {
-    fft_pass_body<H.fac[IP], 0, 0, 1>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], +1, H.S);
+    fft_pass_body<H.fac[IP], 0, 0, 1, (H.nfl > 1)>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], +1, H.S);
     if constexpr (IP + 1 < H.nfac)
       HOT_SYNC(IP, IP + 1);
     else
@@ -1028,7 +1053,7 @@ EMI_DEVFN void hot_conv(real2 *a, int nfl, int fs, const FftPlanDev &pl, const F
   const real2 *tw = (const real2 *)T.tw + pl.tw_off, *bh = (const real2 *)T.bhat + pl.bhat_off;
   const real2 *ptw = (const real2 *)T.ptw;
   hot_dif<PC, H.nfac - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
-  blue_middle<H.fac[0]>(a, nfl, fs, H.S, tw, bh, conj_b, H.S);
+  blue_middle<H.fac[0], (H.nfl > 1)>(a, nfl, fs, H.S, tw, bh, conj_b, H.S);
   HOT_SYNC(0, 1);
   hot_dit<PC, 1, LASTDIT ? H.nfac : H.nfac - 1>(a, nfl, fs, pl, tw, ptw);
 }
