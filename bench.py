@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 # fp64 matrix-core peak of MI355X: 256 CU x 4 SIMD x 32 FLOP/clk/SIMD (v_mfma_f64_16x16x4_f64 =
 # 2048 FLOP / 64 cycles) x 2.4 GHz = 78.6 TFLOP/s (AMD MI355X datasheet "FP64 matrix 78.6 TF";
 # /opt/skills/guides/MI355X_MICROARCH.md lists no fp64 row; tools/mfma_f64_peak.hip measures 78.0 on the box,
-# profiles/r1d_mfma_peak.txt).
+# profiles/r1e_mfma_peak.txt).
 PEAK_F64_MFMA_TFLOPS = 78.6
 # fp32 matrix-core peak (v_mfma_f32_16x16x4_f32: 2048 FLOP / 32 cycles): 157.3 TFLOP/s
 # (/opt/skills/guides/MI355X_MICROARCH.md, "FP32 matrix")

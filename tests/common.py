@@ -98,8 +98,8 @@ def spec_weights(nasm0, nsmax, nspec2):
 
 def adjoint_case(et, xp, nsmax, nloen, nuv, nsc, nproma=None, seed=7, precision=8):
     """Dot-product tests of INV_TRANSAD and DIR_TRANSAD against INV_TRANS and DIR_TRANS (the
-    reference's test_invtrans_adjoint.F90 / test_dirtrans_adjoint.F90): returns the two relative errors
-    |<A x, y> - <x, A* y>| / |<A x, y>|."""
+    reference's test_invtrans_adjoint.F90 / test_dirtrans_adjoint.F90): returns the two errors
+    |<A x, y> - <x, A* y>| / (|A x| |y|)."""
     to0, back0 = xp
     dt = np.float32 if precision == 4 else np.float64
     to = lambda a: to0(np.ascontiguousarray(a, dtype=dt))
@@ -130,7 +130,8 @@ def adjoint_case(et, xp, nsmax, nloen, nuv, nsc, nproma=None, seed=7, precision=
         et.inv_transad(r, pgp=y, kproma=npr, **kw(*aty))
         sel = lambda l: [l[0] if nuv else None, l[1] if nuv else None, l[2] if nsc else None]
         lhs, rhs = dot_gp(ax, y), dot_sp(sel(x), sel(aty))
-        e_inv = abs(lhs - rhs) / abs(lhs)
+        # relative to the size of the terms, not to the (possibly cancelling) sum
+        e_inv = abs(lhs - rhs) / np.sqrt(dot_gp(ax, ax) * dot_gp(y, y))
         # ---- DIR_TRANS vs DIR_TRANSAD
         xg = to(rg())
         ys = [to(rs(nuv)), to(rs(nuv)), to(rs(nsc))]
@@ -139,7 +140,7 @@ def adjoint_case(et, xp, nsmax, nloen, nuv, nsc, nproma=None, seed=7, precision=
         bty = to(np.zeros((nb, nf, npr)))
         et.dir_transad(r, pgp=bty, kproma=npr, **kw(*ys))
         lhs, rhs = dot_sp(sel(bx), sel(ys)), dot_gp(xg, bty)
-        e_dir = abs(lhs - rhs) / abs(lhs)
+        e_dir = abs(lhs - rhs) / np.sqrt(dot_gp(xg, xg) * dot_gp(bty, bty))
         return e_inv, e_dir
     finally:
         et.trans_release(r)
