@@ -60,3 +60,20 @@ def test_multi_rank_path_on_one_gpu(world, nsc):
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("DIST OK rank %d" % rank) in out, out
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_mpi_host_with_alltoallv_hook(nranks):
+    """A C / MPI host of the C-ABI (tests/mpi/test_mpi_hook.c): `mpiexec -n N`, every rank one task of the
+    W-set, the all-to-all-v hook of ectrans_amd/mpi/emi_mpi_hook.c (MPI_Alltoallv, staged through pinned host
+    memory because this MPICH is not GPU-aware; the ranks share the one GPU).  Skipped without MPI."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec) or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI installation")
+    d = os.path.join(ROOT, "ectrans_amd", "mpi")
+    subprocess.check_call(["make", "-s", "-C", d, "test_mpi_hook"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([mpiexec, "-n", str(nranks), os.path.join(d, "test_mpi_hook")], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert p.returncode == 0 and p.stdout.count("MPI HOOK OK") == nranks, p.stdout + p.stderr
