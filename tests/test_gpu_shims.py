@@ -34,19 +34,19 @@ def test_transi_c_api():
     _run("transi", "transi_test", "TRANSI API OK")
 
 
-@pytest.mark.parametrize("world,nsc", [(2, 2), (4, 2), (2, 300), (3, 300)])
-def test_multi_rank_path_on_one_gpu(world, nsc):
+@pytest.mark.parametrize("world,nsc,prec", [(2, 2, 8), (4, 2, 8), (2, 300, 8), (3, 300, 8), (2, 300, 4)])
+def test_multi_rank_path_on_one_gpu(world, nsc, prec):
     """The N > 1 path with the REAL HIP kernels: `world` ranks share cuda:0 (RCCL cannot put two
     ranks on one device, so the hook stages the all-to-all-v through gloo -- ectrans_amd/dist.py);
     every rank checks its wavenumber/latitude share against the oracle (tests/dist_worker.py).
     With 300 scalar fields the calls run as 4 pipelined batches: Legendre, exchange and FFT of
     different batches on three streams with double-buffered Fourier buffers (EMI_PIPELINE_DIST)."""
     import sys
-    port = 29540 + world + (10 if nsc > 2 else 0)
+    port = 29540 + world + (10 if nsc > 2 else 0) + (20 if prec == 4 else 0)
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   EMI_TEST_NSMAX="63", EMI_TEST_DEVICE="cuda", EMI_TEST_NSC=str(nsc))
+                   EMI_TEST_NSMAX="63", EMI_TEST_DEVICE="cuda", EMI_TEST_NSC=str(nsc), EMI_TEST_PRECISION=str(prec))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
