@@ -38,6 +38,10 @@ class _Init(C.Structure):
                 ("myproc", C.c_int), ("device", C.c_int)]
 
 
+class _LegpolIO(C.Structure):
+    _fields_ = [("io", C.c_char_p), ("fname", C.c_char_p), ("ptr", C.c_void_p), ("len", C.c_size_t)]
+
+
 class _Setup(C.Structure):
     _fields_ = [("ksmax", C.c_int), ("kdgl", C.c_int), ("kloen", C.POINTER(C.c_int)), ("kdlon", C.c_int),
                 ("precision", C.c_int), ("lduseflt", C.c_int), ("ldll", C.c_int), ("ldstretch", C.c_int)]
@@ -80,6 +84,7 @@ def _bind(L):
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
     L.emi_init.argtypes = [C.POINTER(_Init)]
     L.emi_setup.argtypes = [C.POINTER(_Setup), ip]
+    L.emi_setup_legpol.argtypes = [C.POINTER(_Setup), C.POINTER(_LegpolIO), ip]
     L.emi_inq_int.argtypes = [C.c_int, C.c_char_p, ip]
     L.emi_inq_int_array.argtypes = [C.c_int, C.c_char_p, ip, C.c_int]
     L.emi_inq_real_array.argtypes = [C.c_int, C.c_char_p, dp, C.c_int]
@@ -178,8 +183,13 @@ def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, mypr
 _PREC = {}  # kresol -> array dtype name of that resolution
 
 
-def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, pstret=None, precision=8):
+def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, pstret=None, precision=8,
+                cdio_legpol=None, cdlegpolfname=None, klegpolptr=None, klegpolptr_len=None):
     """SETUP_TRANS (setup_trans.h:12-115); returns KRESOL.
+
+    cdio_legpol: "writef" writes the Legendre polynomials of this setup to `cdlegpolfname`, "readf" takes
+    them from that file, "membuf" from the file image `klegpolptr` (bytes-like or numpy array, or an
+    address with `klegpolptr_len`) -- the reference's format (write_legpol_mod.F90), one task only.
 
     precision: 8 = the reference's double-precision library (libtrans_dp, JPRB=JPRD), arrays are
     float64; 4 = its single-precision library (libtrans_sp, JPRB=JPRM), arrays are float32 (setup --
@@ -197,7 +207,20 @@ def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, ps
     cfg.lduseflt, cfg.ldll = int(bool(lduseflt)), int(bool(ldll))
     cfg.ldstretch = int(pstret is not None and abs(pstret - 1.0) > 100 * np.finfo(float).eps)
     kresol = C.c_int(0)
-    _chk(lib().emi_setup(C.byref(cfg), C.byref(kresol)))
+    if cdio_legpol is None:
+        _chk(lib().emi_setup(C.byref(cfg), C.byref(kresol)))
+    else:
+        io = _LegpolIO(str(cdio_legpol).encode(), None if cdlegpolfname is None else str(cdlegpolfname).encode(), None, 0)
+        seg = None
+        if klegpolptr is not None:
+            if isinstance(klegpolptr, int):
+                io.ptr, io.len = klegpolptr, int(klegpolptr_len or 0)
+            else:
+                seg = np.frombuffer(klegpolptr, dtype=np.uint8) if not isinstance(klegpolptr, np.ndarray) \
+                    else np.ascontiguousarray(klegpolptr).view(np.uint8).reshape(-1)
+                io.ptr, io.len = seg.ctypes.data, seg.size if klegpolptr_len is None else int(klegpolptr_len)
+        _chk(lib().emi_setup_legpol(C.byref(cfg), C.byref(io), C.byref(kresol)))
+        del seg  # the library has copied what it needs
     _PREC[kresol.value] = "float32" if precision == 4 else "float64"
     return kresol.value
 

@@ -9,6 +9,11 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../../include/ectrans_mi.h"
 #include "emi_kernels.h"
 #include "emi_setup.h"
@@ -460,7 +465,88 @@ static int build_fft_plans(Plan &P) {
   return 0;
 }
 
-extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
+
+// ------------------------------------------------------------------------------------------
+// CDIO_LEGPOL: the reference's Legendre-polynomial file / memory segment (NPROC = 1 only,
+// setup_trans.F90:360-384).  Byte format of write_legpol_mod.F90:66-158 / read_legpol_mod.F90:78-215:
+//   4 x int32   'LEGP' 'OL  ' NSMAX NDGNH
+//   2*NDGNH x int32   (NLOEN(jgl), NMEN(jgl)), jgl = 1..NDGNH
+//   per wavenumber in MYMS order:  RPNMA(IDGLU, ILA) then RPNMS(IDGLU, ILS), 8-byte reals, column-major,
+//   IDGLU = MIN(NDGNH, NDGLU(m)), ILA = (NSMAX-m+2)/2, ILS = (NSMAX-m+3)/2, columns with n descending
+// ('LEGPOLBF' files carry butterfly-compressed matrices of the FLT option, which this library refuses.)
+// ------------------------------------------------------------------------------------------
+struct LegpolSource {
+  const char *base = nullptr;
+  size_t len = 0;
+  void *map = nullptr;
+  size_t maplen = 0;
+  std::vector<size_t> offA, offS;  // byte offsets of RPNMA / RPNMS per wavenumber
+  ~LegpolSource() {
+    if (map) munmap(map, maplen);
+  }
+};
+
+static int legpol_open(LegpolSource &src, const emi_legpol_io_t *io, bool membuf) {
+  if (membuf) {
+    if (!io->ptr) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KLEGPOLPTR NULL POINTER");
+    if (!io->len) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KLEGPOLPTR_LEN ARGUMENT MISSING");
+    src.base = (const char *)io->ptr;
+    src.len = io->len;
+    return 0;
+  }
+  if (!io->fname || !io->fname[0]) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: CDLEGPOLFNAME ARGUMENT MISSING");
+  int fd = open(io->fname, O_RDONLY);
+  struct stat st;
+  if (fd < 0 || fstat(fd, &st) != 0) {
+    if (fd >= 0) close(fd);
+    EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL: BYTES_IO_OPEN FAILED (%s)", io->fname);
+  }
+  src.maplen = (size_t)st.st_size;
+  src.map = src.maplen ? mmap(nullptr, src.maplen, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+  close(fd);
+  if (src.map == MAP_FAILED || !src.map) {
+    src.map = nullptr;
+    EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:BYTES_IO_READ FAILED (%s)", io->fname);
+  }
+  src.base = (const char *)src.map;
+  src.len = src.maplen;
+  return 0;
+}
+
+// header checks of read_legpol_mod.F90:78-118 and the per-wavenumber offsets
+static int legpol_index(LegpolSource &src, int nsmax, int ndgnh, const std::vector<int> &nloen, const std::vector<int> &nmen,
+                        const std::vector<int> &ndglu) {
+  const size_t head = 16 + (size_t)8 * ndgnh;
+  if (src.len < 16) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:BYTES_IO_READ FAILED (segment shorter than its header)");
+  int ib[4];
+  memcpy(ib, src.base, 16);
+  if (memcmp(src.base, "LEGPOL  ", 8) != 0) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:WRONG LABEL");
+  if (ib[2] != nsmax) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:WRONG SPECTRAL TRUNCATION");
+  if (ib[3] != ndgnh) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:WRONG NO OF GAUSSIAN LATITUDES");
+  if (src.len < head) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:BYTES_IO_READ FAILED (segment shorter than its latitude table)");
+  for (int j = 0; j < ndgnh; j++) {
+    int v[2];
+    memcpy(v, src.base + 16 + (size_t)8 * j, 8);
+    if (v[0] != nloen[j]) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:WRONG NLOEN (latitude %d: %d, file %d)", j + 1, nloen[j], v[0]);
+    if (v[1] != nmen[j]) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:WRONG NMEN (latitude %d: %d, file %d)", j + 1, nmen[j], v[1]);
+  }
+  size_t off = head;
+  src.offA.assign(nsmax + 1, 0);
+  src.offS.assign(nsmax + 1, 0);
+  for (int m = 0; m <= nsmax; m++) {
+    const size_t nd = (size_t)std::min(ndgnh, ndglu[m]);
+    src.offA[m] = off;
+    off += nd * (size_t)((nsmax - m + 2) / 2) * 8;
+    src.offS[m] = off;
+    off += nd * (size_t)((nsmax - m + 3) / 2) * 8;
+  }
+  if (off > src.len) EMI_FAIL(EMI_ERR_ARG, "READ_LEGPOL:BYTES_IO_READ FAILED (%zu bytes needed, %zu present)", off, src.len);
+  return 0;
+}
+
+static int legpol_write(int kresol, const char *fname);
+
+extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *io, int *kresol) {
   if (!G.init) EMI_FAIL(EMI_ERR_STATE, "SETUP_TRANS: SETUP_TRANS0 HAS TO BE CALLED BEFORE SETUP_TRANS");
   if (!cfg) EMI_FAIL(EMI_ERR_ARG, "emi_setup: null config");
   if (cfg->kdgl <= 0 || cfg->kdgl % 2 != 0) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KDGL IS NOT A POSITIVE, EVEN NUMBER");
@@ -470,6 +556,25 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   if (cfg->precision != 0 && cfg->precision != 8 && cfg->precision != 4)
     EMI_FAIL(EMI_ERR_ARG, "emi_setup: precision must be 8 (fp64, the _dp library) or 4 (fp32, _sp), got %d", cfg->precision);
   if (cfg->ksmax < 0) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KSMAX < 0");
+  // CDIO_LEGPOL (setup_trans.F90:360-384)
+  enum { LP_NONE, LP_READF, LP_WRITEF, LP_MEMBUF } lp_mode = LP_NONE;
+  if (io && io->io && io->io[0]) {
+    std::string mode(io->io);
+    while (!mode.empty() && mode.back() == ' ') mode.pop_back();
+    if (G.nproc > 1) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS:CDIO_LEGPOL OPTIONS ONLY FOR NPROC=1 ");
+    if (mode == "readf" || mode == "READF")
+      lp_mode = LP_READF;
+    else if (mode == "writef" || mode == "WRITEF")
+      lp_mode = LP_WRITEF;
+    else if (mode == "membuf" || mode == "MEMBUF")
+      lp_mode = LP_MEMBUF;
+    else
+      EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS:CDIO_LEGPOL UNKNOWN METHOD (%s)", mode.c_str());
+    if (lp_mode != LP_MEMBUF && (!io->fname || !io->fname[0])) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: CDLEGPOLFNAME ARGUMENT MISSING");
+  }
+  LegpolSource lp_src;
+  if ((lp_mode == LP_READF || lp_mode == LP_MEMBUF) && legpol_open(lp_src, io, lp_mode == LP_MEMBUF)) return EMI_ERR_ARG;
+  const bool lp_read = lp_src.base != nullptr;
   int slot = -1;
   for (int i = 0; i < G.max_resol; i++)
     if (!G.plans[i] || !G.plans[i]->active) {
@@ -538,6 +643,10 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
     P.racthe[j] = 1.0 / c / P.ra;
   }
   emi::wavenumber_cutoffs(N, L, P.nloen, P.reduced, P.cos2, P.nmen, P.ndglu);
+  if (lp_read && legpol_index(lp_src, N, P.ndgnh, P.nloen, P.nmen, P.ndglu)) {
+    delete pp;
+    return EMI_ERR_ARG;
+  }
 
   // ---- distribution over tasks
   // wavenumbers: the reference's zig-zag W-set assignment (suwavedi_mod.F90:118-137)
@@ -723,7 +832,8 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   // m >= 2: k_legpol on the device (below, once the device tables exist); m = 0, 1 (ordinary Legendre
   // recurrence, supolf_mod.F90:124-142) on the host.  EMI_LEGPOL_HOST=1 computes every panel on the
   // host threads instead (the two paths agree bit for bit, tests/test_gpu_parity.py).
-  const bool legpol_host = getenv("EMI_LEGPOL_HOST") && atoi(getenv("EMI_LEGPOL_HOST"));
+  // With CDIO_LEGPOL = readf / membuf every panel is taken from the file or segment instead (read_legpol_mod.F90:120-215).
+  const bool legpol_host = lp_read || (getenv("EMI_LEGPOL_HOST") && atoi(getenv("EMI_LEGPOL_HOST")));
   if (emi_dev_memset(dP, 0, (size_t)P.p_elems * esz, 0) || emi_dev_memset(dPT, 0, (size_t)P.pt_elems * esz, 0)) {
     delete pp;
     return EMI_ERR_RUNTIME;
@@ -739,13 +849,23 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
       const int nmax = N + 2;
       std::vector<double> pan((size_t)2 * nk * ld, 0.0), col(nmax + 1);
       std::vector<int> corr(nmax + 1);
-      emi::LegCoef lc = emi::legendre_coefficients(m, nmax);
-      for (int j = 0; j < nd; j++) {
-        double mu = P.rmu[isl0 + j];
+      if (lp_read) {
+        // reference column c holds n descending: row k of the panel (n = m + 2k + par) is column nc-1-k
         for (int par = 0; par < 2; par++) {
-          emi::legendre_column(lc, mu, par, col.data(), corr.data());
+          const int nc = par ? (N - m + 2) / 2 : (N - m + 3) / 2;
+          const char *mat = lp_src.base + (par ? lp_src.offA[m] : lp_src.offS[m]);
           double *dst = pan.data() + (size_t)par * nk * ld;
-          for (int k = 0; m + 2 * k + par <= N + 1; k++) dst[(size_t)k * ld + j] = col[m + 2 * k + par];
+          for (int k = 0; k < nc; k++) memcpy(dst + (size_t)k * ld, mat + ((size_t)(nc - 1 - k) * nd) * 8, (size_t)nd * 8);
+        }
+      } else {
+        emi::LegCoef lc = emi::legendre_coefficients(m, nmax);
+        for (int j = 0; j < nd; j++) {
+          double mu = P.rmu[isl0 + j];
+          for (int par = 0; par < 2; par++) {
+            emi::legendre_column(lc, mu, par, col.data(), corr.data());
+            double *dst = pan.data() + (size_t)par * nk * ld;
+            for (int k = 0; m + 2 * k + par <= N + 1; k++) dst[(size_t)k * ld + j] = col[m + 2 * k + par];
+          }
         }
       }
       // the recurrences always run in double (as the reference's _sp build does: the JPRD work arrays of suleg_mod.F90:130-162);
@@ -874,8 +994,18 @@ extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) {
   if (G.plans[slot]) delete G.plans[slot];
   G.plans[slot] = pp;
   if (kresol) *kresol = slot + 1;
+  if (lp_mode == LP_WRITEF) {  // suleg_mod.F90:1186
+    rc = legpol_write(slot + 1, io->fname);
+    phase("legendre file written");
+    if (rc) {
+      emi_release(slot + 1);
+      return rc;
+    }
+  }
   return EMI_SUCCESS;
 }
+
+extern "C" int emi_setup(const emi_setup_t *cfg, int *kresol) { return emi_setup_legpol(cfg, nullptr, kresol); }
 
 extern "C" int emi_set_alltoallv(emi_alltoallv_fn fn, void *user) {
   G.a2a = fn;
@@ -1046,6 +1176,43 @@ extern "C" int emi_inq_legendre(int kresol, int m, int symmetric, double *out, i
   // reference column c (0-based) holds n descending: k = nc-1-c
   for (int c = 0; c < nc; c++)
     for (int j = 0; j < nd; j++) out[(size_t)c * nd + j] = pan[(size_t)(nc - 1 - c) * ld + j];
+  return EMI_SUCCESS;
+}
+
+// WRITE_LEGPOL (write_legpol_mod.F90:66-158): the panels as emi_inq_legendre returns them, in MYMS order
+static int legpol_write(int kresol, const char *fname) {
+  Plan *P = get_plan(kresol);
+  if (!P) EMI_FAIL(EMI_ERR_STATE, "WRITE_LEGPOL: unknown resolution %d", kresol);
+  FILE *f = fopen(fname, "wb");
+  if (!f) EMI_FAIL(EMI_ERR_ARG, "WRITE_LEGPOL: BYTES_IO_OPEN FAILED (%s)", fname);
+  int head[4];
+  memcpy(head, "LEGPOL  ", 8);
+  head[2] = P->nsmax;
+  head[3] = P->ndgnh;
+  bool ok = fwrite(head, 4, 4, f) == 4;
+  std::vector<int> lat(2 * (size_t)P->ndgnh);
+  for (int j = 0; j < P->ndgnh; j++) {
+    lat[2 * j] = P->nloen[j];
+    lat[2 * j + 1] = P->nmen[j];
+  }
+  ok = ok && fwrite(lat.data(), 4, lat.size(), f) == lat.size();
+  std::vector<double> buf;
+  for (int m = 0; ok && m <= P->nsmax; m++)
+    for (int sym = 0; ok && sym < 2; sym++) {  // anti-symmetric first
+      int nr = 0, nc = 0;
+      if (emi_inq_legendre(kresol, m, sym, nullptr, &nr, &nc)) {
+        fclose(f);
+        return EMI_ERR_RUNTIME;
+      }
+      buf.resize((size_t)nr * nc);
+      if (emi_inq_legendre(kresol, m, sym, buf.data(), &nr, &nc)) {
+        fclose(f);
+        return EMI_ERR_RUNTIME;
+      }
+      ok = fwrite(buf.data(), 8, buf.size(), f) == buf.size();
+    }
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) EMI_FAIL(EMI_ERR_RUNTIME, "WRITE_LEGPOL:BYTES_IO_WRITE FAILED (%s)", fname);
   return EMI_SUCCESS;
 }
 

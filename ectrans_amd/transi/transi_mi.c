@@ -1,6 +1,7 @@
 /* transi_mi.c -- see transi_mi.h.  Thin marshalling onto include/ectrans_mi.h. */
 #include "transi_mi.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -73,6 +74,26 @@ int trans_set_trunc(struct Trans_t *t, int nsmax) {
   return TRANS_SUCCESS;
 }
 
+static int set_path(char **dst, const char *path) {
+  free(*dst);
+  *dst = NULL;
+  if (!path) return TRANS_MISSING_ARG;
+  *dst = (char *)malloc(strlen(path) + 1);
+  if (!*dst) return TRANS_ERROR;
+  strcpy(*dst, path);
+  return TRANS_SUCCESS;
+}
+
+int trans_set_read(struct Trans_t *t, const char *filepath) { return set_path(&t->readfp, filepath); }
+
+int trans_set_write(struct Trans_t *t, const char *filepath) { return set_path(&t->writefp, filepath); }
+
+int trans_set_cache(struct Trans_t *t, const void *cache, size_t cachesize) {
+  t->cache = cache;
+  t->cachesize = cachesize;
+  return TRANS_SUCCESS;
+}
+
 int trans_setup(struct Trans_t *t) {
   int rc = trans_init();
   if (rc) return rc;
@@ -86,7 +107,24 @@ int trans_setup(struct Trans_t *t) {
   cfg.kloen = t->nloen;
   cfg.kdlon = t->nlon;
   cfg.precision = 8;
-  if (emi_setup(&cfg, &t->handle) != 0) return TRANS_ERROR;
+  emi_legpol_io_t io;
+  memset(&io, 0, sizeof(io));
+  if (t->cachesize > 0 && !t->cache) { /* transi_module.F90:737-741 */
+    fprintf(stderr, "Cache memory was not allocated\n");
+    return TRANS_MISSING_ARG;
+  }
+  if (t->readfp && t->readfp[0]) {
+    io.io = "readf";
+    io.fname = t->readfp;
+  } else if (t->writefp && t->writefp[0]) {
+    io.io = "writef";
+    io.fname = t->writefp;
+  } else if (t->cachesize > 0) {
+    io.io = "membuf";
+    io.ptr = t->cache;
+    io.len = t->cachesize;
+  }
+  if (emi_setup_legpol(&cfg, io.io ? &io : NULL, &t->handle) != 0) return TRANS_ERROR;
   t->myproc = t->nproc = 1;
   emi_inq_int(t->handle, "nspec2", &t->nspec2);
   t->nspec = t->nspec2 / 2;
@@ -345,6 +383,7 @@ int trans_specnorm(struct SpecNorm_t *s) {
 int trans_delete(struct Trans_t *t) {
   int rc = TRANS_SUCCESS;
   if (t->handle) rc = emi_release(t->handle) ? TRANS_ERROR : TRANS_SUCCESS;
+  free(t->readfp), free(t->writefp);
   free(t->nloen), free(t->nmyms), free(t->nasm0), free(t->nvalue), free(t->ndglu), free(t->nnmeng), free(t->rmu), free(t->rgw);
   memset(t, 0, sizeof(*t));
   return rc;

@@ -7,7 +7,7 @@
  * (TRANS_SUCCESS = 0, negative error codes, trans_error_msg()).
  *
  * Not provided (outside SURVEY.md section 8): vordiv_to_UV,
- * LAM, lonlat, legendre-cache I/O, rmeanu/rmeanv (lglobal is honoured: one task, global == local).  They return
+ * LAM, lonlat, rmeanu/rmeanv (lglobal is honoured: one task, global == local).  They return
  * TRANS_NOTIMPL instead of being silently ignored.
  */
 #ifndef TRANSI_MI_H
@@ -35,6 +35,12 @@ struct Trans_t {
   _bool lsplit;
   int llatlon; /* must stay 0 */
   int flt;     /* <= 0: Fast Legendre Transform not requested (the only supported setting) */
+  /* Legendre polynomials from / to a file or a memory image (transi.h:719-722; set with trans_set_read,
+   * trans_set_write, trans_set_cache; precedence read > write > cache as transi_module.F90:762-866) */
+  char *readfp;
+  char *writefp;
+  const void *cache;
+  size_t cachesize;
   /* filled by trans_setup */
   int myproc, nproc;
   int handle; /* KRESOL */
@@ -117,6 +123,9 @@ int trans_init(void);
 int trans_new(struct Trans_t *);
 int trans_set_resol(struct Trans_t *, int ndgl, const int *nloen);
 int trans_set_trunc(struct Trans_t *, int nsmax);
+int trans_set_read(struct Trans_t *, const char *filepath);          /* transi.h:192 */
+int trans_set_write(struct Trans_t *, const char *filepath);         /* transi.h:193 */
+int trans_set_cache(struct Trans_t *, const void *cache, size_t cachesize); /* transi.h:194 */
 int trans_setup(struct Trans_t *);
 int trans_inquire(struct Trans_t *, const char *varlist);
 struct DirTrans_t new_dirtrans(struct Trans_t *);

@@ -67,6 +67,22 @@ typedef struct {
 } emi_setup_t;
 int emi_setup(const emi_setup_t *cfg, int *kresol);
 
+/* SETUP_TRANS with its Legendre-polynomial I/O arguments CDIO_LEGPOL, CDLEGPOLFNAME, KLEGPOLPTR,
+ * KLEGPOLPTR_LEN (setup_trans.F90:63-71, 360-384; one task only, as there).  The byte format is the
+ * reference's (write_legpol_mod.F90:66-158, read_legpol_mod.F90:78-215), so files and memory segments
+ * are interchangeable with libtrans_dp's: 'LEGPOL  ', NSMAX, NDGNH, (NLOEN, NMEN) per northern
+ * latitude, then per wavenumber RPNMA(ndglu, (nsmax-m+2)/2) and RPNMS(ndglu, (nsmax-m+3)/2) as
+ * 8-byte reals.  "readf"/"membuf": the panels are taken from the file / segment (label, truncation,
+ * latitude count, NLOEN and NMEN are checked with the reference's messages); "writef": the panels this
+ * setup computed are written out.  io == NULL or io->io == NULL: plain emi_setup.              */
+typedef struct {
+  const char *io;    /* CDIO_LEGPOL: "readf" | "writef" | "membuf" (or upper case)              */
+  const char *fname; /* CDLEGPOLFNAME (readf, writef)                                          */
+  const void *ptr;   /* KLEGPOLPTR (membuf): host memory holding a file image                  */
+  size_t len;        /* KLEGPOLPTR_LEN, bytes                                                  */
+} emi_legpol_io_t;
+int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *io, int *kresol);
+
 /* ---- TRANS_INQ (trans/cpu/external/trans_inq.F90:11-529), subset used by callers ----- */
 /* integer scalars: "nspec2" "nspec2g" "nspec2mx" "ngptot" "ngptotg" "ngptotmx" "nump" "ndgl" "nsmax"
  * "ndlon" "nproc" "myproc" "nfrstlat" "nlstlat"                                           */

@@ -47,7 +47,7 @@ def unblock(gp, ngptot):
     return np.concatenate([gp[b] for b in range(nb)], axis=1)[:, :ngptot]
 
 
-def run_case(et, Oracle, xp, nsmax, nloen, nuv, nsc, flags=None, nproma=None, seed=1, precision=8):
+def run_case(et, Oracle, xp, nsmax, nloen, nuv, nsc, flags=None, nproma=None, seed=1, precision=8, setup_kw=None):
     """inverse + direct through the C-ABI (`et`) against the oracle; returns (e_inv, e_dir).
     xp(a) moves a numpy array to the memory space under test and back: (to, back).
     precision=4 runs the fp32 library on float32 copies of the same inputs (the oracle stays fp64)."""
@@ -57,7 +57,7 @@ def run_case(et, Oracle, xp, nsmax, nloen, nuv, nsc, flags=None, nproma=None, se
         to0, back0 = xp
         to, back = (lambda a: to0(a.astype(np.float32))), (lambda a: np.asarray(back0(a), dtype=np.float64))
     nloen = np.asarray(nloen, dtype=np.int32)
-    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision, **(setup_kw or {}))
     try:
         o = Oracle(nsmax, nloen)
         rng = np.random.default_rng(seed)
@@ -144,3 +144,79 @@ def adjoint_case(et, xp, nsmax, nloen, nuv, nsc, nproma=None, seed=7, precision=
         return e_inv, e_dir
     finally:
         et.trans_release(r)
+
+
+def legpol_image(o, nsmax, nloen):
+    """The reference's Legendre-polynomial file (write_legpol_mod.F90:66-158, non-FLT, no lat-lon part)
+    assembled from the ORACLE's panels: 'LEGPOL  ', NSMAX, NDGNH; (NLOEN, NMEN) per northern latitude;
+    per wavenumber RPNMA then RPNMS, column-major 8-byte reals."""
+    ndgnh = len(nloen) // 2
+    parts = [b"LEGPOL  ", np.array([nsmax, ndgnh], dtype="<i4").tobytes(),
+             np.stack([np.asarray(nloen)[:ndgnh], np.asarray(o.nmen)[:ndgnh]], axis=1).astype("<i4").tobytes()]
+    for m in range(nsmax + 1):
+        for sym in (False, True):
+            parts.append(np.ascontiguousarray(o.rpnm(m, sym), dtype="<f8").tobytes())  # [col][row] = column-major
+    return b"".join(parts)
+
+
+def legpol_io_case(et, Oracle, xp, tmpdir, nsmax=21, precision=8):
+    """CDIO_LEGPOL of SETUP_TRANS: writef / readf / membuf in the reference's byte format."""
+    import os
+    nloen = octahedral(nsmax)
+    o = Oracle(nsmax, nloen)
+    ref = legpol_image(o, nsmax, nloen)
+    head = 16 + 8 * (len(nloen) // 2)
+    fw = os.path.join(str(tmpdir), "legpol_w.bin")
+    # writef: integers exact, panels as the oracle's
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision, cdio_legpol="writef", cdlegpolfname=fw)
+    mine = open(fw, "rb").read()
+    assert len(mine) == len(ref) and mine[:head] == ref[:head]
+    a, b = np.frombuffer(mine[head:], dtype="<f8"), np.frombuffer(ref[head:], dtype="<f8")
+    assert np.abs(a - b).max() <= (1e-14 if precision == 8 else 1e-6) * np.abs(b).max()
+    computed = {(m, s): et.legendre_panel(r, m, s) for m in range(nsmax + 1) for s in (False, True)}
+    et.trans_release(r)
+    # readf of a file made from the oracle's panels: the library holds exactly those values ...
+    fr = os.path.join(str(tmpdir), "legpol_r.bin")
+    open(fr, "wb").write(ref)
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision, cdio_legpol="READF", cdlegpolfname=fr)
+    for m in range(nsmax + 1):
+        for s in (False, True):
+            want = o.rpnm(m, s)
+            assert np.array_equal(et.legendre_panel(r, m, s), want if precision == 8 else want.astype(np.float32).astype(np.float64))
+    et.trans_release(r)
+    # ... and transforms with them
+    tol = 1e-12 if precision == 8 else 3e-5
+    e = run_case(et, Oracle, xp, nsmax, nloen, 1, 2, precision=precision, setup_kw=dict(cdio_legpol="readf", cdlegpolfname=fr))
+    assert max(e) < tol, e
+    # membuf: the image this library wrote gives back the computed panels bit for bit
+    for seg in (mine, np.frombuffer(mine, dtype=np.uint8)):
+        r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision, cdio_legpol="membuf", klegpolptr=seg)
+        assert all(np.array_equal(et.legendre_panel(r, m, s), v) for (m, s), v in computed.items())
+        et.trans_release(r)
+    # the reference's checks (read_legpol_mod.F90:88-118)
+    bad = bytearray(ref)
+    bad[0:8] = b"LEGPOLBF"
+    other = octahedral(nsmax).copy()
+    other[3] += 4
+    other[-4] += 4
+    cases = [(dict(klegpolptr=bytes(bad)), nsmax, nloen, "WRONG LABEL"),
+             (dict(klegpolptr=ref), nsmax - 1, nloen, "WRONG SPECTRAL TRUNCATION"),
+             (dict(klegpolptr=ref), nsmax, octahedral(nsmax + 1), "WRONG NO OF GAUSSIAN LATITUDES"),
+             (dict(klegpolptr=ref), nsmax, other, "WRONG NLOEN"),
+             (dict(klegpolptr=ref[:len(ref) - 8]), nsmax, nloen, "BYTES_IO_READ FAILED"),
+             (dict(klegpolptr=None), nsmax, nloen, "KLEGPOLPTR")]
+    for kw, n, nl, msg in cases:
+        try:
+            et.setup_trans(n, len(nl), nl, precision=precision, cdio_legpol="membuf", **kw)
+        except et.TransError as err:
+            assert msg in str(err), (msg, str(err))
+        else:
+            raise AssertionError("no error for " + msg)
+    for kw, msg in ((dict(cdio_legpol="readf", cdlegpolfname=os.path.join(str(tmpdir), "absent.bin")), "BYTES_IO_OPEN FAILED"),
+                    (dict(cdio_legpol="readf"), "CDLEGPOLFNAME"), (dict(cdio_legpol="mmap"), "UNKNOWN METHOD")):
+        try:
+            et.setup_trans(nsmax, len(nloen), nloen, **kw)
+        except et.TransError as err:
+            assert msg in str(err), (msg, str(err))
+        else:
+            raise AssertionError("no error for " + msg)

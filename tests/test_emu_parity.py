@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
-from tests.common import adjoint_case, octahedral, run_case
+from tests.common import adjoint_case, legpol_io_case, octahedral, run_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-12  # fp64: observed ~1e-15
@@ -157,6 +157,12 @@ def test_setup_tables_match_oracle(et):
             assert np.abs(et.legendre_panel(r, m, sym) - o.rpnm(m, sym)).max(initial=0.0) < 1e-14
     assert (et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")) == (o.nspec2, o.ngptot)
     et.trans_release(r)
+
+
+@pytest.mark.parametrize("precision", [8, 4])
+def test_legendre_polynomial_file_io(et, tmp_path, precision):
+    """CDIO_LEGPOL = writef / readf / membuf in the reference's file format (write_legpol_mod.F90)."""
+    legpol_io_case(et, Oracle, XP, tmp_path, nsmax=15, precision=precision)
 
 
 def test_device_legendre_setup_with_rescaling(et, monkeypatch):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.common import adjoint_case, block, octahedral, random_spectrum, rel_err, run_case, unblock
+from tests.common import adjoint_case, block, legpol_io_case, octahedral, random_spectrum, rel_err, run_case, unblock
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -173,6 +173,15 @@ def test_device_legendre_setup_matches_host_and_oracle(et, monkeypatch):
         finally:
             et.trans_release(r)
             et.trans_release(rh)
+
+
+@pytest.mark.parametrize("precision,nsmax", [(8, 47), (4, 47), (8, 159)])
+def test_legendre_polynomial_file_io(et, dev, tmp_path, precision, nsmax):
+    """CDIO_LEGPOL = writef / readf / membuf in the reference's file format (write_legpol_mod.F90:66-158):
+    written panels against an image assembled from the oracle's, panels read back bit for bit, transforms
+    from a read set-up against the oracle, the reference's header checks.  T159 has device-computed
+    panels with rescaling (m >= 2 runs k_legpol) behind the written file."""
+    legpol_io_case(et, Oracle, dev, tmp_path, nsmax=nsmax, precision=precision)
 
 
 @pytest.mark.parametrize("case", [(21, 0, 3, None, 8), (63, 2, 2, None, 8), (63, 1, 1, 1000, 8), (159, 2, 3, None, 8), (63, 2, 2, None, 4)])

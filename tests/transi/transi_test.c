@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../ectrans_amd/transi/transi_mi.h"
 
@@ -147,6 +148,74 @@ int main(void) {
       return 12;
     }
     free(x), free(y), free(p), free(g), free(w);
+  }
+  { /* Legendre polynomials written to a file, then taken from a memory image of it and from the file
+     * itself: the sequence of the reference's tests/transi/transi_test_io.c:34-83, plus a check that the
+     * transforms of the three set-ups agree exactly */
+    const char *tmp = getenv("TMPDIR");
+    char path[600];
+    snprintf(path, sizeof(path), "%s/emi_transi_legpol.bin", tmp && tmp[0] ? tmp : "/tmp");
+    const int ns2 = trans.nspec2, ng = trans.ngptot;
+    double *x = calloc(ns2, sizeof(double)), *g0 = malloc(sizeof(double) * ng), *g1 = malloc(sizeof(double) * ng);
+    x[trans.nasm0[4] - 1 + 2 * (19 - 4)] = 1.0;
+    x[trans.nasm0[0] - 1 + 2 * 3] = -0.5;
+    struct InvTrans_t v0 = new_invtrans(&trans);
+    v0.nscalar = 1, v0.rspscalar = x, v0.rgp = g0;
+    CHECK(trans_invtrans(&v0));
+    struct Trans_t tw;
+    CHECK(trans_new(&tw));
+    CHECK(trans_set_resol(&tw, ndgl, nloen));
+    CHECK(trans_set_trunc(&tw, nsmax));
+    CHECK(trans_set_write(&tw, path));
+    CHECK(trans_setup(&tw));
+    CHECK(trans_delete(&tw));
+    FILE *f = fopen(path, "rb");
+    if (!f) return 20;
+    fseek(f, 0, SEEK_END);
+    size_t size = (size_t)ftell(f);
+    rewind(f);
+    void *buffer = malloc(size);
+    if (fread(buffer, 1, size, f) != size) return 21;
+    fclose(f);
+    for (int pass = 0; pass < 2; pass++) {
+      struct Trans_t tr;
+      CHECK(trans_new(&tr));
+      CHECK(trans_set_resol(&tr, ndgl, nloen));
+      CHECK(trans_set_trunc(&tr, nsmax));
+      if (pass == 0)
+        CHECK(trans_set_cache(&tr, buffer, size));
+      else
+        CHECK(trans_set_read(&tr, path));
+      CHECK(trans_setup(&tr));
+      struct InvTrans_t v1 = new_invtrans(&tr);
+      v1.nscalar = 1, v1.rspscalar = x, v1.rgp = g1;
+      CHECK(trans_invtrans(&v1));
+      for (int i = 0; i < ng; i++)
+        if (g1[i] != g0[i]) {
+          fprintf(stderr, "legendre %s: point %d differs\n", pass ? "file" : "cache", i);
+          return 22;
+        }
+      CHECK(trans_delete(&tr));
+    }
+    { /* a cache of another truncation is refused with the reference's message */
+      struct Trans_t tr;
+      CHECK(trans_new(&tr));
+      CHECK(trans_set_resol(&tr, ndgl, nloen));
+      CHECK(trans_set_trunc(&tr, nsmax - 1));
+      CHECK(trans_set_cache(&tr, buffer, size));
+      int rc = trans_setup(&tr);
+      if (rc == TRANS_SUCCESS || !strstr(trans_error_msg(rc), "READ_LEGPOL:WRONG SPECTRAL TRUNCATION")) return 23;
+      tr.handle = 0;
+      trans_delete(&tr);
+      CHECK(trans_new(&tr));
+      CHECK(trans_set_resol(&tr, ndgl, nloen));
+      CHECK(trans_set_cache(&tr, NULL, size));
+      if (trans_setup(&tr) != TRANS_MISSING_ARG) return 24;
+      trans_delete(&tr);
+    }
+    remove(path);
+    free(buffer), free(x), free(g0), free(g1);
+    printf("legendre file / cache set-ups identical (%zu bytes)\n", size);
   }
   CHECK(trans_delete(&trans));
   CHECK(trans_finalize());
