@@ -2,6 +2,7 @@
 // (tile 64 x 128, both parities, 8-row stages, 32 MFMAs per wave and stage) rebuilt piece by piece:
 //   V0 MFMAs only | V1 + LDS fragment reads | V2 + the two barriers per stage | V3 + the LDS tile writes
 //   V4 + global prefetch of the next stage (coalesced reads of a 1 GiB buffer) | V5 the same, two stages ahead
+//   V8-V13 the operands by LDS-DMA into a ring of three stages (see probe_glds)
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/probe tools/leg_loop_probe.hip && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -137,6 +138,70 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
   out[(long long)blockIdx.x * 256 + tid] = sum;
 }
 
+
+// V8: the operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a ring of three
+// stages, two stages in flight; ONE raw barrier per stage behind a counted vmcnt.  Unpadded LDS rows: the odd rows'
+// 128-byte halves are swapped through the per-lane SOURCE address (the LDS image of an LDS-DMA is lane-linear).
+typedef __attribute__((address_space(3))) void *lds_vp;
+template <int HIT, int MODE = 0>
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(2, 2))) void probe_glds(double *out, const double *src, int nst, long long stride) {
+  extern __shared__ double lds[];  // [3][A: 8 kk x (2 par x 64) | B: 16 rows x 128]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
+  v4d acc[2][2][4];
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) acc[p][i][j] = (v4d){0, 0, 0, 0};
+  const double *g = src + (long long)blockIdx.x * 4096;
+#define GLDS_ISSUE(s_)                                                                                     \
+  {                                                                                                        \
+    double *st = lds + ((s_) % 3) * 3072;                                                                  \
+    const double *q = g + (HIT ? 0 : (long long)(s_) * stride);                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                        \
+      const int kk = 2 * w + i;                                                                            \
+      __builtin_amdgcn_global_load_lds(q + kk * 128 + ((l ^ ((kk & 1) << 3)) << 1), (lds_vp)(st + kk * 128), 16, 0, 0); \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                        \
+      const int r = 4 * w + i;                                                                             \
+      __builtin_amdgcn_global_load_lds(q + 1024 + r * 128 + ((l ^ ((r & 1) << 3)) << 1), (lds_vp)(st + 1024 + r * 128), 16, 0, 0); \
+    }                                                                                                      \
+  }
+  GLDS_ISSUE(0);
+  if (nst > 1) GLDS_ISSUE(1);
+  for (int s = 0; s < nst; s++) {
+    if (MODE == 0 || MODE == 3) {
+      if (s + 1 < nst)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (MODE != 1 && MODE != 3 && s + 2 < nst) GLDS_ISSUE(s + 2);
+    const double *As = lds + (s % 3) * 3072, *Bs = As + 1024;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int kk = 4 * ks + (l >> 4), sw = (kk & 1) << 4;
+        double a[2], b[4];
+#pragma unroll
+        for (int i = 0; i < 2; i++) a[i] = As[kk * 128 + p * 64 + ((wm * 32 + i * 16 + (l & 15)) ^ sw)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = Bs[(p * 8 + kk) * 128 + ((wn * 64 + j * 16 + (l & 15)) ^ sw)];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[p][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[p][i][j], 0, 0, 0);
+        if (MODE == 3 && p == 0 && ks == 1 && s + 2 < nst) GLDS_ISSUE(s + 2);  // DMA issued mid-stage
+      }
+  }
+#undef GLDS_ISSUE
+  double sum = 0;
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
+  out[(long long)blockIdx.x * 256 + tid] = sum;
+}
+
 template <int V>
 static void run(double *out, const double *src, const char *what) {
   const int nblk = 256 * 2 * 8, nst = 80;  // 16 tiles per CU-slot, K = 640 n-pairs
@@ -146,7 +211,13 @@ static void run(double *out, const double *src, const char *what) {
   float best = 1e30f;
   for (int rep = 0; rep < 4; rep++) {
     hipEventRecord(e0, 0);
-    if (V == 7)
+    if (V == 8 || V == 9)
+      hipLaunchKernelGGL(probe_glds<(V == 9)>, dim3(nblk), dim3(256), 3 * 3072 * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
+    else if (V >= 10 && V <= 12)
+      hipLaunchKernelGGL((probe_glds<1, V - 9>), dim3(nblk), dim3(256), 3 * 3072 * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
+    else if (V == 13)
+      hipLaunchKernelGGL((probe_glds<0, 3>), dim3(nblk), dim3(256), 3 * 3072 * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
+    else if (V == 7)
       hipLaunchKernelGGL(probe2, dim3(nblk), dim3(256), (2 * 8 * LDA + 2 * 8 * LDB) * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
     else
       hipLaunchKernelGGL(probe<V>, dim3(nblk), dim3(256), (2 * 8 * LDA + 2 * 8 * LDB) * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
@@ -173,5 +244,11 @@ int main() {
   run<5>(out, src, "+ global prefetch two stages ahead");
   run<6>(out, src, "V4 with the same lines every stage (hits)");
   run<7>(out, src, "V4 two stages ahead, loop unrolled by two");
+  run<8>(out, src, "LDS-DMA ring of 3, one barrier per stage");
+  run<9>(out, src, "V8 with the same lines every stage (hits)");
+  run<10>(out, src, "V9 without the DMA (barrier + MFMA loop only)");
+  run<11>(out, src, "V9 with DMA but no vmcnt wait");
+  run<12>(out, src, "V9 with the DMA issued mid-stage");
+  run<13>(out, src, "V8 with the DMA issued mid-stage");
   return 0;
 }
