@@ -6,17 +6,24 @@
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/probe tools/leg_loop_probe.hip && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 #define LDA 80
 #define LDB 144
+
+__device__ int g_random_operands = 0;
 
 template <int V>
 __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(2, 2))) void probe(double *out, const double *src, int nst, long long stride) {
   extern __shared__ double lds[];
   double *As = lds, *Bs = lds + 2 * 8 * LDA;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
-  for (int i = tid; i < 2 * 8 * LDA + 2 * 8 * LDB; i += 256) lds[i] = 1.0 + 1e-9 * i;
+  for (int i = tid; i < 2 * 8 * LDA + 2 * 8 * LDB; i += 256) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
+    lds[i] = g_random_operands ? (double)(int)h * (1.0 / 2147483648.0) * (1.0 + 1e-13 * (h & 1023)) : 1.0 + 1e-9 * i;
+  }
   __syncthreads();
   v4d acc[2][2][4];
   for (int p = 0; p < 2; p++)
@@ -236,6 +243,11 @@ int main() {
   hipMalloc((void **)&out, (size_t)4096 * 256 * 8);
   hipMalloc((void **)&src, (size_t)1 << 30);
   hipMemset(src, 0, (size_t)1 << 30);
+  if (getenv("PROBE_RANDOM")) {  // operand tiles with random mantissas: the matrix cores' power draw is data dependent
+    int one = 1;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_random_operands), &one, sizeof(int));
+    printf("random operand values in LDS (V1-V3 read them; V4+ overwrite them with the zero-filled source)\n");
+  }
   run<0>(out, src, "MFMAs only");
   run<1>(out, src, "+ LDS fragment reads");
   run<2>(out, src, "+ two barriers per stage");
