@@ -186,6 +186,8 @@ struct Plan {
   // (the same allocation when nproc == 1)
   char *d_W = nullptr, *d_FBL = nullptr, *d_FBF = nullptr;  // esz-sized reals; capacities in reals
   size_t cap_W = 0, cap_FBL = 0, cap_FBF = 0;
+  char *d_Z = nullptr;  // one work-buffer row of zeros (k_leg_dir reads it for latitudes past the last one)
+  size_t cap_Z = 0;
   void *d_desc = nullptr;
   size_t cap_desc = 0;
 };
@@ -1023,6 +1025,7 @@ extern "C" int emi_release(int kresol) {
     emi_dev_free(kv.second.d_dir);
   }
   emi_dev_free(P->d_W);
+  emi_dev_free(P->d_Z);
   emi_dev_free(P->d_FBL);
   if (P->d_FBF != P->d_FBL) emi_dev_free(P->d_FBF);
   emi_dev_free(P->d_desc);
@@ -1266,6 +1269,7 @@ static int grow(char **p, size_t *cap, size_t need, const char *what) {
 static int ensure_work(Plan &P, int bfpad, int nfb) {
   const size_t rowb = (size_t)2 * bfpad * P.esz;
   if (grow(&P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer")) return -1;
+  if (grow(&P.d_Z, &P.cap_Z, rowb, "zero row")) return -1;  // grow() clears what it allocates; nothing writes here
   if (P.nproc == 1) {
     if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * P.frows * rowb, "Fourier work buffer")) return -1;
     P.d_FBF = P.d_FBL;
@@ -1973,7 +1977,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     // stream A: Legendre + spectral unpack
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sA);
     iv = g_pt.start(1, sA);
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, ldw, (RT *)P.d_W, ldw);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (const RT *)P.d_Z, ldw, (RT *)P.d_W, ldw);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);

@@ -277,20 +277,20 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 // (prfi2b_mod.F90:82-94, ledir_mod.F90:100-267 DGEMM('T','N') x2; Gaussian weights and
 //  1/(a cos) were folded into FB by k_fft_dir)
 // tile: 64 k (n-pairs) x 2 parities x 128 columns; wave (par, wn) owns 64 k x 64 col.
-EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, int ldf, real_t *W, int ldw) {
+// FULL: all four 16-row groups of the tile are live (nine tiles in ten): the stage loop is then one
+// straight-line block, which lets the compiler interleave the LDS fragment reads with the MFMAs.
+template <bool FULL>
+EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, const int ct, const int ni, const real_t *FB, const real_t *Z, int ldf,
+                            real_t *W, int ldw) {
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
   real_t *Bs = As + 2 * 16 * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int par = w & 1, wn = w >> 1;
-  const int2 tm = tilemap[EMI_BID];
-  if (tm.x < 0) return;
-  const int m = tm.x, kt = tm.y >> 16, ct = tm.y & 0xffff;
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
   const int nst = (ndglu + 15) >> 4;  // stages of 16 latitudes: 32 MFMAs per wave between barriers
-  const int ni = (nkpad - k0 + 15) >> 4 < 4 ? (nkpad - k0 + 15) >> 4 : 4;  // live 16-row groups of this tile
   const long long wb = g.wbase[m];
 
   acc4 acc[4][4];
@@ -307,6 +307,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
   const long long stepA = 16LL * ldk, rowA8 = 8LL * ldk;
   const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow + 4 i, i = 0..3, of each stage
   const real_t *FBc = FB + col0 + 2 * bc2;
+  const real_t *Zc = Z + col0 + 2 * bc2;         // a row of zeros: rows past the last latitude load it (no branch)
   real2 ra0, ra1, ra2, ra3;                      // P^T of stage s+1
   real2 rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
   // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
@@ -331,14 +332,14 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
     const int j0_ = 16 * (s_) + brow;                                               \
     const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + 4], is1 = rowS[j0_ + 4];         \
     const int in2 = rowN[j0_ + 8], is2 = rowS[j0_ + 8], in3 = rowN[j0_ + 12], is3 = rowS[j0_ + 12]; \
-    rn0 = in0 >= 0 ? *(const real2 *)(FBc + (long long)in0 * ldf) : mk2(0, 0);      \
-    rs0 = is0 >= 0 ? *(const real2 *)(FBc + (long long)is0 * ldf) : mk2(0, 0);      \
-    rn1 = in1 >= 0 ? *(const real2 *)(FBc + (long long)in1 * ldf) : mk2(0, 0);      \
-    rs1 = is1 >= 0 ? *(const real2 *)(FBc + (long long)is1 * ldf) : mk2(0, 0);      \
-    rn2 = in2 >= 0 ? *(const real2 *)(FBc + (long long)in2 * ldf) : mk2(0, 0);      \
-    rs2 = is2 >= 0 ? *(const real2 *)(FBc + (long long)is2 * ldf) : mk2(0, 0);      \
-    rn3 = in3 >= 0 ? *(const real2 *)(FBc + (long long)in3 * ldf) : mk2(0, 0);      \
-    rs3 = is3 >= 0 ? *(const real2 *)(FBc + (long long)is3 * ldf) : mk2(0, 0);      \
+    rn0 = *(const real2 *)(in0 >= 0 ? FBc + (long long)in0 * ldf : Zc);      \
+    rs0 = *(const real2 *)(is0 >= 0 ? FBc + (long long)is0 * ldf : Zc);      \
+    rn1 = *(const real2 *)(in1 >= 0 ? FBc + (long long)in1 * ldf : Zc);      \
+    rs1 = *(const real2 *)(is1 >= 0 ? FBc + (long long)is1 * ldf : Zc);      \
+    rn2 = *(const real2 *)(in2 >= 0 ? FBc + (long long)in2 * ldf : Zc);      \
+    rs2 = *(const real2 *)(is2 >= 0 ? FBc + (long long)is2 * ldf : Zc);      \
+    rn3 = *(const real2 *)(in3 >= 0 ? FBc + (long long)in3 * ldf : Zc);      \
+    rs3 = *(const real2 *)(is3 >= 0 ? FBc + (long long)is3 * ldf : Zc);      \
   }
 #define LEGDIR_LOADA(s_)                                          \
   {                                                               \
@@ -379,7 +380,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
       for (int j = 0; j < 4; j++) b[j] = Bs[(par * 16 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
 #pragma unroll
       for (int i = 0; i < 4; i++)
-        if (i < ni) {  // the last k tile of a wavenumber: 16-row groups past the end are skipped
+        if (FULL || i < ni) {  // the last k tile of a wavenumber: 16-row groups past the end are skipped
 #pragma unroll
           for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
         }
@@ -398,6 +399,16 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
         for (int jn = 0; jn < 4; jn++) pw[jn * 16] = acc[i][jn][q];
       }
     }
+}
+EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const real_t *Z, int ldf, real_t *W, int ldw) {
+  const int2 tm = tilemap[EMI_BID];
+  if (tm.x < 0) return;
+  const int m = tm.x, kt = tm.y >> 16, ct = tm.y & 0xffff;
+  const int left = ((g.wrows[m] >> 1) - kt * 64 + 15) >> 4;  // live 16-row groups of this tile
+  if (left >= 4)
+    leg_dir_tile<true>(g, m, kt, ct, 4, FB, Z, ldf, W, ldw);
+  else
+    leg_dir_tile<false>(g, m, kt, ct, left, FB, Z, ldf, W, ldw);
 }
 
 // ==========================================================================================

@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import ectrans_amd as et
+if os.environ.get("EMI_LIB"):  # A/B runs of two builds on the same box
+    et._use_library_for_tests(os.environ["EMI_LIB"])
 N, nlev, nfld = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 prec = int(sys.argv[5]) if len(sys.argv) > 5 else 8
