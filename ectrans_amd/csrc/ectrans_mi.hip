@@ -1238,11 +1238,15 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
     emi_h2d(d, h, elems * esz, s);
     return d;
   }
-  void *out(void *h, size_t elems, bool host) {
+  // preload: the call does not write every element of the array (padding of the last NPROMA block, more
+  // fields in the array than the call produces) -- start from the caller's contents so that the copy back
+  // leaves those elements as they were, as the reference does
+  void *out(void *h, size_t elems, bool host, bool preload = false, emi_stream_t s = 0) {
     if (!h || !host) return h;
     void *d = nullptr;
     if (emi_dev_malloc(&d, elems * esz)) return nullptr;
     dev.push_back(d);
+    if (preload) emi_h2d(d, h, elems * esz, s);
     outs.push_back({d, {h, elems * esz}});
     return d;
   }
@@ -1633,11 +1637,12 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   const int nvar_uv = ((nuv && lvorgp) ? 1 : 0) + ((nuv && ldivgp) ? 1 : 0) + 2 + (luvder ? 2 : 0);
   const int dmul = lscders ? 3 : 1;
   const size_t gsz = (size_t)nproma * ngpblks;
-  void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host);
-  void *d_gpuv = hs.out(a.gpuv, gsz * nuv * nvar_uv, host && nuv);
-  void *d_gp2 = hs.out(a.gp2, gsz * a.nf_sc2 * dmul, host);
-  void *d_gp3a = hs.out(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar * dmul, host);
-  void *d_gp3b = hs.out(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar * dmul, host);
+  const bool gpad = gsz != (size_t)P.ngptot;  // last NPROMA block padded: those elements are not written
+  void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host, gpad || a.gp_nfld > if_gp, st);
+  void *d_gpuv = hs.out(a.gpuv, gsz * nuv * nvar_uv, host && nuv, gpad, st);
+  void *d_gp2 = hs.out(a.gp2, gsz * a.nf_sc2 * dmul, host, gpad, st);
+  void *d_gp3a = hs.out(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar * dmul, host, gpad, st);
+  void *d_gp3b = hs.out(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar * dmul, host, gpad, st);
 
   // ---- Legendre-space fields (ltinv_mod.F90:166-262): [vor][div] u v scalars [nsders]
   std::vector<SpecSrc> lt;

@@ -218,6 +218,29 @@ def test_call_mode_2_arrays_and_batches(et):
     et.trans_release(r)
 
 
+def test_host_output_arrays_keep_unwritten_elements(et):
+    """Host arrays are staged through device memory: what INV_TRANS does not write -- the padding of the last
+    NPROMA block, fields of PGP beyond those the call produces -- must come back as the caller left it (the
+    reference never touches those elements)."""
+    N = 8
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+    npr = 37
+    nb = (ng - 1) // npr + 1
+    assert nb * npr > ng
+    rng = np.random.default_rng(11)
+    sp = rng.uniform(-1, 1, (ns2, 2))
+    junk = [np.full(50000, np.nan) for _ in range(4)]  # poison the heap the staging buffers come from
+    del junk
+    gp = np.full((nb, 3, npr), -7.25)  # one field more than the call produces
+    et.inv_trans(r, pspscalar=sp, pgp=gp, kproma=npr)
+    tail = ng - (nb - 1) * npr
+    assert np.all(gp[-1, :, tail:] == -7.25) and np.all(gp[:, 2, :] == -7.25)
+    assert np.all(np.isfinite(gp)) and np.all(gp[:-1, :2, :] != -7.25)
+    et.trans_release(r)
+
+
 def test_argument_errors_mirror_abort_trans(et):
     N = 8
     nloen = octahedral(N)

@@ -222,6 +222,27 @@ def test_host_arrays_match_oracle(et):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
+def test_host_output_arrays_keep_unwritten_elements(et):
+    """What INV_TRANS does not write (padding of the last NPROMA block, surplus fields of PGP) comes back
+    from the device staging as the caller left it."""
+    N = 21
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        npr = 97
+        nb = (ng - 1) // npr + 1
+        assert nb * npr > ng
+        sp = np.random.default_rng(11).uniform(-1, 1, (ns2, 2))
+        gp = np.full((nb, 3, npr), -7.25)
+        et.inv_trans(r, pspscalar=sp, pgp=gp, kproma=npr)
+        tail = ng - (nb - 1) * npr
+        assert np.all(gp[-1, :, tail:] == -7.25) and np.all(gp[:, 2, :] == -7.25)
+        assert np.all(np.isfinite(gp)) and np.all(gp[:-1, :2, :] != -7.25)
+    finally:
+        et.trans_release(r)
+
+
 def test_field_batching_is_invisible(et, dev):
     """NPROMATR-like field packets (dir_trans_ctl_mod.F90:128-175): results must not depend on
     the batch size."""
