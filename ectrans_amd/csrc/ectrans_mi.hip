@@ -759,14 +759,22 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
 
   // ---- Fourier-buffer row tables.  One task: both sides share one latitude-major buffer
   // (row = fbase[lat] + m).  Several tasks: the Legendre-side buffer is cut into one block per
-  // destination task (rows ordered wavenumber-major, then latitude), the FFT-side buffer into one
-  // block per source task with exactly the same row order, so the all-to-all-v moves whole blocks.
+  // destination task, the FFT-side buffer into one block per source task with exactly the same row
+  // order, so the all-to-all-v moves whole blocks.  Inside a block the rows are latitude-major, then
+  // wavenumber -- the order of the one-task buffer restricted to the block: an FFT workgroup then finds the
+  // wavenumbers of its latitude in NPROC short contiguous runs.  (The other order, wavenumber-major, makes
+  // every Fourier row of a latitude a separate far-apart line: measured on one task, EMI_FB_ORDER=m with
+  // EMI_FB_TABLE=1, the FFT kernels are 13-20 % slower and the Legendre kernels 1 % faster; the row table
+  // itself costs the FFT kernels 1.5 %.)
   std::vector<int> legN(P.lbase[NU]), legS(P.lbase[NU]), fftrow(P.frows);
   P.leg_rows.assign(NP, 0);
   P.leg_disp.assign(NP, 0);
   P.fft_rows.assign(NP, 0);
   P.fft_disp.assign(NP, 0);
-  if (NP == 1) {
+  const char *fbo = getenv("EMI_FB_ORDER");
+  const bool mmajor = fbo && fbo[0] == 'm';                 // experiment / A-B: wavenumber-major blocks
+  const bool tables = NP > 1 || mmajor || getenv("EMI_FB_TABLE");  // one task: plain affine rows unless asked
+  if (!tables) {
     for (int ml = 0; ml < NU; ml++) {
       const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
       for (int j = 0; j < nd; j++) {
@@ -777,7 +785,12 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
     for (long long i = 0; i < P.frows; i++) fftrow[i] = (int)i;
     P.leg_rows[0] = P.fft_rows[0] = P.frows;
   } else {
-    // Legendre side: block d holds (ml ascending, lat in band d ascending with NMEN(lat) >= m)
+    for (int ml = 0; ml < NU; ml++)
+      if (ml > 0 && P.mval[ml] <= P.mval[ml - 1]) {
+        delete pp;
+        EMI_FAIL(EMI_ERR_RUNTIME, "internal: local wavenumbers not ascending");
+      }
+    // Legendre side: block d holds the rows (lat in band d, local wavenumber ml with m <= NMEN(lat))
     for (int ml = 0; ml < NU; ml++) {
       const int m = P.mval[ml];
       for (int lat = 0; lat < L; lat++)
@@ -786,27 +799,50 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
     for (int d = 1; d < NP; d++) P.leg_disp[d] = P.leg_disp[d - 1] + P.leg_rows[d - 1];
     {
       std::vector<long long> pos(P.leg_disp);
-      std::vector<int> rowof(L);
-      for (int ml = 0; ml < NU; ml++) {
-        const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
-        for (int lat = 0; lat < L; lat++)
-          if (P.nmen[lat] >= m) rowof[lat] = (int)pos[band_of(lat)]++;
-        for (int j = 0; j < nd; j++) {
-          legN[P.lbase[ml] + j] = rowof[isl0 + j];
-          legS[P.lbase[ml] + j] = rowof[L - 1 - isl0 - j];
+      if (mmajor) {
+        std::vector<int> rowof(L);
+        for (int ml = 0; ml < NU; ml++) {
+          const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
+          for (int lat = 0; lat < L; lat++)
+            if (P.nmen[lat] >= m) rowof[lat] = (int)pos[band_of(lat)]++;
+          for (int j = 0; j < nd; j++) {
+            legN[P.lbase[ml] + j] = rowof[isl0 + j];
+            legS[P.lbase[ml] + j] = rowof[L - 1 - isl0 - j];
+          }
+        }
+      } else {
+        // the local wavenumbers are ascending, so those present at a latitude are ml = 0 .. cnt-1 and the
+        // row of (lat, ml) is the first row of the latitude + ml
+        std::vector<long long> latbase(L);
+        for (int lat = 0; lat < L; lat++) {
+          const int cnt = (int)(std::upper_bound(P.mval.begin(), P.mval.end(), P.nmen[lat]) - P.mval.begin());
+          latbase[lat] = pos[band_of(lat)];
+          pos[band_of(lat)] += cnt;
+        }
+        for (int ml = 0; ml < NU; ml++) {
+          const int nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
+          for (int j = 0; j < nd; j++) {
+            legN[P.lbase[ml] + j] = (int)(latbase[isl0 + j] + ml);
+            legS[P.lbase[ml] + j] = (int)(latbase[L - 1 - isl0 - j] + ml);
+          }
         }
       }
     }
-    // FFT side: block s holds (wavenumbers of task s ascending, local lat ascending with NMEN >= m)
+    // FFT side: block s holds the rows (local lat, wavenumber m of task s with m <= NMEN(lat)), same order
     for (int m = 0; m <= N; m++)
       for (int jl = 0; jl < NL; jl++)
         if (P.l_nmen[jl] >= m) P.fft_rows[P.procm[m]]++;
     for (int sr = 1; sr < NP; sr++) P.fft_disp[sr] = P.fft_disp[sr - 1] + P.fft_rows[sr - 1];
     {
       std::vector<long long> pos(P.fft_disp);
-      for (int m = 0; m <= N; m++)
+      if (mmajor) {
+        for (int m = 0; m <= N; m++)
+          for (int jl = 0; jl < NL; jl++)
+            if (P.l_nmen[jl] >= m) fftrow[P.l_fbase[jl] + m] = (int)pos[P.procm[m]]++;
+      } else {
         for (int jl = 0; jl < NL; jl++)
-          if (P.l_nmen[jl] >= m) fftrow[P.l_fbase[jl] + m] = (int)pos[P.procm[m]]++;
+          for (int m = 0; m <= P.l_nmen[jl]; m++) fftrow[P.l_fbase[jl] + m] = (int)pos[P.procm[m]]++;
+      }
     }
     long long tl = 0, tf = 0;
     for (int r = 0; r < NP; r++) tl += P.leg_rows[r], tf += P.fft_rows[r];
@@ -926,7 +962,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   g.gpoff = d_gpoff;
   g.nasm0 = d_nasm0;
   g.fbase = d_fbase;
-  g.fftrow = NP == 1 ? nullptr : d_fftrow;  // one task: rows are fbase[lat] + m, no table
+  g.fftrow = tables ? d_fftrow : nullptr;  // one task: rows are fbase[lat] + m, no table
   g.lbase = d_lbase;
   g.legN = d_legN;
   g.legS = d_legS;

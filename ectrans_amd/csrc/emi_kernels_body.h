@@ -237,6 +237,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
       rb2 = *(const real2 *)(pW + 2 * rowW4);
       rb3 = *(const real2 *)(pW + 3 * rowW4);
     }
+    EMI_PRIO_HI();
 #pragma unroll
     for (int p = 0; p < 2; p++)
 #pragma unroll
@@ -252,6 +253,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 #pragma unroll
           for (int j = 0; j < 4; j++) acc[p][i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[p][i][j]);
       }
+    EMI_PRIO_LO();
   }
   // epilogue (ASRE1B): rows = latitudes
   const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
@@ -370,6 +372,7 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
       LEGDIR_LOADB(s + 1);
       LEGDIR_LOADA(s + 1);
     }
+    EMI_PRIO_HI();
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
       const int kk = 4 * ks + (l >> 4);
@@ -385,6 +388,7 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
           for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
         }
     }
+    EMI_PRIO_LO();
   }
 #undef LEGDIR_LOADA
 #undef LEGDIR_LOADB

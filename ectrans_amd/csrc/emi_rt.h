@@ -39,6 +39,12 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 #define EMI_LDS_DECL extern __shared__ __attribute__((aligned(16))) char emi_lds_raw[]
+// Wave priority around the MFMA block of the Legendre stage loops: the two waves of a SIMD are in
+// different phases (one issues MFMAs, the other address arithmetic, LDS writes and loads for its next
+// stage); with the MFMA wave at the higher priority its next MFMA never queues behind the other wave's
+// vector instructions.  Measured +2.5 % on both Legendre kernels (priority 1 and 3 alike).
+#define EMI_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define EMI_PRIO_LO() __builtin_amdgcn_s_setprio(0)
 #define EMI_LDS_PTR (emi_lds_raw)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -94,6 +100,8 @@ static inline void emu_barrier() {
 #define EMI_SYNC() emu_barrier()
 #define EMI_WAVE_SYNC() emu_barrier()  // lanes are threads here: a real barrier
 #define EMI_LDS_DECL
+#define EMI_PRIO_HI() ((void)0)
+#define EMI_PRIO_LO() ((void)0)
 #define EMI_LDS_PTR (emu_ctx->lds)
 
 typedef double v4d __attribute__((vector_size(32)));

@@ -8,14 +8,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_wset_sharding_with_alltoallv(world):
+@pytest.mark.parametrize("world,order", [(2, "lat"), (3, "lat"), (2, "m")])
+def test_wset_sharding_with_alltoallv(world, order):
+    """order: row order inside the exchanged Fourier blocks -- latitude-major (default) or wavenumber-major
+    (EMI_FB_ORDER=m, kept for A/B measurements)."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
     port = 29510 + world
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1024", EMI_TEST_NSMAX="9")
+                   OMP_NUM_THREADS="1024", EMI_TEST_NSMAX="9", EMI_FB_ORDER=order)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
