@@ -271,11 +271,34 @@ static int build_fft_plans(Plan &P) {
     if (pl.blue) {
       pl.S = emi::next_235(2 * pl.sz - 1);
       emi::factorize_smooth(pl.S, fac);
+      // EMI_FFT_MERGE=1 (off by default): a specialised kernel with the last two factors merged into one
+      // composite radix 6, 9 or 10 (one LDS round trip fewer).  Even NLOEN only: odd rows run the generic
+      // kernels, which have no such butterflies.  Measured at TCo1279: the direct kernels gain 2 % (95.4 against
+      // 97.6 ms), the inverse ones lose 6 % (110.4 against 104.3 ms: their last pass, fused with the grid
+      // store, spills 112-136 B per lane at radix 9 and 10), and one plan serves both directions.
+      std::vector<int> fm;
+      const char *mg = getenv("EMI_FFT_MERGE");
+      if (mg && atoi(mg) != 0 && !pl.cmode && !getenv("EMI_FFT_NO_HOT") && emi::merge_tail(fac, fm)) {
+        static const int hp[][9] = {
+#define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_) {pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_},
+            EMI_HOT_PLAN_LIST(EMI_HOT_ROW)
+#undef EMI_HOT_ROW
+        };
+        for (const auto &r : hp) {
+          bool same = r[1] == pl.S && r[2] == (int)fm.size();
+          for (size_t i = 0; same && i < fm.size(); i++) same = r[3 + i] == fm[i];
+          if (same) {
+            fac = fm;
+            break;
+          }
+        }
+      }
     }
     if (pl.S > 65535 || fac.size() > 14) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d not supported (work size %d)", n, pl.S);
     pl.nfac = (int)fac.size();
     for (int i = 0; i < pl.nfac; i++) pl.fac[i] = fac[i];
-    auto si = sidx.find(pl.S);
+    const int skey = pl.S * 16 + pl.nfac;  // the tables depend on the factor list: merged and plain lists differ in length
+    auto si = sidx.find(skey);
     if (si == sidx.end()) {
       Shared sh{};
       sh.S = pl.S;
@@ -290,7 +313,7 @@ static int build_fft_plans(Plan &P) {
         if (lenp > 1) n_ptw += (size_t)(fac[ip] - 1) * lenp;
         lenp *= fac[ip];
       }
-      si = sidx.emplace(pl.S, (int)shared.size()).first;
+      si = sidx.emplace(skey, (int)shared.size()).first;
       shared.push_back(sh);
     }
     const Shared &sh = shared[si->second];

@@ -497,6 +497,43 @@ EMI_DEVFN void butterfly(real2 *v, const real2 *tw, int S, int sgn) {
       v[2 * k2] = t0[k2];
       v[2 * k2 + 1] = t1[k2];
     }
+  } else if constexpr (R == 6 || R == 9 || R == 10) {
+    // composite radices of the specialised kernels (work lengths 3072 = 8^3 * 6, 4608 = 8^3 * 9,
+    // 5120 = 8^3 * 10: four LDS round trips instead of five): Cooley-Tukey inside the registers,
+    // n = R2 n1 + n2, k = k1 + R1 k2 with constant twiddles W_R^{n2 k1}
+    constexpr int R1 = (R == 10) ? 5 : 3, R2 = R / R1;
+    real2 t[R2][R1];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; n2++) {
+#pragma unroll
+      for (int n1 = 0; n1 < R1; n1++) t[n2][n1] = v[R2 * n1 + n2];
+      butterfly<R1>(t[n2], tw, S, sgn);
+    }
+    // cos / sin of 2 pi j / R, j = 0 .. 4 (all that n2 k1 reaches)
+    constexpr real_t c6[5] = {1.0, 0.5, -0.5, -1.0, -0.5}, s6[5] = {0.0, 0.86602540378443864676, 0.86602540378443864676, 0.0, -0.86602540378443864676};
+    constexpr real_t c9[5] = {1.0, 0.76604444311897803520, 0.17364817766693034885, -0.5, -0.93969262078590838405};
+    constexpr real_t s9[5] = {0.0, 0.64278760968653932632, 0.98480775301220805937, 0.86602540378443864676, 0.34202014332566873304};
+    constexpr real_t c10[5] = {1.0, 0.80901699437494742410, 0.30901699437494742410, -0.30901699437494742410, -0.80901699437494742410};
+    constexpr real_t s10[5] = {0.0, 0.58778525229247312917, 0.95105651629515357212, 0.95105651629515357212, 0.58778525229247312917};
+#pragma unroll
+    for (int n2 = 1; n2 < R2; n2++)
+#pragma unroll
+      for (int k1 = 1; k1 < R1; k1++) {
+        const int j = n2 * k1;
+        const real_t c = (R == 6) ? c6[j] : (R == 9) ? c9[j] : c10[j];
+        const real_t sn = ((R == 6) ? s6[j] : (R == 9) ? s9[j] : s10[j]) * (real_t)sgn;  // forward: exp(-i..)
+        const real2 a = t[n2][k1];
+        t[n2][k1] = mk2(a.x * c - a.y * sn, a.x * sn + a.y * c);
+      }
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) {
+      real2 u[R2];
+#pragma unroll
+      for (int n2 = 0; n2 < R2; n2++) u[n2] = t[n2][k1];
+      butterfly<R2>(u, tw, S, sgn);
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) v[k1 + R1 * k2] = u[k2];
+    }
   } else {
     // generic small prime (7): DFT matrix rows from the twiddle table, fully unrolled
     real2 y[R], w[R];
@@ -533,7 +570,9 @@ EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_cl
 // table [t-1][j], all in flight together with the LDS reads -- and applied before (DIT) or after
 // (DIF) the butterfly.
 // one butterfly q of one field
-template <int R, int DIF, int MASK, int TW>
+// NOUT: outputs t < NOUT are stored (the last pass of a Bluestein convolution, of which only the first sz <= (S+1)/2
+// elements are ever read: the rest of the butterfly is dead code)
+template <int R, int DIF, int MASK, int TW, int NOUT = R>
 EMI_DEVFN void fft_bfly_at(real2 *af, int q, int S, int lenp, int sh, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
   const int len = lenp * R;
   int blk, j;
@@ -575,23 +614,23 @@ EMI_DEVFN void fft_bfly_at(real2 *af, int q, int S, int lenp, int sh, const real
     for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
   }
 #pragma unroll
-  for (int t = 0; t < R; t++) af[FPAD(base + t * lenp)] = v[t];
+  for (int t = 0; t < NOUT; t++) af[FPAD(base + t * lenp)] = v[t];
 }
 // FLAT = 0: field after field, butterfly q = tid + i * nthreads of each (long rows: every sweep is full
 // anyway).  FLAT = 1: the (field, butterfly) pairs of the workgroup are dealt to the threads as one list,
 // so short rows (fewer butterflies than threads) still fill the sweeps.
-template <int R, int DIF, int MASK, int TW, int FLAT = 0>
+template <int R, int DIF, int MASK, int TW, int FLAT = 0, int NOUT = R>
 EMI_DEVFN void fft_pass_body(real2 *a, int nfl, int fstride, int S, int lenp, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
   const int nb = S / R, sh = log2_exact(lenp);
   if (FLAT) {
     for (int idx = EMI_TID; idx < nfl * nb; idx += EMI_NTHREADS) {
       const int fl = idx / nb, q = idx - fl * nb;
-      fft_bfly_at<R, DIF, MASK, TW>(a + (long long)fl * fstride, q, S, lenp, sh, tw, ptw, sgn, nvalid);
+      fft_bfly_at<R, DIF, MASK, TW, NOUT>(a + (long long)fl * fstride, q, S, lenp, sh, tw, ptw, sgn, nvalid);
     }
   } else {
     for (int fl = 0; fl < nfl; fl++) {
       real2 *af = a + (long long)fl * fstride;
-      for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) fft_bfly_at<R, DIF, MASK, TW>(af, q, S, lenp, sh, tw, ptw, sgn, nvalid);
+      for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) fft_bfly_at<R, DIF, MASK, TW, NOUT>(af, q, S, lenp, sh, tw, ptw, sgn, nvalid);
     }
   }
 }
@@ -737,9 +776,12 @@ EMI_DEVFN bool grid_pair_ok(const GridRow &r, unsigned o) {
 // final DIT pass of the inverse real transform, stored straight to the grid array:
 // logical output z_i (i < sz): x_{2i} = Re, x_{2i+1} = Im (or x_i = Re z_i in complex mode),
 // Bluestein: z_i = a'_i * conj(chirp_i) / L.
-template <int R>
+// BLUE (specialised kernels: always Bluestein): i = j + t lenp < sz <= (S+1)/2 only for t < (R+1)/2 -- the other
+// outputs, their chirp values and the part of the butterfly that only feeds them are never generated.
+template <int R, int BLUE = 0>
 EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, const real2 *tw, const real2 *ptw, const FftPlanDev &pl,
                                 const real2 *chirp, const GridFld *flds, int f0, long long gp0, int nproma) {
+  constexpr int NOUT = BLUE ? (R + 1) / 2 : R;
   const int nb = S / R, sh = log2_exact(lenp), sz = pl.sz;
   const real_t invL = pl.blue ? (real_t)(1.0 / (double)S) : (real_t)1.0;
   for (int fl = 0; fl < nfl; fl++) {
@@ -749,7 +791,7 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
       int blk, j;
       split_q(q, lenp, sh, blk, j);  // last pass: len == S, blk == 0
-      real2 v[R], w[R], ch[R];
+      real2 v[R], w[R], ch[NOUT];
       if (lenp > 1) {
         const real2 *pw_ = ptw + j;
 #pragma unroll
@@ -761,13 +803,17 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
 #pragma unroll
         for (int t = 1; t < R; t++) v[t] = cmulc(v[t], w[t]);  // inverse: conjugate twiddles
       }
-      if (pl.blue) {  // chirp values of the outputs: in flight during the butterfly
+      if (pl.blue && R <= 8) {  // chirp values of the outputs: in flight during the butterfly
 #pragma unroll
-        for (int t = 0; t < R; t++) ch[t] = (j + t * lenp < sz) ? chirp[j + t * lenp] : mk2(0.0, 0.0);
+        for (int t = 0; t < NOUT; t++) ch[t] = (j + t * lenp < sz) ? chirp[j + t * lenp] : mk2(0.0, 0.0);
       }
       butterfly<R>(v, tw, S, +1);
+      if (pl.blue && R > 8) {  // composite radices: no registers to spare during the butterfly
 #pragma unroll
-      for (int t = 0; t < R; t++) {
+        for (int t = 0; t < NOUT; t++) ch[t] = (j + t * lenp < sz) ? chirp[j + t * lenp] : mk2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int t = 0; t < NOUT; t++) {
         const int i = j + t * lenp;
         if (i < sz) {
           real2 z = v[t];
@@ -788,6 +834,12 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
       }
     }
   }
+}
+
+template <int R>
+EMI_DEVFN void dit_last_to_grid_any(real2 *a, int nfl, int fs, int S, int lenp, const real2 *tw, const real2 *ptw, const FftPlanDev &pl,
+                                    const real2 *chirp, const GridFld *flds, int f0, long long gp0, int nproma) {
+  dit_last_to_grid<R, 0>(a, nfl, fs, S, lenp, tw, ptw, pl, chirp, flds, f0, gp0, nproma);
 }
 
 // ==========================================================================================
@@ -901,7 +953,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
     lenp = run_dit(a, nfl, fs, S, pl, T, 0, pl.nfac - 1, 1, +1);
   }
   const int rl = pl.fac[pl.nfac - 1];
-  FFT_DISPATCH(dit_last_to_grid, rl, a, nfl, fs, S, lenp, tw, (const real2 *)T.ptw + pl.ptw_off[pl.nfac - 1], pl, chirp, flds, f0, gp0, nproma);
+  FFT_DISPATCH(dit_last_to_grid_any, rl, a, nfl, fs, S, lenp, tw, (const real2 *)T.ptw + pl.ptw_off[pl.nfac - 1], pl, chirp, flds, f0, gp0, nproma);
 }
 
 // ==========================================================================================
@@ -1054,7 +1106,9 @@ template <int PC, int IP, int END>
 EMI_DEVFN void hot_dit(real2 *a, int nfl, int fs, const FftPlanDev &pl, const real2 *tw, const real2 *ptw) {
   constexpr HotPlanC H = hot_plan(PC);
   if constexpr (IP < END) {
-    fft_pass_body<H.fac[IP], 0, 0, 1, (H.nfl > 1)>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], +1, H.S);
+    // the very last pass of the convolution (direct transform): only the first half of its outputs is read
+    constexpr int R = H.fac[IP], NOUT = (IP == H.nfac - 1) ? (R + 1) / 2 : R;
+    fft_pass_body<R, 0, 0, 1, (H.nfl > 1), NOUT>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], +1, H.S);
     if constexpr (IP + 1 < H.nfac)
       HOT_SYNC(IP, IP + 1);
     else
@@ -1118,7 +1172,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   EMI_SYNC();
   hot_conv<PC, 0>(a, nfl, fs, pl, T, 1, sz);
   constexpr int last = H.nfac - 1;
-  dit_last_to_grid<H.fac[last]>(a, nfl, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
+  dit_last_to_grid<H.fac[last], 1>(a, nfl, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
                                 (const real2 *)T.ptw + pl.ptw_off[last], pl, chirp, flds, f0, g.gpoff[lat], nproma);
   (void)n;
 }

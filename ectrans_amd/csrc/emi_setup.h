@@ -250,6 +250,18 @@ inline bool factorize_smooth(int s, std::vector<int> &fac) {
     }
   return s == 1;
 }
+// The last two factors (2,3), (3,3), (2,5) as one composite radix 6, 9, 10 (specialised FFT kernels only:
+// their butterflies do the two steps in registers).  Returns false when the list does not end that way.
+inline bool merge_tail(const std::vector<int> &fac, std::vector<int> &out) {
+  const size_t n = fac.size();
+  if (n < 2) return false;
+  const int a = fac[n - 2], b = fac[n - 1];
+  if (!((a == 2 && b == 3) || (a == 3 && b == 3) || (a == 2 && b == 5))) return false;
+  if (n >= 3 && fac[n - 3] != 8) return false;  // e.g. 8,8,4,... 3,3,3 or 2,3,5 tails stay as they are
+  out.assign(fac.begin(), fac.end() - 2);
+  out.push_back(a * b);
+  return true;
+}
 // Bluestein work length: among 2^a * {1,3,5,9,15} >= n, the one minimising L * (passes + 1)
 inline int next_235(int n) {
   static const int odd[] = {1, 3, 5, 9, 15};
