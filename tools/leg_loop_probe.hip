@@ -209,16 +209,115 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
   out[(long long)blockIdx.x * 256 + tid] = sum;
 }
 
+// V14-V17 "ping-pong": a 512-thread workgroup = two 256-thread halves, each with its own tile, LDS image and
+// prefetch registers (one wave of each half per SIMD).  The halves alternate phases separated by ONE workgroup
+// barrier: in phase p half (p & 1) runs the 32 MFMAs of its stage while the other half waits for its prefetched
+// operands, writes them to its LDS image and requests the next ones -- matrix work beside memory work by
+// construction, 2 barriers per pair of stages instead of 4.  HEAVY: the non-MFMA phase of k_leg_dir (12 loads,
+// 8 add/sub pairs, 12 LDS writes instead of 6 loads and 6 writes).
+template <int HIT, int HEAVY>
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(2, 2))) void probe_pp(double *out, const double *src, int nst, long long stride) {
+  extern __shared__ double lds[];
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
+  const int area = 2 * 8 * LDA + (HEAVY ? 4 : 2) * 8 * LDB;
+  double *As = lds + half * area, *Bs = As + 2 * 8 * LDA, *Bx = Bs + 2 * 8 * LDB;
+  for (int i = tid; i < area; i += 256) As[i] = 1.0 + 1e-9 * i;
+  __syncthreads();
+  v4d acc[2][2][4];
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) acc[p][i][j] = (v4d){0, 0, 0, 0};
+  const int arow = tid >> 5, ac2 = tid & 31, brow = tid >> 6, bc2 = tid & 63;
+  const double *g = src + (long long)(blockIdx.x * 2 + half) * 4096 + tid * 2;
+  d2 ra0 = {1, 2}, ra1 = {3, 4}, rb0 = {5, 6}, rb1 = {7, 8}, rb2 = {9, 10}, rb3 = {11, 12};
+  d2 rc0 = ra0, rc1 = ra1, rc2 = rb0, rc3 = rb1, rc4 = rb2, rc5 = rb3;
+#define PP_LOAD(s_)                                                                                         \
+  {                                                                                                         \
+    const double *q = g + (HIT ? 0 : (long long)(s_) * stride);                                             \
+    ra0 = *(const d2 *)q, ra1 = *(const d2 *)(q + 512), rb0 = *(const d2 *)(q + 1024), rb1 = *(const d2 *)(q + 1536); \
+    rb2 = *(const d2 *)(q + 2048), rb3 = *(const d2 *)(q + 2560);                                           \
+    if (HEAVY) {                                                                                            \
+      const double *q2 = q + stride / 2 + 3072;                                                             \
+      rc0 = *(const d2 *)q2, rc1 = *(const d2 *)(q2 + 512), rc2 = *(const d2 *)(q2 + 1024), rc3 = *(const d2 *)(q2 + 1536); \
+      rc4 = *(const d2 *)(q2 + 2048), rc5 = *(const d2 *)(q2 + 2560);                                       \
+    }                                                                                                       \
+  }
+#define PP_STORE()                                                                                          \
+  {                                                                                                         \
+    *(d2 *)(As + (0 * 8 + arow) * LDA + 2 * ac2) = ra0;                                                     \
+    *(d2 *)(As + (1 * 8 + arow) * LDA + 2 * ac2) = ra1;                                                     \
+    if (!HEAVY) {                                                                                           \
+      *(d2 *)(Bs + (((brow + 0) & 1) * 8 + ((brow + 0) >> 1)) * LDB + 2 * bc2) = rb0;                       \
+      *(d2 *)(Bs + (((brow + 4) & 1) * 8 + ((brow + 4) >> 1)) * LDB + 2 * bc2) = rb1;                       \
+      *(d2 *)(Bs + (((brow + 8) & 1) * 8 + ((brow + 8) >> 1)) * LDB + 2 * bc2) = rb2;                       \
+      *(d2 *)(Bs + (((brow + 12) & 1) * 8 + ((brow + 12) >> 1)) * LDB + 2 * bc2) = rb3;                     \
+    } else {                                                                                                \
+      *(d2 *)(Bx + (0 * 8 + arow) * LDA + 2 * ac2) = rc0;                                                   \
+      *(d2 *)(Bx + (1 * 8 + arow) * LDA + 2 * ac2) = rc1;                                                   \
+      *(d2 *)(Bs + (0 * 8 + brow) * LDB + 2 * bc2) = rb0 + rc2;                                             \
+      *(d2 *)(Bs + (1 * 8 + brow) * LDB + 2 * bc2) = rb0 - rc2;                                             \
+      *(d2 *)(Bs + (0 * 8 + brow + 4) * LDB + 2 * bc2) = rb1 + rc3;                                         \
+      *(d2 *)(Bs + (1 * 8 + brow + 4) * LDB + 2 * bc2) = rb1 - rc3;                                         \
+      *(d2 *)(Bx + 2 * 8 * LDA + (0 * 8 + brow) * LDB + 2 * bc2) = rb2 + rc4;                               \
+      *(d2 *)(Bx + 2 * 8 * LDA + (1 * 8 + brow) * LDB + 2 * bc2) = rb2 - rc4;                               \
+      *(d2 *)(Bx + 2 * 8 * LDA + (0 * 8 + brow + 4) * LDB + 2 * bc2) = rb3 + rc5;                           \
+      *(d2 *)(Bx + 2 * 8 * LDA + (1 * 8 + brow + 4) * LDB + 2 * bc2) = rb3 - rc5;                           \
+    }                                                                                                       \
+  }
+  PP_LOAD(0);
+  if (half == 0) {
+    PP_STORE();
+    PP_LOAD(1);
+  }
+  __syncthreads();
+  for (int p = 0; p < 2 * nst; p++) {
+    const int s = p >> 1;
+    if ((p & 1) == half) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          const int kk = 4 * ks + (l >> 4);
+          double a[2], b[4];
+#pragma unroll
+          for (int i = 0; i < 2; i++) a[i] = As[(pr * 8 + kk) * LDA + wm * 32 + i * 16 + (l & 15)];
+#pragma unroll
+          for (int j = 0; j < 4; j++) b[j] = Bs[(pr * 8 + kk) * LDB + wn * 64 + j * 16 + (l & 15)];
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[pr][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[pr][i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+      PP_STORE();
+      PP_LOAD(s + 2);
+    }
+    __syncthreads();
+  }
+#undef PP_LOAD
+#undef PP_STORE
+  double sum = ra0.x + rb3.y + rc0.x + rc5.y;
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
+  out[(long long)blockIdx.x * 512 + threadIdx.x] = sum;
+}
+
 template <int V>
-static void run(double *out, const double *src, const char *what) {
-  const int nblk = 256 * 2 * 8, nst = 80;  // 16 tiles per CU-slot, K = 640 n-pairs
+static void run(double *out, const double *src, const char *what, int nst = 80) {
+  const int nblk = 256 * 2 * 8;  // 16 tiles per CU-slot; nst = 80: K = 640 n-pairs
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   float best = 1e30f;
   for (int rep = 0; rep < 4; rep++) {
     hipEventRecord(e0, 0);
-    if (V == 8 || V == 9)
+    if (V >= 14 && V <= 17)
+      hipLaunchKernelGGL((probe_pp<(V & 1), (V >= 16)>), dim3(nblk / 2), dim3(512), 2 * (2 * 8 * LDA + (V >= 16 ? 4 : 2) * 8 * LDB) * 8, 0, out, src, nst,
+                         (long long)4096 * nblk / 64);
+    else if (V == 8 || V == 9)
       hipLaunchKernelGGL(probe_glds<(V == 9)>, dim3(nblk), dim3(256), 3 * 3072 * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
     else if (V >= 10 && V <= 12)
       hipLaunchKernelGGL((probe_glds<1, V - 9>), dim3(nblk), dim3(256), 3 * 3072 * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
@@ -235,7 +334,7 @@ static void run(double *out, const double *src, const char *what) {
     if (ms < best) best = ms;
   }
   double flops = (double)nblk * 4 * nst * 32 * 2048.0;
-  printf("V%d %-44s %6.1f TFLOP/s  (%.1f %% of 78.6)\n", V, what, flops / best / 1e9, 100 * flops / best / 1e9 / 78.6);
+  printf("V%d nst %2d %-44s %6.1f TFLOP/s  (%.1f %% of 78.6)\n", V, nst, what, flops / best / 1e9, 100 * flops / best / 1e9 / 78.6);
 }
 
 int main() {
@@ -262,5 +361,12 @@ int main() {
   run<11>(out, src, "V9 with DMA but no vmcnt wait");
   run<12>(out, src, "V9 with the DMA issued mid-stage");
   run<13>(out, src, "V8 with the DMA issued mid-stage");
+  run<14>(out, src, "ping-pong halves, one barrier per phase");
+  run<15>(out, src, "V14 with the same lines every stage (hits)");
+  run<16>(out, src, "V14 with k_leg_dir's non-MFMA phase");
+  run<17>(out, src, "V16 with the same lines every stage (hits)");
+  run<4>(out, src, "V4 short tiles", 20);
+  run<14>(out, src, "V14 short tiles", 20);
+  run<16>(out, src, "V16 short tiles", 20);
   return 0;
 }
