@@ -11,12 +11,14 @@
 #include "ectrans_oracle.h"
 
 #include <complex.h>
+#include <omp.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 typedef double complex cplx;
+#define ORC_NB 8 /* columns per block of the restated DGEMMs (LEINV, LEDIR) */
 
 /* ------------------------------------------------------------------------------------ */
 /* state (tpm_dim.F90:22-47, tpm_geometry.F90:21-35, tpm_fields.F90:20-37, tpm_flt.F90)  */
@@ -94,32 +96,65 @@ static void cfft_pow2(int n, cplx *x, const cplx *w /* n twiddles of sign */) {
   }
 }
 
-static void bluestein(int n, int sign, const cplx *in, int istride, cplx *out) {
+/* Tables of one Bluestein length and sign (twiddles of the power-of-two work length, chirp, filter
+ * spectrum): they depend on (n, sign) only, so a plan computes them once instead of once per transform. */
+typedef struct {
+  int n, sign, m;
+  cplx *wf, *wb, *c, *b;
+} bluetab;
+#define ORC_NBLUE 4
+typedef struct {
+  bluetab tab[ORC_NBLUE];
+  int ntab;
+} bluecache;
+static _Thread_local bluecache *cur_blue = NULL; /* set by r2c_plan / c2r_plan around cfft_rec */
+
+static void bluetab_make(bluetab *t, int n, int sign) {
   int m = 1;
   while (m < 2 * n - 1) m <<= 1;
-  cplx *a = xcalloc(m, sizeof(cplx)), *b = xcalloc(m, sizeof(cplx));
-  cplx *c = xcalloc(n, sizeof(cplx));
-  cplx *wf = xcalloc(m, sizeof(cplx)), *wb = xcalloc(m, sizeof(cplx));
-  make_twiddles(m, -1, wf);
-  make_twiddles(m, +1, wb);
+  t->n = n, t->sign = sign, t->m = m;
+  t->c = xcalloc(n, sizeof(cplx));
+  t->b = xcalloc(m, sizeof(cplx));
+  t->wf = xcalloc(m, sizeof(cplx)), t->wb = xcalloc(m, sizeof(cplx));
+  make_twiddles(m, -1, t->wf);
+  make_twiddles(m, +1, t->wb);
   for (int j = 0; j < n; j++) {
     long j2 = ((long)j * j) % (2L * n);
     double ang = M_PI * (double)j2 / (double)n;
-    c[j] = cos(ang) + I * (sign * sin(ang)); /* exp(sign i pi j^2/n) */
+    t->c[j] = cos(ang) + I * (sign * sin(ang)); /* exp(sign i pi j^2/n) */
   }
+  t->b[0] = conj(t->c[0]);
+  for (int j = 1; j < n; j++) t->b[j] = t->b[m - j] = conj(t->c[j]);
+  cfft_pow2(m, t->b, t->wf);
+}
+static void bluetab_free(bluetab *t) { free(t->c), free(t->b), free(t->wf), free(t->wb); }
+
+static void bluestein(int n, int sign, const cplx *in, int istride, cplx *out) {
+  bluetab local, *t = NULL;
+  int own = 0;
+  if (cur_blue) {
+    for (int i = 0; i < cur_blue->ntab; i++)
+      if (cur_blue->tab[i].n == n && cur_blue->tab[i].sign == sign) t = &cur_blue->tab[i];
+    if (!t && cur_blue->ntab < ORC_NBLUE) {
+      t = &cur_blue->tab[cur_blue->ntab++];
+      bluetab_make(t, n, sign);
+    }
+  }
+  if (!t) {
+    bluetab_make(&local, n, sign);
+    t = &local;
+    own = 1;
+  }
+  const int m = t->m;
+  const cplx *c = t->c, *b = t->b;
+  cplx *a = xcalloc(m, sizeof(cplx));
   for (int j = 0; j < n; j++) a[j] = in[(size_t)j * istride] * c[j];
-  b[0] = conj(c[0]);
-  for (int j = 1; j < n; j++) b[j] = b[m - j] = conj(c[j]);
-  cfft_pow2(m, a, wf);
-  cfft_pow2(m, b, wf);
+  cfft_pow2(m, a, t->wf);
   for (int k = 0; k < m; k++) a[k] *= b[k];
-  cfft_pow2(m, a, wb);
+  cfft_pow2(m, a, t->wb);
   for (int k = 0; k < n; k++) out[k] = a[k] * c[k] / (double)m;
   free(a);
-  free(b);
-  free(c);
-  free(wf);
-  free(wb);
+  if (own) bluetab_free(&local);
 }
 
 /* out[0..n) = DFT_sign(in[0], in[stride], ...); wtop: table of size ntop (n | ntop) */
@@ -152,6 +187,7 @@ static void cfft_rec(int n, int sign, const cplx *in, int istride, cplx *out, co
 typedef struct {
   int n;
   cplx *wf, *wb;
+  bluecache blue;
 } fftplan;
 
 static fftplan fftplan_make(int n) {
@@ -161,25 +197,30 @@ static fftplan fftplan_make(int n) {
   p.wb = xcalloc(n, sizeof(cplx));
   make_twiddles(n, -1, p.wf);
   make_twiddles(n, +1, p.wb);
+  p.blue.ntab = 0;
   return p;
 }
 static void fftplan_free(fftplan *p) {
   free(p->wf);
   free(p->wb);
+  for (int i = 0; i < p->blue.ntab; i++) bluetab_free(&p->blue.tab[i]);
+  p->blue.ntab = 0;
 }
 
-static void r2c_plan(const fftplan *p, const double *in, cplx *work /* 2n */, double *out) {
+static void r2c_plan(fftplan *p, const double *in, cplx *work /* 2n */, double *out) {
   int n = p->n;
   cplx *a = work, *b = work + n;
   for (int j = 0; j < n; j++) a[j] = in[j];
+  cur_blue = &p->blue;
   cfft_rec(n, -1, a, 1, b, p->wf, n);
+  cur_blue = NULL;
   for (int k = 0; k <= n / 2; k++) {
     out[2 * k] = creal(b[k]);
     out[2 * k + 1] = cimag(b[k]);
   }
 }
 
-static void c2r_plan(const fftplan *p, const double *in, cplx *work /* 2n */, double *out) {
+static void c2r_plan(fftplan *p, const double *in, cplx *work /* 2n */, double *out) {
   int n = p->n;
   cplx *a = work, *b = work + n;
   /* Hermitian completion; imaginary parts of k=0 (and k=n/2 for even n) are ignored, as
@@ -194,7 +235,9 @@ static void c2r_plan(const fftplan *p, const double *in, cplx *work /* 2n */, do
       a[n - k] = conj(v);
     }
   }
+  cur_blue = &p->blue;
   cfft_rec(n, +1, a, 1, b, p->wb, n);
+  cur_blue = NULL;
   for (int j = 0; j < n; j++) out[j] = creal(b[j]);
 }
 
@@ -878,29 +921,47 @@ static void ltinv(const orc_trans *t, int km, int kf_uv, int kf_scalars, int kf_
   int iskip = (km == 0) ? 2 : 1;
   const double *pia = COL(ista);
   const double *rpa = t->rpnma[km], *rps = t->rpnms[km];
-  double *zca = xcalloc(idglu > 0 ? idglu : 1, 8), *zcs = xcalloc(idglu > 0 ? idglu : 1, 8);
-  for (int jk = 1; jk <= ifc; jk++) {
-    int active = ((jk - 1) % iskip) == 0; /* m=0: imaginary columns are zero */
-    for (int ji = 0; ji < idglu; ji++) zca[ji] = zcs[ji] = 0.0;
-    if (active) {
-      /* DGEMM('N','N') restated column by column: for every output latitude the sum still
-       * runs over j = 1..ILA in ascending order (axpy form keeps the panel access contiguous) */
-      for (int j = 1; j <= ila; j++) {
-        double b = A2(pia, nlei1, ia + 1 + (j - 1) * 2, jk);
-        const double *col = rpa + (size_t)(j - 1) * idglu;
-        for (int ji = 0; ji < idglu; ji++) zca[ji] += col[ji] * b;
-      }
-      for (int j = 1; j <= ils; j++) {
-        double b = A2(pia, nlei1, is + 1 + (j - 1) * 2, jk);
-        const double *col = rps + (size_t)(j - 1) * idglu;
-        for (int ji = 0; ji < idglu; ji++) zcs[ji] += col[ji] * b;
+  /* DGEMM('N','N') restated in blocks of ORC_NB columns: each panel column is read once per block instead of
+   * once per output column.  For every output element the sum still runs over j = 1..ILA in ascending
+   * order, one multiply and one add at a time (no contraction), so the values are those of the
+   * column-by-column loops.                                                                            */
+  const size_t ldz = (size_t)(idglu > 0 ? idglu : 1);
+  double *zca = xcalloc(ldz * ORC_NB, 8), *zcs = xcalloc(ldz * ORC_NB, 8);
+  for (int jk0 = 1; jk0 <= ifc; jk0 += ORC_NB) {
+    int nb = IMIN(ORC_NB, ifc - jk0 + 1);
+    int active[ORC_NB];
+    double b[ORC_NB];
+    for (int c = 0; c < nb; c++) active[c] = ((jk0 + c - 1) % iskip) == 0; /* m=0: imaginary columns are zero */
+    for (size_t i = 0; i < ldz * ORC_NB; i++) zca[i] = zcs[i] = 0.0;
+    for (int j = 1; j <= ila; j++) {
+      const double *col = rpa + (size_t)(j - 1) * idglu;
+      for (int c = 0; c < nb; c++) b[c] = A2(pia, nlei1, ia + 1 + (j - 1) * 2, jk0 + c);
+      for (int c = 0; c < nb; c++) {
+        if (!active[c]) continue;
+        double *z = zca + (size_t)c * ldz;
+        const double bc = b[c];
+        for (int ji = 0; ji < idglu; ji++) z[ji] += col[ji] * bc;
       }
     }
-    for (int ji = 1; ji <= idglu; ji++) {
-      int jgl = isl + ji - 1, igls = t->ndgl + 1 - jgl;
-      /* ASRE1B: north = A+S, south = S-A */
-      FOUR(t, four, kf_out_lt, jgl, km, jk - 1) = zca[ji - 1] + zcs[ji - 1];
-      FOUR(t, four, kf_out_lt, igls, km, jk - 1) = zcs[ji - 1] - zca[ji - 1];
+    for (int j = 1; j <= ils; j++) {
+      const double *col = rps + (size_t)(j - 1) * idglu;
+      for (int c = 0; c < nb; c++) b[c] = A2(pia, nlei1, is + 1 + (j - 1) * 2, jk0 + c);
+      for (int c = 0; c < nb; c++) {
+        if (!active[c]) continue;
+        double *z = zcs + (size_t)c * ldz;
+        const double bc = b[c];
+        for (int ji = 0; ji < idglu; ji++) z[ji] += col[ji] * bc;
+      }
+    }
+    for (int c = 0; c < nb; c++) {
+      const int jk = jk0 + c;
+      const double *za = zca + (size_t)c * ldz, *zs = zcs + (size_t)c * ldz;
+      for (int ji = 1; ji <= idglu; ji++) {
+        int jgl = isl + ji - 1, igls = t->ndgl + 1 - jgl;
+        /* ASRE1B: north = A+S, south = S-A */
+        FOUR(t, four, kf_out_lt, jgl, km, jk - 1) = za[ji - 1] + zs[ji - 1];
+        FOUR(t, four, kf_out_lt, igls, km, jk - 1) = zs[ji - 1] - za[ji - 1];
+      }
     }
   }
   free(zca), free(zcs);
@@ -940,9 +1001,11 @@ int orc_inv_trans(const orc_trans *t, int nuv, int nsc, const double *spvor, con
   int nm = t->nsmax + 1;
   double *four = xcalloc((size_t)t->ndgl * nm * 2 * (kf_out_lt > 0 ? kf_out_lt : 1), 8);
   /* LTINV_CTL: loop over m (ltinv_ctl_mod.F90:118-138) */
+  const double tt0 = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 1)
   for (int km = 0; km <= t->nsmax; km++)
     ltinv(t, km, nuv, nsc, kf_scders, kf_out_lt, lvorgp, ldivgp, spvor, spdiv, spsc, four);
+  if (getenv("ORC_TIMING")) fprintf(stderr, "orc_inv_trans: Legendre %.3f s\n", omp_get_wtime() - tt0);
   /* FTINV_CTL (ftinv_ctl_mod.F90:173-191): per latitude FOURIER_IN, FSC, FTINV; then TRLTOG
    * (NPROC=1: pure copy ZGTF(field, point) -> PGP(point, field, 1)).                    */
 #pragma omp parallel
@@ -1029,31 +1092,54 @@ static void ltdir(const orc_trans *t, int km, int kf_fs, int kf_uv, int kf_scala
   int ila = (itmax - km + 2) / 2, ils = (itmax - km + 3) / 2;
   int iskip = (km == 0) ? 2 : 1;
   const double *rpa = t->rpnma[km], *rps = t->rpnms[km];
-  double *zba = xcalloc(idglu > 0 ? idglu : 1, 8), *zbs = xcalloc(idglu > 0 ? idglu : 1, 8);
-  for (int jk = 1; jk <= ifc; jk += iskip) {
+  /* blocks of ORC_NB columns, operands stored [latitude][column] so that the loop over the columns of a
+   * block is the vector loop; every dot product still runs over the latitudes in ascending order, one
+   * multiply and one add at a time -- the values of the column-by-column loops                       */
+  const size_t ldz = (size_t)(idglu > 0 ? idglu : 1);
+  double *zba = xcalloc(ldz * ORC_NB, 8), *zbs = xcalloc(ldz * ORC_NB, 8);
+  int ncol = 0;
+  for (int jk = 1; jk <= ifc; jk += iskip) ncol++;
+  for (int c0 = 0; c0 < ncol; c0 += ORC_NB) {
+    int nb = IMIN(ORC_NB, ncol - c0);
+    for (size_t i = 0; i < ldz * ORC_NB; i++) zba[i] = zbs[i] = 0.0;
     /* PRFI2B (prfi2b_mod.F90:82-94), LDFOU2 (ldfou2_mod.F90:85-96), ZB=PAIA*PW (ledir_mod.F90:118-124) */
-    for (int j = 1; j <= idglu; j++) {
-      int jgl = isl + j - 1, igls = t->ndgl + 1 - jgl;
-      double fn = FOUR(t, four, kf_fs, jgl, km, jk - 1), fs = FOUR(t, four, kf_fs, igls, km, jk - 1);
-      double psia = fn + fs, paia = fn - fs;
-      if (jk <= 4 * kf_uv) {
-        double zacthe = t->racthe[jgl - 1];
-        paia *= zacthe;
-        psia *= zacthe;
+    for (int c = 0; c < nb; c++) {
+      const int jk = 1 + (c0 + c) * iskip;
+      for (int j = 1; j <= idglu; j++) {
+        int jgl = isl + j - 1, igls = t->ndgl + 1 - jgl;
+        double fn = FOUR(t, four, kf_fs, jgl, km, jk - 1), fs = FOUR(t, four, kf_fs, igls, km, jk - 1);
+        double psia = fn + fs, paia = fn - fs;
+        if (jk <= 4 * kf_uv) {
+          double zacthe = t->racthe[jgl - 1];
+          paia *= zacthe;
+          psia *= zacthe;
+        }
+        zba[(size_t)(j - 1) * ORC_NB + c] = paia * t->rw[jgl - 1];
+        zbs[(size_t)(j - 1) * ORC_NB + c] = psia * t->rw[jgl - 1];
       }
-      zba[j - 1] = paia * t->rw[jgl - 1];
-      zbs[j - 1] = psia * t->rw[jgl - 1];
     }
     /* LEDIR GEMM('T','N') (ledir_mod.F90:130,204) + scatter (ledir_mod.F90:181-187,255-261) */
     for (int j = 1; j <= ila; j++) {
-      double s = 0.0;
-      for (int k = 0; k < idglu; k++) s += rpa[(size_t)(j - 1) * idglu + k] * zba[k];
-      A2(zoa1, nled4, ia + (j - 1) * 2, jk) = s;
+      double sv[ORC_NB];
+      const double *row = rpa + (size_t)(j - 1) * idglu;
+      for (int c = 0; c < ORC_NB; c++) sv[c] = 0.0;
+      for (int k = 0; k < idglu; k++) {
+        const double r = row[k];
+        const double *zb = zba + (size_t)k * ORC_NB;
+        for (int c = 0; c < ORC_NB; c++) sv[c] += r * zb[c];
+      }
+      for (int c = 0; c < nb; c++) A2(zoa1, nled4, ia + (j - 1) * 2, 1 + (c0 + c) * iskip) = sv[c];
     }
     for (int j = 1; j <= ils; j++) {
-      double s = 0.0;
-      for (int k = 0; k < idglu; k++) s += rps[(size_t)(j - 1) * idglu + k] * zbs[k];
-      A2(zoa1, nled4, is + (j - 1) * 2, jk) = s;
+      double sv[ORC_NB];
+      const double *row = rps + (size_t)(j - 1) * idglu;
+      for (int c = 0; c < ORC_NB; c++) sv[c] = 0.0;
+      for (int k = 0; k < idglu; k++) {
+        const double r = row[k];
+        const double *zb = zbs + (size_t)k * ORC_NB;
+        for (int c = 0; c < ORC_NB; c++) sv[c] += r * zb[c];
+      }
+      for (int c = 0; c < nb; c++) A2(zoa1, nled4, is + (j - 1) * 2, 1 + (c0 + c) * iskip) = sv[c];
     }
   }
   free(zba), free(zbs);
@@ -1150,8 +1236,10 @@ void orc_dir_trans(const orc_trans *t, int nuv, int nsc, const double *gp, doubl
     free(outc), free(work);
   }
   /* LTDIR_CTL (ltdir_ctl_mod.F90:90-98) */
+  const double tt0 = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 1)
   for (int km = 0; km <= t->nsmax; km++) ltdir(t, km, kf_fs, nuv, nsc, four, spvor, spdiv, spsc);
+  if (getenv("ORC_TIMING")) fprintf(stderr, "orc_dir_trans: Legendre %.3f s\n", omp_get_wtime() - tt0);
   free(four);
 }
 
