@@ -1958,12 +1958,15 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   const int bfpad = roundup(maxb, 64);
   if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
   const int ldw = 2 * bfpad;
-  struct Bat { size_t off_g, off_o; int ng, no; };
+  struct Bat { size_t off_g, off_o, off_f; int ng, no; };
+  // EMI_NO_FUSE_DIR: every field through W and k_postpack_dir (the path before the fused epilogue; A/B)
+  static const bool fuse_dir = !getenv("EMI_NO_FUSE_DIR");
   std::vector<Bat> bats;
   std::vector<char> hdesc;
   for (auto &b : batches) {
     std::vector<GridFld> bg;
     std::vector<SpecDst> bo;
+    std::vector<FuseDst> bf(bfpad, FuseDst{nullptr, 0, 0});  // per W field of the batch
     std::map<int, int> loc;
     for (size_t i = 0; i < b.size(); i++) {
       loc[b[i]] = (int)i;
@@ -1987,7 +1990,10 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
           case 2: sd.dst = (char *)d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev * P.esz; sd.stride = a.sc3a_nlev; sd.idx = r.lev; break;
           default: sd.dst = (char *)d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev * P.esz; sd.stride = a.sc3b_nlev; sd.idx = r.lev; break;
         }
-        bo.push_back(sd);
+        if (fuse_dir)
+          bf[i] = FuseDst{sd.dst, sd.stride, sd.idx};  // written by the epilogue of k_leg_dir
+        else
+          bo.push_back(sd);
       }
     }
     Bat bt{};
@@ -1999,6 +2005,9 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     bt.off_o = hdesc.size();
     hdesc.resize(bt.off_o + (bo.size() * sizeof(SpecDst) + 255) / 256 * 256);
     memcpy(hdesc.data() + bt.off_o, bo.data(), bo.size() * sizeof(SpecDst));
+    bt.off_f = hdesc.size();
+    hdesc.resize(bt.off_f + (bf.size() * sizeof(FuseDst) + 255) / 256 * 256);
+    memcpy(hdesc.data() + bt.off_f, bf.data(), bf.size() * sizeof(FuseDst));
     bats.push_back(bt);
   }
   if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
@@ -2041,11 +2050,12 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     // stream A: Legendre + spectral unpack
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sA);
     iv = g_pt.start(1, sA);
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (const RT *)P.d_Z, ldw, (RT *)P.d_W, ldw);
+    const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (const RT *)P.d_Z, ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);
-    {
+    if (bt.no > 0) {  // vorticity / divergence from the wind fields left in W
       long long nblk = (long long)P.wrows_total * ((bt.no + 255) / 256);
       EMI_LAUNCH_P(P.esz, k_postpack_dir, nblk, 256, 0, sA, P.g, d_bo, bt.no, (const RT *)P.d_W, ldw, (long long)P.wrows_total);
     }

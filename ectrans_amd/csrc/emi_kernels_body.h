@@ -283,7 +283,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 // straight-line block, which lets the compiler interleave the LDS fragment reads with the MFMAs.
 template <bool FULL>
 EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, const int ct, const int ni, const real_t *FB, const real_t *Z, int ldf,
-                            real_t *W, int ldw) {
+                            real_t *W, int ldw, const FuseDst *fd) {
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
   real_t *Bs = As + 2 * 16 * LG_LDA;
@@ -392,27 +392,57 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   }
 #undef LEGDIR_LOADA
 #undef LEGDIR_LOADB
+  // Epilogue.  Fields whose spectral output is a plain copy (UPDSP, updsp_mod.F90:100-161: every scalar) go
+  // straight to the caller's array -- element (NASM0(m) + 2 (n-m) + c, field), n <= N, imaginary parts of m = 0
+  // zero (updspb_mod.F90:106,117) -- instead of through W and k_postpack_dir; the wind fields (U, V), which
+  // UVTVD combines over n-1, n, n+1, and the padding columns still go to W.  A lane holds one component
+  // (c = l & 1) of four fields.
+  real_t *ud[4];
+  long long us[4];
+  const int cpar = l & 1;
+#pragma unroll
+  for (int jn = 0; jn < 4; jn++) {
+    ud[jn] = nullptr;
+    us[jn] = 0;
+    if (fd) {
+      const FuseDst d = fd[(col0 + wn * 64 + jn * 16 + (l & 15)) >> 1];
+      if (d.dst) {
+        ud[jn] = (real_t *)d.dst + d.idx + (long long)(g.nasm0[m] + cpar) * d.stride;
+        us[jn] = 2LL * d.stride;
+      }
+    }
+  }
+  const int rmax = g.nsmax - g.mval[m];  // rows r = n - m <= rmax carry a coefficient
+  const bool zero_im = (g.mval[m] == 0) && cpar;
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       int k = k0 + i * 16 + EMI_ACC_ROW(l, q);
       if (k < nkpad) {
-        real_t *pw = W + (wb + 2 * k + par) * ldw + col0 + wn * 64 + (l & 15);
+        const int r = 2 * k + par;
+        real_t *pw = W + (wb + r) * ldw + col0 + wn * 64 + (l & 15);
 #pragma unroll
-        for (int jn = 0; jn < 4; jn++) pw[jn * 16] = acc[i][jn][q];
+        for (int jn = 0; jn < 4; jn++) {
+          if (ud[jn]) {
+            if (r <= rmax) ud[jn][(long long)r * us[jn]] = zero_im ? (real_t)0.0 : acc[i][jn][q];
+          } else {
+            pw[jn * 16] = acc[i][jn][q];
+          }
+        }
       }
     }
 }
-EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const real_t *Z, int ldf, real_t *W, int ldw) {
+EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const real_t *Z, int ldf, real_t *W, int ldw,
+                                      const FuseDst *fd) {
   const int2 tm = tilemap[EMI_BID];
   if (tm.x < 0) return;
   const int m = tm.x, kt = tm.y >> 16, ct = tm.y & 0xffff;
   const int left = ((g.wrows[m] >> 1) - kt * 64 + 15) >> 4;  // live 16-row groups of this tile
   if (left >= 4)
-    leg_dir_tile<true>(g, m, kt, ct, 4, FB, Z, ldf, W, ldw);
+    leg_dir_tile<true>(g, m, kt, ct, 4, FB, Z, ldf, W, ldw, fd);
   else
-    leg_dir_tile<false>(g, m, kt, ct, left, FB, Z, ldf, W, ldw);
+    leg_dir_tile<false>(g, m, kt, ct, left, FB, Z, ldf, W, ldw, fd);
 }
 
 // ==========================================================================================

@@ -57,6 +57,10 @@ struct SpecDst {  // one spectral output field of the direct transform
   int stride, idx;
   int kind, src0, src1, pad_;  // src*: field index in W (U and V for vor/div)
 };
+struct FuseDst {  // k_leg_dir epilogue: where the coefficients of one W field go (dst == NULL: to W, for k_postpack_dir)
+  void *dst;      // real_t array; element (ispec) of the field = dst[ispec * stride + idx]
+  int stride, idx;
+};
 enum { GM_PLAIN = 0, GM_ACOS = 1, GM_EWDER = 2, GM_EWDER_UV = 3 };
 struct GridFld {  // one Fourier-space field <-> one user grid field
   void *base;     // real_t array base; element (p) = base[((p/nproma)*nf_arr + fidx)*nproma + p%nproma]
