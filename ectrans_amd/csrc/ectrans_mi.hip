@@ -271,21 +271,24 @@ static int build_fft_plans(Plan &P) {
     if (pl.blue) {
       pl.S = emi::next_235(2 * pl.sz - 1);
       emi::factorize_smooth(pl.S, fac);
-      // EMI_FFT_MERGE=1 (off by default): a specialised kernel with the last two factors merged into one
-      // composite radix 6, 9 or 10 (one LDS round trip fewer).  Even NLOEN only: odd rows run the generic
-      // kernels, which have no such butterflies.  Measured at TCo1279: the direct kernels gain 2 % (95.4 against
-      // 97.6 ms), the inverse ones lose 6 % (110.4 against 104.3 ms: their last pass, fused with the grid
-      // store, spills 112-136 B per lane at radix 9 and 10), and one plan serves both directions.
+      // A specialised kernel with the last two factors merged into one composite radix 6, 9 or 10 (one LDS round
+      // trip fewer) is preferred when there is one (EMI_FFT_MERGE=0: never).  Even NLOEN only: odd rows run the
+      // generic kernels, which have no such butterflies.  Measured at TCo1279: inverse 103.8 -> 101.1 ms, direct
+      // 99.3 -> 96.3 ms per direction.
       std::vector<int> fm;
       const char *mg = getenv("EMI_FFT_MERGE");
-      if (mg && atoi(mg) != 0 && !pl.cmode && !getenv("EMI_FFT_NO_HOT") && emi::merge_tail(fac, fm)) {
+      if (!(mg && atoi(mg) == 0) && !pl.cmode && !getenv("EMI_FFT_NO_HOT") && emi::merge_tail(fac, fm)) {
         static const int hp[][9] = {
 #define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_) {pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_},
             EMI_HOT_PLAN_LIST(EMI_HOT_ROW)
 #undef EMI_HOT_ROW
         };
+        // fields per workgroup of this work length (the rule further down): the specialised kernel must be
+        // the one for exactly that shape, there is no generic kernel to fall back to with a composite radix
+        int fbk_m = 16;
+        while (fbk_m > 1 && (size_t)fbk_m * FFT_LDS_ELEMS(pl.S) * 2 * P.esz > 40960) fbk_m >>= 1;
         for (const auto &r : hp) {
-          bool same = r[1] == pl.S && r[2] == (int)fm.size();
+          bool same = r[1] == pl.S && r[2] == (int)fm.size() && r[8] == fbk_m;
           for (size_t i = 0; same && i < fm.size(); i++) same = r[3 + i] == fm[i];
           if (same) {
             fac = fm;
@@ -367,6 +370,8 @@ static int build_fft_plans(Plan &P) {
         if (same) hot = r[0];
       }
     }
+    for (int i = 0; i < pl.nfac; i++)
+      if (!hot && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
     int cls = -1;
     for (size_t c = 0; c < P.fclass.size(); c++)
       if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot) cls = (int)c;

@@ -821,6 +821,7 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
     for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) {
       int blk, j;
       split_q(q, lenp, sh, blk, j);  // last pass: len == S, blk == 0
+      EMI_OPAQUE(j);
       real2 v[R], w[R], ch[NOUT];
       if (lenp > 1) {
         const real2 *pw_ = ptw + j;

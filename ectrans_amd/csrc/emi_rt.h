@@ -45,6 +45,9 @@
 // vector instructions.  Measured +2.5 % on both Legendre kernels (priority 1 and 3 alike).
 #define EMI_PRIO_HI() __builtin_amdgcn_s_setprio(1)
 #define EMI_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+// the value of a per-lane integer becomes opaque to the optimiser at this point: index arithmetic that depends on it
+// is recomputed where it is used (an add) instead of being hoisted out of the loop into registers that then spill
+#define EMI_OPAQUE(x) __asm__ volatile("" : "+v"(x))
 #define EMI_LDS_PTR (emi_lds_raw)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -100,6 +103,7 @@ static inline void emu_barrier() {
 #define EMI_SYNC() emu_barrier()
 #define EMI_WAVE_SYNC() emu_barrier()  // lanes are threads here: a real barrier
 #define EMI_LDS_DECL
+#define EMI_OPAQUE(x) ((void)0)
 #define EMI_PRIO_HI() ((void)0)
 #define EMI_PRIO_LO() ((void)0)
 #define EMI_LDS_PTR (emu_ctx->lds)

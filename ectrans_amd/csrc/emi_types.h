@@ -117,8 +117,8 @@ struct FftLaunchDev {
 // workgroup).  The factor lists are what emi::factorize_smooth yields for S and the field count what the
 // 40-KiB rule gives in fp64 (both checked when a plan is matched).  1-8: the rows that carry TCo1279;
 // 9-12: the longer rows of TCo2559 (fp32: up to 10240 points fit the LDS); 13-21: the short rows, several
-// fields per workgroup (most of TCo399); 22-24: plans 3, 5, 6 with their last two factors merged into one
-// composite radix (6, 9, 10: one LDS round trip fewer), preferred when present (emi::merge_tail).
+// fields per workgroup (most of TCo399); 22-27: plans 3, 5, 6, 16, 17, 19 with their last two factors merged into
+// one composite radix (6, 9, 10: one LDS round trip fewer), preferred when present (emi::merge_tail).
 #define EMI_HOT_PLAN_LIST(X)          \
   X(1, 2048, 4, 8, 8, 8, 4, 1, 1)     \
   X(2, 2560, 4, 8, 8, 8, 5, 1, 1)     \
@@ -143,4 +143,7 @@ struct FftLaunchDev {
   X(21, 256, 3, 8, 8, 4, 1, 1, 8)     \
   X(22, 3072, 4, 8, 8, 8, 6, 1, 1)    \
   X(23, 4608, 4, 8, 8, 8, 9, 1, 1)    \
-  X(24, 5120, 4, 8, 8, 8, 10, 1, 1)
+  X(24, 5120, 4, 8, 8, 8, 10, 1, 1)   \
+  X(25, 640, 3, 8, 8, 10, 1, 1, 4)    \
+  X(26, 576, 3, 8, 8, 9, 1, 1, 4)     \
+  X(27, 384, 3, 8, 8, 6, 1, 1, 4)

@@ -75,9 +75,10 @@ def test_specialised_fft_kernels_match_oracle(et, half, precision):
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
-def test_merged_radix_fft_kernels_match_oracle(et, monkeypatch):
-    """EMI_FFT_MERGE=1: work lengths 3072, 4608, 5120 as 8*8*8*{6, 9, 10} (composite-radix butterflies)."""
-    monkeypatch.setenv("EMI_FFT_MERGE", "1")
+def test_unmerged_radix_fft_kernels_match_oracle(et, monkeypatch):
+    """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists 8*8*8*2*3 ... (the default merges the last two
+    factors into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""
+    monkeypatch.setenv("EMI_FFT_MERGE", "0")
     half = [2564, 3068, 4100, 4604, 4612, 5116, 2052, 4092]
     e_inv, e_dir = run_case(et, Oracle, XP, 15, half + half[::-1], 1, 1, dict(scders=True), None)
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)

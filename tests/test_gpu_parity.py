@@ -152,10 +152,11 @@ def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
     assert not np.array_equal(outs[0][0], np.zeros_like(outs[0][0]))
 
 
-def test_merged_radix_fft_kernels_match_oracle(et, dev, monkeypatch):
-    """EMI_FFT_MERGE=1 (opt-in): work lengths 3072, 4608, 5120 as 8*8*8*{6, 9, 10}, composite-radix butterflies."""
+def test_unmerged_radix_fft_kernels_match_oracle(et, dev, monkeypatch):
+    """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists (the default merges the last two factors
+    into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""
     from oracle.oracle import Oracle as O
-    monkeypatch.setenv("EMI_FFT_MERGE", "1")
+    monkeypatch.setenv("EMI_FFT_MERGE", "0")
     half = [2564, 3068, 4100, 4604, 4612, 5116, 2052, 4092]
     e_inv, e_dir = run_case(et, O, dev, 15, np.array(half + half[::-1], dtype=np.int32), 1, 1, dict(scders=True), None)
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
