@@ -2061,7 +2061,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);
     if (bt.no > 0) {  // vorticity / divergence from the wind fields left in W
-      long long nblk = (long long)P.wrows_total * ((bt.no + 255) / 256);
+      long long nblk = ((long long)P.wrows_total + 3) / 4 * ((bt.no + 63) / 64);  // block = 4 rows x 64 fields
       EMI_LAUNCH_P(P.esz, k_postpack_dir, nblk, 256, 0, sA, P.g, d_bo, bt.no, (const RT *)P.d_W, ldw, (long long)P.wrows_total);
     }
     g_pt.stop(iv, sA);
