@@ -1965,7 +1965,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   const int ldw = 2 * bfpad;
   struct Bat { size_t off_g, off_o, off_f; int ng, no; };
   // EMI_NO_FUSE_DIR: every field through W and k_postpack_dir (the path before the fused epilogue; A/B)
-  static const bool fuse_dir = !getenv("EMI_NO_FUSE_DIR");
+  const bool fuse_dir = !getenv("EMI_NO_FUSE_DIR");
   std::vector<Bat> bats;
   std::vector<char> hdesc;
   for (auto &b : batches) {

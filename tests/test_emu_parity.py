@@ -84,6 +84,17 @@ def test_unmerged_radix_fft_kernels_match_oracle(et, monkeypatch):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
+@pytest.mark.parametrize("env", [("EMI_NO_FUSE_DIR", "1"), ("EMI_FB_TABLE", "1"), ("EMI_FB_ORDER", "m"), ("EMI_FFT_NO_HOT", "1")])
+def test_ab_switches_keep_parity(et, monkeypatch, env):
+    """The environment switches kept for A/B measurements select code that must stay correct: every field through
+    W and k_postpack_dir; Fourier rows through the row table on one task; wavenumber-major Fourier rows; the
+    generic FFT kernels only."""
+    monkeypatch.setenv(*env)
+    n, nloen, nuv, nsc, flags, nproma = CASES["nproma_blocks"]
+    e_inv, e_dir = run_case(et, Oracle, XP, n, nloen, nuv, nsc, flags, nproma)
+    assert e_inv < TOL and e_dir < TOL, (env, e_inv, e_dir)
+
+
 def test_dist_and_gath_routines_single_task(et):
     """DIST_SPEC/GATH_SPEC/DIST_GRID/GATH_GRID with one task are pure re-layouts."""
     N = 10
