@@ -1381,18 +1381,24 @@ static int ensure_desc(Plan &P, size_t bytes) {
   return 0;
 }
 
-static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int2 **d_map, long long *nblocks) {
+// mg (1, 2, 4 or 8): the XCDs work in mg groups of 8/mg; consecutive wavenumbers go to different groups, and inside
+// a group every XCD takes a range of column tiles (and a residue class of row tiles when there are fewer column
+// tiles than XCDs in the group).  mg = 1: all eight XCDs share every wavenumber.
+static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int mg, int2 **d_map, long long *nblocks) {
+  const int nx = 8 / mg;  // XCDs per group
   int gx = 1;
-  while (gx * 2 <= std::min(nct, 8)) gx *= 2;
-  const int gy = 8 / gx;
+  while (gx * 2 <= std::min(nct, nx)) gx *= 2;
+  const int gy = nx / gx;
   std::vector<std::vector<int2>> per(8);
   for (int ml = 0; ml < P.nump; ml++) {
     const int nrt = pref[ml + 1] - pref[ml];
-    for (int x = 0; x < 8; x++) {
-      // rotate the column ranges and row residues with ml: the ranges differ by one tile, rotation
+    const int grp = ml % mg, mlg = ml / mg;
+    for (int xi = 0; xi < nx; xi++) {
+      const int x = grp * nx + xi;
+      // rotate the column ranges and row residues with the wavenumber: the ranges differ by one tile, rotation
       // evens the per-XCD totals out (a fixed assignment leaves XCDs with 4 of 26 column tiles 23 %
       // more work than those with 3)
-      const int xc = (x + ml) % gx, xl = (x / gx + ml) % gy;
+      const int xc = (xi + mlg) % gx, xl = (xi / gx + mlg) % gy;
       const int c0 = (int)((long long)xc * nct / gx), c1 = (int)((long long)(xc + 1) * nct / gx);
       for (int rt = xl; rt < nrt; rt += gy)
         for (int ct = c0; ct < c1; ct++) per[x].push_back(int2{ml, (rt << 16) | ct});
@@ -1411,7 +1417,13 @@ static int leg_tilemaps(Plan &P, int nct, LegMaps **out) {
   auto it = P.legmaps.find(nct);
   if (it == P.legmaps.end()) {
     LegMaps lm;
-    if (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv, &lm.n_inv) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir, &lm.n_dir))
+    auto groups = [](const char *name, int dflt) {
+      const char *e = getenv(name);
+      const int v = e ? atoi(e) : dflt;
+      return (v == 1 || v == 2 || v == 4 || v == 8) ? v : dflt;
+    };
+    if (build_tilemap(P, P.lattile_pref, nct, groups("EMI_LEG_INV_MGROUPS", 1), &lm.d_inv, &lm.n_inv) ||
+        build_tilemap(P, P.ktile_pref, nct, groups("EMI_LEG_DIR_MGROUPS", 1), &lm.d_dir, &lm.n_dir))
       return EMI_ERR_RUNTIME;
     it = P.legmaps.emplace(nct, lm).first;
   }

@@ -15,6 +15,8 @@ python3 tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_p
 # 3. SQ counters (MFMA busy, LDS conflicts, occupancy) in their own pass
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/${TAG}_pmc_sq1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/${TAG}_pmc_sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $O/${TAG}_pmc_sq2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/${TAG}_pmc_sq2.log 2>&1
+# 3b. L2 hit rate per kernel: TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/${TAG}_pmc_l2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/${TAG}_pmc_l2.log 2>&1
 # 4. the bench line itself, with the CPU baseline, outside any profiler
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench_err.log
 tail -c 3000 $O/${TAG}_bench.json
