@@ -8,7 +8,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,order", [(2, "lat"), (3, "lat"), (2, "m")])
+@pytest.mark.parametrize("world,order", [(2, "lat"), (3, "lat"), (4, "lat"), (2, "m")])
 def test_wset_sharding_with_alltoallv(world, order):
     """order: row order inside the exchanged Fourier blocks -- latitude-major (default) or wavenumber-major
     (EMI_FB_ORDER=m, kept for A/B measurements)."""
