@@ -186,8 +186,6 @@ struct Plan {
   // (the same allocation when nproc == 1)
   char *d_W = nullptr, *d_FBL = nullptr, *d_FBF = nullptr;  // esz-sized reals; capacities in reals
   size_t cap_W = 0, cap_FBL = 0, cap_FBF = 0;
-  char *d_Z = nullptr;  // one work-buffer row of zeros (k_leg_dir reads it for latitudes past the last one)
-  size_t cap_Z = 0;
   void *d_desc = nullptr;
   size_t cap_desc = 0;
 };
@@ -1089,7 +1087,6 @@ extern "C" int emi_release(int kresol) {
     emi_dev_free(kv.second.d_dir);
   }
   emi_dev_free(P->d_W);
-  emi_dev_free(P->d_Z);
   emi_dev_free(P->d_FBL);
   if (P->d_FBF != P->d_FBL) emi_dev_free(P->d_FBF);
   emi_dev_free(P->d_desc);
@@ -1337,13 +1334,13 @@ static int grow(char **p, size_t *cap, size_t need, const char *what) {
 static int ensure_work(Plan &P, int bfpad, int nfb) {
   const size_t rowb = (size_t)2 * bfpad * P.esz;
   if (grow(&P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer")) return -1;
-  if (grow(&P.d_Z, &P.cap_Z, rowb, "zero row")) return -1;  // grow() clears what it allocates; nothing writes here
   if (P.nproc == 1) {
-    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * P.frows * rowb, "Fourier work buffer")) return -1;
+    // + 1: a row of zeros behind the Fourier rows (k_leg_dir reads it for latitudes past the last one of a stage)
+    if (grow(&P.d_FBL, &P.cap_FBL, ((size_t)nfb * P.frows + 1) * rowb, "Fourier work buffer")) return -1;
     P.d_FBF = P.d_FBL;
     P.cap_FBF = P.cap_FBL;
   } else {
-    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * P.lrows * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
+    if (grow(&P.d_FBL, &P.cap_FBL, ((size_t)nfb * P.lrows + 1) * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
     if (grow(&P.d_FBF, &P.cap_FBF, (size_t)nfb * P.frows * rowb, "Fourier (FFT-side) exchange buffer")) return -1;
   }
   return 0;
@@ -2044,6 +2041,9 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   // events of batch ib: 3 ib = FFT done, 3 ib + 1 = Legendre done, 3 ib + 2 = exchange done (as INV_TRANS)
   const bool dist = P.nproc > 1;
   const size_t lstride = (size_t)(dist ? P.lrows : P.frows) * ldw * P.esz, fstride = (size_t)P.frows * ldw * P.esz;
+  // the zero row of this call's layout (the buffer may have held rows of another width before)
+  const long long lrows_call = dist ? P.lrows : P.frows, zrow_abs = (piped ? 2 : 1) * lrows_call;
+  emi_dev_memset(P.d_FBL + (size_t)zrow_abs * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
   for (int ib = 0; ib < nbat; ib++) {
     const Bat &bt = bats[ib];
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
@@ -2068,7 +2068,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sA);
     iv = g_pt.start(1, sA);
     const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (const RT *)P.d_Z, ldw, (RT *)P.d_W, ldw, d_bf);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)(zrow_abs - (piped ? (long long)(ib & 1) * lrows_call : 0)), ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);

@@ -285,7 +285,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 // FULL: all four 16-row groups of the tile are live (nine tiles in ten): the stage loop is then one
 // straight-line block, which lets the compiler interleave the LDS fragment reads with the MFMAs.
 template <bool FULL>
-EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, const int ct, const int ni, const real_t *FB, const real_t *Z, int ldf,
+EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, const int ct, const int ni, const real_t *FB, const int zrow, int ldf,
                             real_t *W, int ldw, const FuseDst *fd) {
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
@@ -312,7 +312,6 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   const long long stepA = 16LL * ldk, rowA8 = 8LL * ldk;
   const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow + 4 i, i = 0..3, of each stage
   const real_t *FBc = FB + col0 + 2 * bc2;
-  const real_t *Zc = Z + col0 + 2 * bc2;         // a row of zeros: rows past the last latitude load it (no branch)
   real2 ra0, ra1, ra2, ra3;                      // P^T of stage s+1
   real2 rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
   // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
@@ -323,7 +322,9 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   int *rowN = (int *)(Bs + 2 * 16 * LG_LDB);
   int *rowS = rowN + 16 * nst;
   for (int j = tid; j < 16 * nst; j += LG_THREADS) {
-    int rn_ = -1, rs_ = -1;
+    // latitudes past the last one read row `zrow` of the buffer, a row of zeros behind the Fourier rows: no
+    // branch, no select, and the row address is one 32 x 32 -> 64-bit multiply-add
+    int rn_ = zrow, rs_ = zrow;
     if (j < ndglu) {
       rn_ = g.legN[lb + j];
       rs_ = g.legS[lb + j];
@@ -337,14 +338,14 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
     const int j0_ = 16 * (s_) + brow;                                               \
     const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + 4], is1 = rowS[j0_ + 4];         \
     const int in2 = rowN[j0_ + 8], is2 = rowS[j0_ + 8], in3 = rowN[j0_ + 12], is3 = rowS[j0_ + 12]; \
-    rn0 = *(const real2 *)(in0 >= 0 ? FBc + (long long)in0 * ldf : Zc);      \
-    rs0 = *(const real2 *)(is0 >= 0 ? FBc + (long long)is0 * ldf : Zc);      \
-    rn1 = *(const real2 *)(in1 >= 0 ? FBc + (long long)in1 * ldf : Zc);      \
-    rs1 = *(const real2 *)(is1 >= 0 ? FBc + (long long)is1 * ldf : Zc);      \
-    rn2 = *(const real2 *)(in2 >= 0 ? FBc + (long long)in2 * ldf : Zc);      \
-    rs2 = *(const real2 *)(is2 >= 0 ? FBc + (long long)is2 * ldf : Zc);      \
-    rn3 = *(const real2 *)(in3 >= 0 ? FBc + (long long)in3 * ldf : Zc);      \
-    rs3 = *(const real2 *)(is3 >= 0 ? FBc + (long long)is3 * ldf : Zc);      \
+    rn0 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in0 * (unsigned)ldf); \
+    rs0 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is0 * (unsigned)ldf); \
+    rn1 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in1 * (unsigned)ldf); \
+    rs1 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is1 * (unsigned)ldf); \
+    rn2 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in2 * (unsigned)ldf); \
+    rs2 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is2 * (unsigned)ldf); \
+    rn3 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in3 * (unsigned)ldf); \
+    rs3 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is3 * (unsigned)ldf); \
   }
 #define LEGDIR_LOADA(s_)                                          \
   {                                                               \
@@ -371,9 +372,12 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
     *(real2 *)(Bs + (0 * 16 + brow + 12) * LG_LDB + 2 * bc2) = cadd(rn3, rs3);
     *(real2 *)(Bs + (1 * 16 + brow + 12) * LG_LDB + 2 * bc2) = csub(rn3, rs3);
     EMI_SYNC();
-    if (s + 1 < nst) {
-      LEGDIR_LOADB(s + 1);
-      LEGDIR_LOADA(s + 1);
+    {
+      // unconditional (the last stage requests its own rows again and drops them): with the loads inside an
+      // `if (s + 1 < nst)` the compiler copies all twelve prefetch registers at the loop back edge, 44 moves per stage
+      const int sn = (s + 1 < nst) ? s + 1 : s;
+      LEGDIR_LOADB(sn);
+      LEGDIR_LOADA(sn);
     }
     EMI_PRIO_HI();
 #pragma unroll
@@ -436,16 +440,16 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
       }
     }
 }
-EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const real_t *Z, int ldf, real_t *W, int ldw,
+EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const int zrow, int ldf, real_t *W, int ldw,
                                       const FuseDst *fd) {
   const int2 tm = tilemap[EMI_BID];
   if (tm.x < 0) return;
   const int m = tm.x, kt = tm.y >> 16, ct = tm.y & 0xffff;
   const int left = ((g.wrows[m] >> 1) - kt * 64 + 15) >> 4;  // live 16-row groups of this tile
   if (left >= 4)
-    leg_dir_tile<true>(g, m, kt, ct, 4, FB, Z, ldf, W, ldw, fd);
+    leg_dir_tile<true>(g, m, kt, ct, 4, FB, zrow, ldf, W, ldw, fd);
   else
-    leg_dir_tile<false>(g, m, kt, ct, left, FB, Z, ldf, W, ldw, fd);
+    leg_dir_tile<false>(g, m, kt, ct, left, FB, zrow, ldf, W, ldw, fd);
 }
 
 // ==========================================================================================
