@@ -884,8 +884,9 @@ EMI_DEVFN void dit_last_to_grid_any(real2 *a, int nfl, int fs, int S, int lenp, 
 // k_fft_inv: FOURIER_IN (fourier_in_mod.F90:64-76) + FSC (fsc_mod.F90:138-187) + FTINV
 // (ftinv_mod.F90:65-84; FFTW c2r semantics, unnormalised) + TRLTOG local copy.
 // ==========================================================================================
-EMI_DEVFN real2 fsc_load(const real_t *FB, long long row, int ldf, const GridFld &gf, int k, real_t racthe) {
-  real2 x = *(const real2 *)(FB + row * ldf + 2 * gf.src);
+// row < 2^31 and ldf > 0: the row offset is one 32 x 32 -> 64-bit multiply
+EMI_DEVFN real2 fsc_load(const real_t *FB, int row, int ldf, const GridFld &gf, int k, real_t racthe) {
+  real2 x = *(const real2 *)(FB + (unsigned long long)(unsigned)row * (unsigned)ldf + 2 * gf.src);
   if (gf.mode == GM_ACOS)
     x = cscale(x, racthe);
   else if (gf.mode == GM_EWDER)
@@ -1073,7 +1074,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
         x = af[FPAD(k)];
         if (pl.blue) x = cscale(cmul(x, chirp[k]), invL);
       }
-      *(real2 *)(FB + (long long)FROW(k) * ldf + 2 * (f0 + fl)) = cscale(x, sc);
+      *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * (f0 + fl)) = cscale(x, sc);
     }
   }
 }
@@ -1268,7 +1269,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
     real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
     real2 t = cmuli(cmul(rtw[k], d1));
     real2 x = mk2((real_t)0.5 * (s1.x - t.x), (real_t)0.5 * (s1.y - t.y));
-    *(real2 *)(FB + (long long)FROW(k) * ldf + 2 * (f0 + fl)) = cscale(x, sc);
+    *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * (f0 + fl)) = cscale(x, sc);
   }
   }
 }
