@@ -1833,8 +1833,11 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     sX = (emi_stream_t)g_pipe.sX;
     g_pipe.begin(st);
   }
-  LegMaps *lmaps = nullptr;
-  if (leg_tilemaps(P, ldw / LG_BN, &lmaps)) return EMI_ERR_RUNTIME;
+  // Legendre tile maps per batch: a batch with fewer fields than the row width (the last one of a call) only
+  // gets the column tiles that hold fields (built before anything is queued: a new map is a blocking upload)
+  std::vector<LegMaps *> bmaps(nbat, nullptr);
+  for (int ib = 0; ib < nbat; ib++)
+    if (leg_tilemaps(P, (bats[ib].nl + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile);
   // Events of batch ib: 3 ib = Legendre done, 3 ib + 1 = FFT done, 3 ib + 2 = exchange done.  Both
   // Fourier buffers are double buffered ([ib & 1]); one task: FBf == FBl and there is no exchange.
@@ -1856,6 +1859,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     }
     g_pt.stop(iv, sA);
     iv = g_pt.start(1, sA);
+    LegMaps *lmaps = bmaps[ib];
     EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib, sA);
@@ -2035,8 +2039,9 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     sX = (emi_stream_t)g_pipe.sX;
     g_pipe.begin(st);
   }
-  LegMaps *lmaps = nullptr;
-  if (leg_tilemaps(P, ldw / LG_BN, &lmaps)) return EMI_ERR_RUNTIME;
+  std::vector<LegMaps *> bmaps(nbat, nullptr);  // per batch: only the column tiles that hold fields (as INV_TRANS)
+  for (int ib = 0; ib < nbat; ib++)
+    if (leg_tilemaps(P, (bats[ib].ng + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile);
   // events of batch ib: 3 ib = FFT done, 3 ib + 1 = Legendre done, 3 ib + 2 = exchange done (as INV_TRANS)
   const bool dist = P.nproc > 1;
@@ -2068,6 +2073,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sA);
     iv = g_pt.start(1, sA);
     const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
+    LegMaps *lmaps = bmaps[ib];
     EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)(zrow_abs - (piped ? (long long)(ib & 1) * lrows_call : 0)), ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
