@@ -693,13 +693,25 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       P.procm[m] = ik - 1;
     }
   }
-  // latitudes: contiguous bands holding ~equal numbers of grid points (whole latitudes, as the
-  // Fourier-space distribution of sumplatb_mod.F90 with LDSPLIT=.FALSE.); the grid-point
-  // distribution is chosen identical, so TRGTOL/TRLTOG stay local copies.
+  // latitudes: contiguous bands of whole latitudes (the Fourier-space distribution of sumplatb_mod.F90 with
+  // LDSPLIT=.FALSE., which weighs a latitude by NLOEN); the grid-point distribution is chosen identical, so
+  // TRGTOL/TRLTOG stay local copies.  The weight here is the measured cost of a row in the FFT kernels (ps per
+  // field, both directions, TCo1279 kernel statistics by work length): 20 ps per point up to NLOEN = 1500, falling
+  // linearly to 16.9 ps at 4900, plus 1.75 ns per row -- with equal numbers of points the polar tasks of an 8-task
+  // TCo1279 job spent 18 % longer in the FFT phase than the equatorial ones (26.8 against 22.6 ms) and set the
+  // job's pace.  EMI_LAT_ROW_COST=0 restores the reference's weight (NLOEN).
+  const char *rowc = getenv("EMI_LAT_ROW_COST");
+  const bool by_cost = !(rowc && atoi(rowc) == 0);
+  std::vector<long long> wcum(L + 1, 0);
+  for (int j = 0; j < L; j++) {
+    const double n = (double)P.nloen[j];
+    const double w = by_cost ? n * (n <= 1500.0 ? 20.0 : std::max(15.0, 20.0 - (n - 1500.0) * 0.00091)) + 1750.0 : n;
+    wcum[j + 1] = wcum[j] + (long long)(w + 0.5);
+  }
   P.latlo.assign(NP + 1, 0);
   for (int r = 1; r < NP; r++) {
-    long long target = cum[L] * r / NP;
-    int j = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+    long long target = wcum[L] * r / NP;
+    int j = (int)(std::lower_bound(wcum.begin(), wcum.end(), target) - wcum.begin());
     j = std::max(j, P.latlo[r - 1] + 1);
     j = std::min(j, L - (NP - r));
     P.latlo[r] = j;
