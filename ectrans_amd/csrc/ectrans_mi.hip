@@ -1347,12 +1347,12 @@ static int ensure_work(Plan &P, int bfpad, int nfb) {
   const size_t rowb = (size_t)2 * bfpad * P.esz;
   if (grow(&P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer")) return -1;
   if (P.nproc == 1) {
-    // + 1: a row of zeros behind the Fourier rows (k_leg_dir reads it for latitudes past the last one of a stage)
-    if (grow(&P.d_FBL, &P.cap_FBL, ((size_t)nfb * P.frows + 1) * rowb, "Fourier work buffer")) return -1;
+    // + 1 per buffer: a row of zeros behind the Fourier rows (k_leg_dir reads it for latitudes past the last one of a stage)
+    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * (P.frows + 1) * rowb, "Fourier work buffer")) return -1;
     P.d_FBF = P.d_FBL;
     P.cap_FBF = P.cap_FBL;
   } else {
-    if (grow(&P.d_FBL, &P.cap_FBL, ((size_t)nfb * P.lrows + 1) * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
+    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * (P.lrows + 1) * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
     if (grow(&P.d_FBF, &P.cap_FBF, (size_t)nfb * P.frows * rowb, "Fourier (FFT-side) exchange buffer")) return -1;
   }
   return 0;
@@ -1807,15 +1807,20 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   const int bsz = pick_batch(P, nlt, depth);
   const int nbat = (nlt + bsz - 1) / bsz;
   const bool piped = depth > 1 && nbat > 1;
-  const int bfpad = roundup(std::min(bsz, nlt), 64);
+  // The 64-field column tiles of the call are dealt evenly to the batches and every batch has its own row width
+  // (2 x its tiles x 64 reals): no batch computes, stores or exchanges columns of another batch's width (with
+  // batches of ceil(fields / nbat) rounded up to 64 the 4 x 448 columns of a 1645-field call were 9 % padding).
+  const int tiles_total = (nlt + 63) / 64;
+  const int bfpad = 64 * ((tiles_total + nbat - 1) / nbat);  // widest batch
   if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
-  const int ldw = 2 * bfpad;
+  const int ldw_max = 2 * bfpad;
   // all descriptors of the call in one upload
-  struct Bat { size_t off_l, off_g; int nl, ng; };
+  struct Bat { size_t off_l, off_g; int nl, ng, ldw; };
   std::vector<Bat> bats;
   std::vector<char> hdesc;
-  for (int b0 = 0; b0 < nlt; b0 += bsz) {
-    const int nb = std::min(bsz, nlt - b0);
+  for (int ibat = 0, b0 = 0; ibat < nbat; ibat++) {
+    const int tiles_b = tiles_total / nbat + (ibat < tiles_total % nbat ? 1 : 0);
+    const int nb = std::min(64 * tiles_b, nlt - b0);
     std::vector<GridFld> bg;
     for (auto &go : gout)
       if (go.lt >= b0 && go.lt < b0 + nb) {
@@ -1825,6 +1830,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
       }
     Bat bt{};
     bt.nl = nb;
+    bt.ldw = 2 * 64 * tiles_b;
     bt.ng = (int)bg.size();
     bt.off_l = hdesc.size();
     hdesc.resize(bt.off_l + ((size_t)nb * sizeof(SpecSrc) + 255) / 256 * 256);
@@ -1833,6 +1839,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     hdesc.resize(bt.off_g + (bg.size() * sizeof(GridFld) + 255) / 256 * 256);
     memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
     bats.push_back(bt);
+    b0 += nb;
   }
   if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
   emi_h2d(P.d_desc, hdesc.data(), hdesc.size(), st);
@@ -1854,9 +1861,11 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   // Events of batch ib: 3 ib = Legendre done, 3 ib + 1 = FFT done, 3 ib + 2 = exchange done.  Both
   // Fourier buffers are double buffered ([ib & 1]); one task: FBf == FBl and there is no exchange.
   const bool dist = P.nproc > 1;
-  const size_t lstride = (size_t)(dist ? P.lrows : P.frows) * ldw * P.esz, fstride = (size_t)P.frows * ldw * P.esz;
+  // buffer strides for the widest batch (+ the zero row DIR_TRANS keeps behind the Legendre-side rows)
+  const size_t lstride = (size_t)((dist ? P.lrows : P.frows) + 1) * ldw_max * P.esz, fstride = (size_t)P.frows * ldw_max * P.esz;
   for (int ib = 0; ib < nbat; ib++) {
     const Bat &bt = bats[ib];
+    const int ldw = bt.ldw, bfpad_b = bt.ldw / 2;  // this batch's row width
     const SpecSrc *d_bl = (const SpecSrc *)((char *)P.d_desc + bt.off_l);
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
     char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * lstride : 0);
@@ -1866,8 +1875,8 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + (dist ? 2 : 1), sA);
     int iv = g_pt.start(0, sA);
     {
-      long long nblk = (long long)P.wrows_total * ((bfpad + 255) / 256);
-      EMI_LAUNCH_P(P.esz, k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad, (RT *)P.d_W, ldw, (long long)P.wrows_total);
+      long long nblk = (long long)P.wrows_total * ((bfpad_b + 255) / 256);
+      EMI_LAUNCH_P(P.esz, k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad_b, (RT *)P.d_W, ldw, (long long)P.wrows_total);
     }
     g_pt.stop(iv, sA);
     iv = g_pt.start(1, sA);
@@ -1987,8 +1996,8 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   const bool piped = depth > 1 && nbat > 1;
   const int bfpad = roundup(maxb, 64);
   if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
-  const int ldw = 2 * bfpad;
-  struct Bat { size_t off_g, off_o, off_f; int ng, no; };
+  const int ldw_max = 2 * bfpad;  // row width of the widest batch; every batch has its own (2 x its fields rounded up to 64)
+  struct Bat { size_t off_g, off_o, off_f; int ng, no, ldw; };
   // EMI_NO_FUSE_DIR: every field through W and k_postpack_dir (the path before the fused epilogue; A/B)
   const bool fuse_dir = !getenv("EMI_NO_FUSE_DIR");
   std::vector<Bat> bats;
@@ -2028,6 +2037,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     }
     Bat bt{};
     bt.ng = (int)bg.size();
+    bt.ldw = 2 * roundup((int)b.size(), 64);
     bt.no = (int)bo.size();
     bt.off_g = hdesc.size();
     hdesc.resize(bt.off_g + (bg.size() * sizeof(GridFld) + 255) / 256 * 256);
@@ -2057,12 +2067,12 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   g_pt.begin(G.profile);
   // events of batch ib: 3 ib = FFT done, 3 ib + 1 = Legendre done, 3 ib + 2 = exchange done (as INV_TRANS)
   const bool dist = P.nproc > 1;
-  const size_t lstride = (size_t)(dist ? P.lrows : P.frows) * ldw * P.esz, fstride = (size_t)P.frows * ldw * P.esz;
-  // the zero row of this call's layout (the buffer may have held rows of another width before)
-  const long long lrows_call = dist ? P.lrows : P.frows, zrow_abs = (piped ? 2 : 1) * lrows_call;
-  emi_dev_memset(P.d_FBL + (size_t)zrow_abs * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
+  // buffer strides for the widest batch, + the zero row behind the Legendre-side rows of each buffer
+  const long long lrows_call = dist ? P.lrows : P.frows;
+  const size_t lstride = (size_t)(lrows_call + 1) * ldw_max * P.esz, fstride = (size_t)P.frows * ldw_max * P.esz;
   for (int ib = 0; ib < nbat; ib++) {
     const Bat &bt = bats[ib];
+    const int ldw = bt.ldw;  // this batch's row width
     const GridFld *d_bg = (const GridFld *)((char *)P.d_desc + bt.off_g);
     const SpecDst *d_bo = (const SpecDst *)((char *)P.d_desc + bt.off_o);
     char *FBl = P.d_FBL + (piped ? (size_t)(ib & 1) * lstride : 0);
@@ -2084,9 +2094,11 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     // stream A: Legendre + spectral unpack
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sA);
     iv = g_pt.start(1, sA);
+    // the zero row of this batch: row `lrows_call` in the batch's own row width (the buffer held other data before)
+    emi_dev_memset(FBl + (size_t)lrows_call * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
     const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
     LegMaps *lmaps = bmaps[ib];
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)(zrow_abs - (piped ? (long long)(ib & 1) * lrows_call : 0)), ldw, (RT *)P.d_W, ldw, d_bf);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);
