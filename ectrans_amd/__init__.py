@@ -532,7 +532,9 @@ def last_phase_launches():
 
 
 def set_profile(on):
-    lib().emi_set_profile(int(bool(on)))
+    """True / 1: HIP-event phase timers per call (last_phase_ms() of the last call); 2: accumulated over all calls
+    since this set_profile(2) -- nothing is resolved, so nothing synchronises, between the calls of a timed loop."""
+    lib().emi_set_profile(int(on))
 
 
 def set_max_batch(n):

@@ -197,7 +197,7 @@ static struct {
   int nproc = 1, myproc = 1;
   std::vector<Plan *> plans;
   int max_batch = 0;
-  bool profile = false;
+  int profile = 0;  // 1: phase timers per call; 2: accumulated over the calls since emi_set_profile(2)
   emi_alltoallv_fn a2a = nullptr;
   void *a2a_user = nullptr;
 } G;
@@ -225,7 +225,7 @@ extern "C" int emi_init(const emi_init_t *cfg) {
 #endif
   G.plans.assign(G.max_resol, nullptr);
   const char *pe = getenv("EMI_PROFILE");
-  G.profile = pe && atoi(pe) != 0;
+  G.profile = pe ? atoi(pe) : 0;
   const char *mb = getenv("EMI_MAX_BATCH");
   if (mb) G.max_batch = atoi(mb);
   G.init = true;
@@ -1459,26 +1459,25 @@ static int pick_batch(Plan &P, int nfields, int depth) {
 // Per-phase device timing with HIP event pairs recorded on the stream each kernel runs on.
 // Nothing is synchronised inside a transform call; emi_last_phase_ms() resolves the events lazily.
 struct PhaseTimer {
-  static const int MAXIV = 256;
-  int n = 0;
+  static const int MAXIV = 4096;
+  int n = 0, ncreated = 0;
   bool on = false;
   int kinds[MAXIV];
 #ifndef EMI_CPU_EMU
   hipEvent_t e0[MAXIV], e1[MAXIV];
-  bool created = false;
-  void begin(bool on_) {
+  // keep: the intervals of earlier calls stay (accumulating mode, emi_set_profile(2)): nothing has to be resolved --
+  // i.e. no host synchronisation -- between the calls of a timed loop
+  void begin(bool on_, bool keep = false) {
     on = on_;
-    n = 0;
-    if (on && !created) {
-      for (int i = 0; i < MAXIV; i++) {
-        (void)hipEventCreate(&e0[i]);
-        (void)hipEventCreate(&e1[i]);
-      }
-      created = true;
-    }
+    if (!keep) n = 0;
   }
   int start(int kind, emi_stream_t s) {
     if (!on || n >= MAXIV) return -1;
+    if (n >= ncreated) {  // events are created as the intervals are first used
+      (void)hipEventCreate(&e0[n]);
+      (void)hipEventCreate(&e1[n]);
+      ncreated = n + 1;
+    }
     kinds[n] = kind;
     (void)hipEventRecord(e0[n], s);
     return n++;
@@ -1498,7 +1497,7 @@ struct PhaseTimer {
     }
   }
 #else
-  void begin(bool) {}
+  void begin(bool, bool = false) {}
   int start(int, emi_stream_t) { return -1; }
   void stop(int, emi_stream_t) {}
   void resolve(double *ms3, int *launches) {
@@ -1857,7 +1856,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   std::vector<LegMaps *> bmaps(nbat, nullptr);
   for (int ib = 0; ib < nbat; ib++)
     if (leg_tilemaps(P, (bats[ib].nl + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
-  g_pt.begin(G.profile);
+  g_pt.begin(G.profile != 0, G.profile == 2);
   // Events of batch ib: 3 ib = Legendre done, 3 ib + 1 = FFT done, 3 ib + 2 = exchange done.  Both
   // Fourier buffers are double buffered ([ib & 1]); one task: FBf == FBl and there is no exchange.
   const bool dist = P.nproc > 1;
@@ -2064,7 +2063,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   std::vector<LegMaps *> bmaps(nbat, nullptr);  // per batch: only the column tiles that hold fields (as INV_TRANS)
   for (int ib = 0; ib < nbat; ib++)
     if (leg_tilemaps(P, (bats[ib].ng + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
-  g_pt.begin(G.profile);
+  g_pt.begin(G.profile != 0, G.profile == 2);
   // events of batch ib: 3 ib = FFT done, 3 ib + 1 = Legendre done, 3 ib + 2 = exchange done (as INV_TRANS)
   const bool dist = P.nproc > 1;
   // buffer strides for the widest batch, + the zero row behind the Legendre-side rows of each buffer
@@ -2179,7 +2178,8 @@ extern "C" int emi_last_phase_launches(int *l3) {
 }
 
 extern "C" int emi_set_profile(int on) {
-  G.profile = on != 0;
+  G.profile = on;
+  g_pt.n = 0;  // a new measurement starts here
   return EMI_SUCCESS;
 }
 

@@ -189,7 +189,9 @@ int emi_work_model(int kresol, int nfields, double *legendre_flops_per_direction
 int emi_last_phase_ms(double *ms3);
 /* Number of Legendre/FFT/pack phase intervals (one per field batch) behind those sums.      */
 int emi_last_phase_launches(int *l3);
-/* Switch the HIP-event phase timers on/off (default: env EMI_PROFILE).                      */
+/* HIP-event phase timers (default: env EMI_PROFILE): 0 off; 1 per call (emi_last_phase_ms = the last call);
+ * 2 accumulated over all calls since this emi_set_profile(2) (nothing is resolved, hence nothing
+ * synchronises, between the calls of a timed loop; up to 4096 intervals).                   */
 int emi_set_profile(int on);
 /* Upper bound on Fourier-space fields per batch (0: from free HBM).                         */
 int emi_set_max_batch(int max_fields);
