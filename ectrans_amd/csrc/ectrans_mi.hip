@@ -1379,6 +1379,47 @@ static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st, char *FBl, c
   return 0;
 }
 
+static int ensure_desc(Plan &P, size_t bytes);
+// The field descriptors of a call go to the device through a small ring of pinned host buffers, so that the copy is
+// asynchronous and the call never waits for the stream: the host prepares and queues the next call while the
+// kernels of this one run (0.6 ms of host work per pair, otherwise exposed between any two calls).  A ring slot is
+// reused four calls later, after the event behind its copy.  The device buffer is one per resolution: the copy of
+// the next call is ordered behind this call's kernels on the caller's stream.
+static int upload_desc(Plan &P, const std::vector<char> &hd, emi_stream_t st) {
+  if (ensure_desc(P, hd.size())) return EMI_ERR_RUNTIME;
+#ifdef EMI_CPU_EMU
+  emi_h2d(P.d_desc, hd.data(), hd.size(), st);
+  return 0;
+#else
+  static struct {
+    void *h[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+    hipEvent_t ev[4];
+    bool init[4] = {false, false, false, false};
+    unsigned next = 0;
+  } ring;
+  const int k = (int)(ring.next++ & 3u);
+  if (ring.init[k]) {
+    EMI_CHECK(hipEventSynchronize(ring.ev[k]));
+  } else {
+    EMI_CHECK(hipEventCreateWithFlags(&ring.ev[k], hipEventDisableTiming));
+    ring.init[k] = true;
+  }
+  if (ring.cap[k] < hd.size()) {
+    if (ring.h[k]) (void)hipHostFree(ring.h[k]);
+    ring.h[k] = nullptr;
+    ring.cap[k] = 0;
+    const size_t cap = std::max(hd.size(), (size_t)1 << 16);
+    EMI_CHECK(hipHostMalloc(&ring.h[k], cap, hipHostMallocDefault));
+    ring.cap[k] = cap;
+  }
+  memcpy(ring.h[k], hd.data(), hd.size());
+  EMI_CHECK(hipMemcpyAsync(P.d_desc, ring.h[k], hd.size(), hipMemcpyHostToDevice, (hipStream_t)st));
+  EMI_CHECK(hipEventRecord(ring.ev[k], (hipStream_t)st));
+  return 0;
+#endif
+}
+
 static int ensure_desc(Plan &P, size_t bytes) {
   if (bytes <= P.cap_desc) return 0;
   emi_stream_sync(0);
@@ -1840,9 +1881,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     bats.push_back(bt);
     b0 += nb;
   }
-  if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
-  emi_h2d(P.d_desc, hdesc.data(), hdesc.size(), st);
-  emi_stream_sync(st);  // hdesc is a stack vector
+  if (upload_desc(P, hdesc, st)) return EMI_ERR_RUNTIME;
   emi_stream_t sA = st, sB = st, sX = st;
   if (piped) {
     if (g_pipe.init()) return EMI_ERR_RUNTIME;
@@ -2049,9 +2088,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     memcpy(hdesc.data() + bt.off_f, bf.data(), bf.size() * sizeof(FuseDst));
     bats.push_back(bt);
   }
-  if (ensure_desc(P, hdesc.size())) return EMI_ERR_RUNTIME;
-  emi_h2d(P.d_desc, hdesc.data(), hdesc.size(), st);
-  emi_stream_sync(st);
+  if (upload_desc(P, hdesc, st)) return EMI_ERR_RUNTIME;
   emi_stream_t sA = st, sB = st, sX = st;
   if (piped) {
     if (g_pipe.init()) return EMI_ERR_RUNTIME;

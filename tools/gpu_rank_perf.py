@@ -39,3 +39,11 @@ for it in range(iters):
     print("KF=%d it%d inv %.1f ms [pack %.1f leg %.1f (%.1f TF) fft %.1f] dir %.1f ms [pack %.1f leg %.1f (%.1f TF) fft %.1f]  pair %.1f ms" % (
         kf, it, (t1 - t0) * 1e3, pi[0], pi[1], wm["legendre_flops"] / max(pi[1], 1e-9) / 1e9, pi[2],
         (t2 - t1) * 1e3, pd[0], pd[1], wm["legendre_flops"] / max(pd[1], 1e-9) / 1e9, pd[2], (t2 - t0) * 1e3), flush=True)
+# the same pairs queued back to back, nothing resolved or synchronised in between (what bench.py times)
+et.set_profile(0)
+torch.cuda.synchronize(); t0 = time.time(); K = 10
+for it in range(K):
+    et.inv_trans(r, pspvor=vor, pspdiv=div, pspsc3a=sc3, pspsc2=sc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+    et.dir_trans(r, pspvor=vor, pspdiv=div, pspsc3a=sc3, pspsc2=sc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+torch.cuda.synchronize()
+print("back to back: %.1f ms per pair" % ((time.time() - t0) / K * 1e3))
