@@ -589,6 +589,35 @@ EMI_DEVFN void butterfly(real2 *v, const real2 *tw, int S, int sgn) {
   }
 }
 
+// Radix-8 / radix-4 butterflies whose upper half of the inputs is zero (the first DIF pass of a Bluestein convolution:
+// the chirped row fills less than half of the work array): the first layer of adds degenerates to copies.  The
+// results are those of butterfly<R> on (v[0..R/2-1], 0, ..., 0) (x + 0 and x - 0 are x).
+template <int R>
+EMI_DEVFN void butterfly_hz(real2 *v, int sgn) {
+  if (R == 4) {
+    const real2 x0 = v[0], x1 = v[1], d = cmul_mi(x1, sgn);
+    v[0] = cadd(x0, x1);
+    v[1] = cadd(x0, d);
+    v[2] = csub(x0, x1);
+    v[3] = csub(x0, d);
+  } else {  // R == 8
+    const real_t h = 0.70710678118654752440;
+    real2 t0[4], t1[4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) t0[n2] = t1[n2] = v[n2];
+    t1[1] = (sgn < 0) ? mk2(h * (t1[1].x + t1[1].y), h * (t1[1].y - t1[1].x)) : mk2(h * (t1[1].x - t1[1].y), h * (t1[1].y + t1[1].x));
+    t1[2] = cmul_mi(t1[2], sgn);
+    t1[3] = (sgn < 0) ? mk2(h * (t1[3].y - t1[3].x), -h * (t1[3].x + t1[3].y)) : mk2(-h * (t1[3].x + t1[3].y), h * (t1[3].x - t1[3].y));
+    bf4(t0[0], t0[1], t0[2], t0[3], sgn);
+    bf4(t1[0], t1[1], t1[2], t1[3], sgn);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) {
+      v[2 * k2] = t0[k2];
+      v[2 * k2 + 1] = t1[k2];
+    }
+  }
+}
+
 // split a butterfly number q into (block, j) for stride lenp (power of two when sh >= 0)
 EMI_DEVFN void split_q(int q, int lenp, int sh, int &blk, int &j) {
   if (sh >= 0) {
@@ -609,7 +638,8 @@ EMI_DEVFN int log2_exact(int v) { return (v & (v - 1)) ? -1 : (31 - __builtin_cl
 // one butterfly q of one field
 // NOUT: outputs t < NOUT are stored (the last pass of a Bluestein convolution, of which only the first sz <= (S+1)/2
 // elements are ever read: the rest of the butterfly is dead code)
-template <int R, int DIF, int MASK, int TW, int NOUT = R>
+// NZ: inputs t >= NZ are zero by construction and are not read (first DIF pass of a Bluestein convolution)
+template <int R, int DIF, int MASK, int TW, int NOUT = R, int NZ = R>
 EMI_DEVFN void fft_bfly_at(real2 *af, int q, int S, int lenp, int sh, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
   const int len = lenp * R;
   int blk, j;
@@ -630,7 +660,9 @@ EMI_DEVFN void fft_bfly_at(real2 *af, int q, int S, int lenp, int sh, const real
 #pragma unroll
   for (int t = 0; t < R; t++) {
     const int i = base + t * lenp;
-    if (MASK)
+    if (t >= NZ)
+      v[t] = mk2(0.0, 0.0);
+    else if (MASK)
       v[t] = (i < nvalid) ? af[FPAD(i)] : mk2(0.0, 0.0);
     else
       v[t] = af[FPAD(i)];
@@ -645,7 +677,10 @@ EMI_DEVFN void fft_bfly_at(real2 *af, int q, int S, int lenp, int sh, const real
 #pragma unroll
     for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
   }
-  butterfly<R>(v, tw, S, sgn);
+  if constexpr (NZ < R && NZ == R / 2 && (R == 8 || R == 4))
+    butterfly_hz<R>(v, sgn);
+  else
+    butterfly<R>(v, tw, S, sgn);
   if (TW && DIF) {
 #pragma unroll
     for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
@@ -656,18 +691,18 @@ EMI_DEVFN void fft_bfly_at(real2 *af, int q, int S, int lenp, int sh, const real
 // FLAT = 0: field after field, butterfly q = tid + i * nthreads of each (long rows: every sweep is full
 // anyway).  FLAT = 1: the (field, butterfly) pairs of the workgroup are dealt to the threads as one list,
 // so short rows (fewer butterflies than threads) still fill the sweeps.
-template <int R, int DIF, int MASK, int TW, int FLAT = 0, int NOUT = R>
+template <int R, int DIF, int MASK, int TW, int FLAT = 0, int NOUT = R, int NZ = R>
 EMI_DEVFN void fft_pass_body(real2 *a, int nfl, int fstride, int S, int lenp, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
   const int nb = S / R, sh = log2_exact(lenp);
   if (FLAT) {
     for (int idx = EMI_TID; idx < nfl * nb; idx += EMI_NTHREADS) {
       const int fl = idx / nb, q = idx - fl * nb;
-      fft_bfly_at<R, DIF, MASK, TW, NOUT>(a + (long long)fl * fstride, q, S, lenp, sh, tw, ptw, sgn, nvalid);
+      fft_bfly_at<R, DIF, MASK, TW, NOUT, NZ>(a + (long long)fl * fstride, q, S, lenp, sh, tw, ptw, sgn, nvalid);
     }
   } else {
     for (int fl = 0; fl < nfl; fl++) {
       real2 *af = a + (long long)fl * fstride;
-      for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) fft_bfly_at<R, DIF, MASK, TW, NOUT>(af, q, S, lenp, sh, tw, ptw, sgn, nvalid);
+      for (int q = EMI_TID; q < nb; q += EMI_NTHREADS) fft_bfly_at<R, DIF, MASK, TW, NOUT, NZ>(af, q, S, lenp, sh, tw, ptw, sgn, nvalid);
     }
   }
 }
@@ -1133,8 +1168,11 @@ template <int PC, int IP>
 EMI_DEVFN void hot_dif(real2 *a, int nfl, int fs, const FftPlanDev &pl, const real2 *tw, const real2 *ptw, int nvalid) {
   constexpr HotPlanC H = hot_plan(PC);
   if constexpr (IP >= 1) {
-    if constexpr (IP == H.nfac - 1)
-      fft_pass_body<H.fac[IP], 1, 1, 1, (H.nfl > 1)>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, nvalid);
+    if constexpr (IP == H.nfac - 1) {
+      // first pass: the chirped row occupies sz <= S/2 elements, i.e. only the legs t < R/2 of an even radix
+      constexpr int R = H.fac[IP], NZ = (R % 2 == 0) ? R / 2 : R;
+      fft_pass_body<R, 1, 1, 1, (H.nfl > 1), R, NZ>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, nvalid);
+    }
     else
       fft_pass_body<H.fac[IP], 1, 0, 1, (H.nfl > 1)>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, H.S);
     HOT_SYNC(IP, IP - 1);
