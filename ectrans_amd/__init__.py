@@ -47,6 +47,11 @@ class _Setup(C.Structure):
                 ("precision", C.c_int), ("lduseflt", C.c_int), ("ldll", C.c_int), ("ldstretch", C.c_int)]
 
 
+class _Ext(C.Structure):  # emi_extents_t
+    _fields_ = [("sp_dim2", C.c_int), ("gp", C.c_int * 3), ("gpuv", C.c_int * 4), ("gp3a", C.c_int * 4),
+                ("gp3b", C.c_int * 4), ("gp2", C.c_int * 3)]
+
+
 class _Inv(C.Structure):
     _fields_ = [("mem_space", C.c_int), ("spvor", C.c_void_p), ("spdiv", C.c_void_p), ("nf_uv", C.c_int),
                 ("spscalar", C.c_void_p), ("nf_scalar", C.c_int), ("spsc3a", C.c_void_p), ("sc3a_nlev", C.c_int),
@@ -54,7 +59,7 @@ class _Inv(C.Structure):
                 ("spsc2", C.c_void_p), ("nf_sc2", C.c_int), ("ldscders", C.c_int), ("ldvorgp", C.c_int),
                 ("lddivgp", C.c_int), ("lduvder", C.c_int), ("kproma", C.c_int), ("gp", C.c_void_p),
                 ("gp_nfld", C.c_int), ("gpuv", C.c_void_p), ("gp3a", C.c_void_p), ("gp3b", C.c_void_p),
-                ("gp2", C.c_void_p), ("stream", C.c_void_p)]
+                ("gp2", C.c_void_p), ("stream", C.c_void_p), ("ext", C.POINTER(_Ext))]
 
 
 class _Dir(C.Structure):
@@ -63,7 +68,7 @@ class _Dir(C.Structure):
                 ("sc3a_nvar", C.c_int), ("spsc3b", C.c_void_p), ("sc3b_nlev", C.c_int), ("sc3b_nvar", C.c_int),
                 ("spsc2", C.c_void_p), ("nf_sc2", C.c_int), ("kproma", C.c_int), ("gp", C.c_void_p),
                 ("gp_nfld", C.c_int), ("gpuv", C.c_void_p), ("gp3a", C.c_void_p), ("gp3b", C.c_void_p),
-                ("gp2", C.c_void_p), ("stream", C.c_void_p)]
+                ("gp2", C.c_void_p), ("stream", C.c_void_p), ("ext", C.POINTER(_Ext))]
 
 
 def build(force=False):
@@ -295,15 +300,24 @@ def _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, psps
     a.sc3b_nvar, a.sc3b_nlev = (0, 0) if pspsc3b is None else (pspsc3b.shape[0], pspsc3b.shape[2])
 
 
-def _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks):
-    for nm, x in (("gp", pgp), ("gpuv", pgpuv), ("gp3a", pgp3a), ("gp3b", pgp3b), ("gp2", pgp2)):
-        if x is not None and (x.shape[0] != ngpblks or x.shape[-1] != nproma):
-            raise TransError("P%s: first/last extents must be (ngpblks=%d, ..., nproma=%d), got %s"
-                             % (nm.upper(), ngpblks, nproma, tuple(x.shape)))
+def _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks, specs=()):
+    """Grid arrays + the extents block (emi_extents_t): the library makes the reference's extent checks
+    (inv_trans.F90:476-600) on the real shapes.  numpy/torch shapes are the Fortran extents reversed."""
+    ext = _Ext()
+    for nm, x, rank in (("gp", pgp, 3), ("gpuv", pgpuv, 4), ("gp3a", pgp3a, 4), ("gp3b", pgp3b, 4), ("gp2", pgp2, 3)):
+        if x is not None:
+            if x.ndim != rank:
+                raise TransError("P%s must have %d dimensions, got shape %s" % (nm.upper(), rank, tuple(x.shape)))
+            for i, n in enumerate(reversed(tuple(x.shape))):
+                getattr(ext, nm)[i] = int(n)
         p, k = _ptr(x, space)
         setattr(a, nm, p)
         keep.append(k)
+    sp2 = [x.shape[-2] if x.ndim == 3 else x.shape[0] for x in specs if x is not None]
+    ext.sp_dim2 = int(min(sp2)) if sp2 else 0
     a.gp_nfld = 0 if pgp is None else pgp.shape[1]
+    a.ext = C.pointer(ext)
+    keep.append(ext)
 
 
 def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
@@ -315,7 +329,8 @@ def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
     nproma = int(kproma) if kproma else ngptot
     ngpblks = (ngptot - 1) // nproma + 1
     _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
-    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks,
+               (pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2))
     a.ldscders, a.ldvorgp, a.lddivgp, a.lduvder = int(ldscders), int(ldvorgp), int(lddivgp), int(lduvder)
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
@@ -331,7 +346,8 @@ def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
     nproma = int(kproma) if kproma else ngptot
     ngpblks = (ngptot - 1) // nproma + 1
     _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
-    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks,
+               (pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2))
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
@@ -347,7 +363,8 @@ def inv_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, 
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
     nproma = int(kproma) if kproma else ngptot
     _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
-    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, (ngptot - 1) // nproma + 1)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, (ngptot - 1) // nproma + 1,
+               (pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2))
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
@@ -361,7 +378,8 @@ def dir_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, 
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
     nproma = int(kproma) if kproma else ngptot
     _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
-    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, (ngptot - 1) // nproma + 1)
+    _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, (ngptot - 1) // nproma + 1,
+               (pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2))
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream

@@ -188,7 +188,43 @@ struct Plan {
   size_t cap_W = 0, cap_FBL = 0, cap_FBF = 0;
   void *d_desc = nullptr;
   size_t cap_desc = 0;
+  // Calls on one resolution share d_desc, W and the Fourier buffers, whatever stream each call names: every call
+  // starts by making its stream wait for the event the previous call of this resolution recorded at its end.
+#ifndef EMI_CPU_EMU
+  hipEvent_t ev_done = nullptr;
+#endif
+  bool ev_valid = false;
 };
+
+// order a call on `st` behind the previous call of the same resolution (device-side wait, nothing blocks the host)
+static int plan_begin(Plan &P, emi_stream_t st) {
+#ifndef EMI_CPU_EMU
+  if (P.ev_valid) EMI_CHECK(hipStreamWaitEvent(st, P.ev_done, 0));
+#else
+  (void)P;
+  (void)st;
+#endif
+  return 0;
+}
+static int plan_end(Plan &P, emi_stream_t st) {
+#ifndef EMI_CPU_EMU
+  if (!P.ev_done) EMI_CHECK(hipEventCreateWithFlags(&P.ev_done, hipEventDisableTiming));
+  EMI_CHECK(hipEventRecord(P.ev_done, st));
+  P.ev_valid = true;
+#else
+  (void)P;
+  (void)st;
+#endif
+  return 0;
+}
+// host waits until the last call of the resolution has finished (before its buffers are freed or regrown)
+static void plan_quiesce(Plan &P) {
+#ifndef EMI_CPU_EMU
+  if (P.ev_valid) (void)hipEventSynchronize(P.ev_done);
+#else
+  (void)P;
+#endif
+}
 
 static struct {
   bool init = false;
@@ -1092,7 +1128,11 @@ extern "C" int emi_set_alltoallv(emi_alltoallv_fn fn, void *user) {
 extern "C" int emi_release(int kresol) {
   Plan *P = get_plan(kresol);
   if (!P) EMI_FAIL(EMI_ERR_STATE, "TRANS_RELEASE: unknown resolution %d", kresol);
+  plan_quiesce(*P);
   emi_stream_sync(0);
+#ifndef EMI_CPU_EMU
+  if (P->ev_done) (void)hipEventDestroy(P->ev_done);
+#endif
   for (void *p : P->dev_allocs) emi_dev_free(p);
   for (auto &kv : P->legmaps) {
     emi_dev_free(kv.second.d_inv);
@@ -1299,6 +1339,7 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
   size_t esz;
   explicit HostStage(int e) : esz((size_t)e) {}
   std::vector<void *> dev;
+  bool failed = false;  // a staging buffer could not be allocated or filled: the call must not launch anything
   std::vector<std::pair<void *, std::pair<void *, size_t>>> outs;  // dev -> (host, bytes)
   ~HostStage() {
     for (void *p : dev) emi_dev_free(p);
@@ -1306,9 +1347,12 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
   const void *in(const void *h, size_t elems, bool host, emi_stream_t s) {
     if (!h || !host) return h;
     void *d = nullptr;
-    if (emi_dev_malloc(&d, elems * esz)) return nullptr;
+    if (emi_dev_malloc(&d, elems * esz)) {
+      failed = true;
+      return nullptr;
+    }
     dev.push_back(d);
-    emi_h2d(d, h, elems * esz, s);
+    if (emi_h2d(d, h, elems * esz, s)) failed = true;
     return d;
   }
   // preload: the call does not write every element of the array (padding of the last NPROMA block, more
@@ -1317,9 +1361,12 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
   void *out(void *h, size_t elems, bool host, bool preload = false, emi_stream_t s = 0) {
     if (!h || !host) return h;
     void *d = nullptr;
-    if (emi_dev_malloc(&d, elems * esz)) return nullptr;
+    if (emi_dev_malloc(&d, elems * esz)) {
+      failed = true;
+      return nullptr;
+    }
     dev.push_back(d);
-    if (preload) emi_h2d(d, h, elems * esz, s);
+    if (preload && emi_h2d(d, h, elems * esz, s)) failed = true;
     outs.push_back({d, {h, elems * esz}});
     return d;
   }
@@ -1329,8 +1376,9 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
   }
 };
 
-static int grow(char **p, size_t *cap, size_t need, const char *what) {
+static int grow(Plan &P, char **p, size_t *cap, size_t need, const char *what, emi_stream_t st) {
   if (need <= *cap) return 0;
+  plan_quiesce(P);  // kernels of the previous call (on whatever stream it named) may still use the old buffer
   emi_stream_sync(0);
   emi_dev_free(*p);
   *p = nullptr;
@@ -1339,21 +1387,21 @@ static int grow(char **p, size_t *cap, size_t need, const char *what) {
   if (emi_dev_malloc(&q, need)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB %s", need / 1073741824.0, what);
   *p = (char *)q;
   *cap = need;
-  emi_dev_memset(q, 0, need, 0);
+  emi_dev_memset(q, 0, need, st);  // on the caller's stream: ordered ahead of this call's kernels
   return 0;
 }
 
-static int ensure_work(Plan &P, int bfpad, int nfb) {
+static int ensure_work(Plan &P, int bfpad, int nfb, emi_stream_t st) {
   const size_t rowb = (size_t)2 * bfpad * P.esz;
-  if (grow(&P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer")) return -1;
+  if (grow(P, &P.d_W, &P.cap_W, (size_t)P.wrows_total * rowb, "packed-spectral work buffer", st)) return -1;
   if (P.nproc == 1) {
     // + 1 per buffer: a row of zeros behind the Fourier rows (k_leg_dir reads it for latitudes past the last one of a stage)
-    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * (P.frows + 1) * rowb, "Fourier work buffer")) return -1;
+    if (grow(P, &P.d_FBL, &P.cap_FBL, (size_t)nfb * (P.frows + 1) * rowb, "Fourier work buffer", st)) return -1;
     P.d_FBF = P.d_FBL;
     P.cap_FBF = P.cap_FBL;
   } else {
-    if (grow(&P.d_FBL, &P.cap_FBL, (size_t)nfb * (P.lrows + 1) * rowb, "Fourier (Legendre-side) exchange buffer")) return -1;
-    if (grow(&P.d_FBF, &P.cap_FBF, (size_t)nfb * P.frows * rowb, "Fourier (FFT-side) exchange buffer")) return -1;
+    if (grow(P, &P.d_FBL, &P.cap_FBL, (size_t)nfb * (P.lrows + 1) * rowb, "Fourier (Legendre-side) exchange buffer", st)) return -1;
+    if (grow(P, &P.d_FBF, &P.cap_FBF, (size_t)nfb * P.frows * rowb, "Fourier (FFT-side) exchange buffer", st)) return -1;
   }
   return 0;
 }
@@ -1422,6 +1470,7 @@ static int upload_desc(Plan &P, const std::vector<char> &hd, emi_stream_t st) {
 
 static int ensure_desc(Plan &P, size_t bytes) {
   if (bytes <= P.cap_desc) return 0;
+  plan_quiesce(P);
   emi_stream_sync(0);
   emi_dev_free(P.d_desc);
   P.d_desc = nullptr;
@@ -1715,6 +1764,63 @@ static int enumerate_scalars(const ARGS &a, const char *who, std::vector<ScalarR
   return 0;
 }
 
+// The reference's extent checks (inv_trans.F90:476-600, dir_trans.F90:370-491) on the extents the caller reports.
+// nvar_uv = IF_UV_PAR; dmul = 3 with LDSCDERS (IF_SC2_G, IF_SC3A_G3 and IF_SC3B_G3 are tripled, inv_trans.F90:371-376).
+// *uv_dim3: the third extent of PGPUV to address with (>= nvar_uv).
+template <class ARGS>
+static int check_extents(const char *who, const ARGS &a, int nspec2, int nproma, int ngpblks, int nuv, int nvar_uv, int dmul,
+                         int *uv_dim3) {
+  *uv_dim3 = nvar_uv;
+  const emi_extents_t *e = a.ext;
+  if (!e) return 0;
+  if (e->sp_dim2 > 0 && e->sp_dim2 < nspec2)
+    EMI_FAIL(EMI_ERR_ARG, "%s : SECOND DIMENSION OF A SPECTRAL ARRAY TOO SMALL (%d < NSPEC2 = %d)", who, e->sp_dim2, nspec2);
+  auto lead = [&](const char *nm, int d1) {
+    if (d1 < nproma) {
+      emi_set_error("%s:FIRST DIMENSION OF %s TOO SMALL (%d < %d)", who, nm, d1, nproma);
+      return -1;
+    }
+    if (d1 != nproma) {
+      emi_set_error("%s: first extent of %s is %d, NPROMA is %d: pass a packed copy at the C-ABI (the Fortran shim does)", who, nm, d1, nproma);
+      return -1;
+    }
+    return 0;
+  };
+  if (a.gp) {
+    if (lead("PGP", e->gp[0])) return EMI_ERR_ARG;
+    if (e->gp[1] != a.gp_nfld) EMI_FAIL(EMI_ERR_ARG, "%s: gp_nfld (%d) is not the second extent of PGP (%d)", who, a.gp_nfld, e->gp[1]);
+    if (e->gp[2] < ngpblks) EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP TOO SMALL (%d < %d)", who, e->gp[2], ngpblks);
+  }
+  if (a.gpuv) {
+    if (lead("PGPUV", e->gpuv[0])) return EMI_ERR_ARG;
+    if (e->gpuv[1] != a.nf_uv) EMI_FAIL(EMI_ERR_ARG, "%s:SEC. DIMENSION OF PGPUV INCONSISTENT (%d, IF_UV_G = %d)", who, e->gpuv[1], a.nf_uv);
+    if (e->gpuv[2] < nvar_uv) EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGPUV TOO SMALL (%d < %d)", who, e->gpuv[2], nvar_uv);
+    if (e->gpuv[3] < ngpblks) EMI_FAIL(EMI_ERR_ARG, "%s:FOURTH DIMENSION OF PGPUV TOO SMALL (%d < %d)", who, e->gpuv[3], ngpblks);
+    *uv_dim3 = e->gpuv[2];
+    (void)nuv;
+  }
+  if (a.gp2 && a.nf_sc2 > 0) {
+    if (lead("PGP2", e->gp2[0])) return EMI_ERR_ARG;
+    if (e->gp2[1] != a.nf_sc2 * dmul) EMI_FAIL(EMI_ERR_ARG, "%s:SEC. DIMENSION OF PGP2 INCONSISTENT (%d, IF_SC2_G = %d)", who, e->gp2[1], a.nf_sc2 * dmul);
+    if (e->gp2[2] < ngpblks) EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP2 TOO SMALL (%d < %d)", who, e->gp2[2], ngpblks);
+  }
+  if (a.gp3a && a.sc3a_nlev * a.sc3a_nvar > 0) {
+    if (lead("PGP3A", e->gp3a[0])) return EMI_ERR_ARG;
+    if (e->gp3a[1] != a.sc3a_nlev) EMI_FAIL(EMI_ERR_ARG, "%s:SEC. DIMENSION OF PGP3A INCONSISTENT (%d, IF_SC3A_G2 = %d)", who, e->gp3a[1], a.sc3a_nlev);
+    if (e->gp3a[2] != a.sc3a_nvar * dmul)
+      EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3A INCONSISTENT (%d, IF_SC3A_G3 = %d)", who, e->gp3a[2], a.sc3a_nvar * dmul);
+    if (e->gp3a[3] < ngpblks) EMI_FAIL(EMI_ERR_ARG, "%s:FOURTH DIMENSION OF PGP3A TOO SMALL (%d < %d)", who, e->gp3a[3], ngpblks);
+  }
+  if (a.gp3b && a.sc3b_nlev * a.sc3b_nvar > 0) {
+    if (lead("PGP3B", e->gp3b[0])) return EMI_ERR_ARG;
+    if (e->gp3b[1] != a.sc3b_nlev) EMI_FAIL(EMI_ERR_ARG, "%s:SEC. DIMENSION OF PGP3B INCONSISTENT (%d, IF_SC3B_G2 = %d)", who, e->gp3b[1], a.sc3b_nlev);
+    if (e->gp3b[2] != a.sc3b_nvar * dmul)
+      EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3B INCONSISTENT (%d, IF_SC3B_G3 = %d)", who, e->gp3b[2], a.sc3b_nvar * dmul);
+    if (e->gp3b[3] < ngpblks) EMI_FAIL(EMI_ERR_ARG, "%s:FOURTH DIMENSION OF PGP3B TOO SMALL (%d < %d)", who, e->gp3b[3], ngpblks);
+  }
+  return 0;
+}
+
 // INV_TRANS, and DIR_TRANSAD when adj: the adjoint of DIR_TRANS (for the inner products of the
 // reference's adjoint tests: plain sum over grid points, SPECNORM weights in spectral space) is the same
 // spectral -> grid pipeline with the Gaussian weight and 1/NLOEN applied per latitude (ledirad_mod.F90:151,183,
@@ -1750,7 +1856,12 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     if (a.spsc3b && a.sc3b_nlev * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "INV_TRANS:PGP3B MISSING");
   }
   if (if_gp == 0) return EMI_SUCCESS;
+  const int nvar_uv = ((nuv && lvorgp) ? 1 : 0) + ((nuv && ldivgp) ? 1 : 0) + 2 + (luvder ? 2 : 0);  // IF_UV_PAR
+  const int dmul = lscders ? 3 : 1;
+  int uv_dim3 = nvar_uv;
+  if (check_extents(adj ? "DIR_TRANSAD" : "INV_TRANS", a, P.nspec2, nproma, ngpblks, nuv, nvar_uv, dmul, &uv_dim3)) return EMI_ERR_ARG;
   if (set_lds_attrs()) return EMI_ERR_RUNTIME;
+  if (plan_begin(P, st)) return EMI_ERR_RUNTIME;
 
   // ---- stage host arrays
   HostStage hs(P.esz);
@@ -1759,15 +1870,14 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   const void *d_sc[4] = {hs.in(a.spscalar, ns2 * a.nf_scalar, host, st), hs.in(a.spsc2, ns2 * a.nf_sc2, host, st),
                            hs.in(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host, st),
                            hs.in(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host, st)};
-  const int nvar_uv = ((nuv && lvorgp) ? 1 : 0) + ((nuv && ldivgp) ? 1 : 0) + 2 + (luvder ? 2 : 0);
-  const int dmul = lscders ? 3 : 1;
   const size_t gsz = (size_t)nproma * ngpblks;
   const bool gpad = gsz != (size_t)P.ngptot;  // last NPROMA block padded: those elements are not written
   void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host, gpad || a.gp_nfld > if_gp, st);
-  void *d_gpuv = hs.out(a.gpuv, gsz * nuv * nvar_uv, host && nuv, gpad, st);
+  void *d_gpuv = hs.out(a.gpuv, gsz * nuv * uv_dim3, host && nuv, gpad || uv_dim3 > nvar_uv, st);
   void *d_gp2 = hs.out(a.gp2, gsz * a.nf_sc2 * dmul, host, gpad, st);
   void *d_gp3a = hs.out(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar * dmul, host, gpad, st);
   void *d_gp3b = hs.out(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar * dmul, host, gpad, st);
+  if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "INV_TRANS: cannot stage the host arrays through device memory (%s)", emi_last_error());
 
   // ---- Legendre-space fields (ltinv_mod.F90:166-262): [vor][div] u v scalars [nsders]
   std::vector<SpecSrc> lt;
@@ -1810,7 +1920,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   auto dest_uv = [&](int var, int lev) {
     GridFld g{};
     if (d_gp) { g.base = d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
-    else { g.base = d_gpuv; g.nf_arr = nuv * nvar_uv; g.fidx = var * nuv + lev; }
+    else { g.base = d_gpuv; g.nf_arr = nuv * uv_dim3; g.fidx = var * nuv + lev; }
     return g;
   };
   auto dest_sc = [&](int isc, int kder) {
@@ -1852,7 +1962,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
   // batches of ceil(fields / nbat) rounded up to 64 the 4 x 448 columns of a 1645-field call were 9 % padding).
   const int tiles_total = (nlt + 63) / 64;
   const int bfpad = 64 * ((tiles_total + nbat - 1) / nbat);  // widest batch
-  if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
+  if (ensure_work(P, bfpad, piped ? 2 : 1, st)) return EMI_ERR_RUNTIME;
   const int ldw_max = 2 * bfpad;
   // all descriptors of the call in one upload
   struct Bat { size_t off_l, off_g; int nl, ng, ldw; };
@@ -1881,6 +1991,11 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     bats.push_back(bt);
     b0 += nb;
   }
+  // Legendre tile maps per batch: a batch with fewer fields than the row width (the last one of a call) only
+  // gets the column tiles that hold fields (built before anything is queued or forked: a new map is a blocking upload)
+  std::vector<LegMaps *> bmaps(nbat, nullptr);
+  for (int ib = 0; ib < nbat; ib++)
+    if (leg_tilemaps(P, (bats[ib].nl + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
   if (upload_desc(P, hdesc, st)) return EMI_ERR_RUNTIME;
   emi_stream_t sA = st, sB = st, sX = st;
   if (piped) {
@@ -1890,11 +2005,6 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     sX = (emi_stream_t)g_pipe.sX;
     g_pipe.begin(st);
   }
-  // Legendre tile maps per batch: a batch with fewer fields than the row width (the last one of a call) only
-  // gets the column tiles that hold fields (built before anything is queued: a new map is a blocking upload)
-  std::vector<LegMaps *> bmaps(nbat, nullptr);
-  for (int ib = 0; ib < nbat; ib++)
-    if (leg_tilemaps(P, (bats[ib].nl + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile != 0, G.profile == 2);
   // Events of batch ib: 3 ib = Legendre done, 3 ib + 1 = FFT done, 3 ib + 2 = exchange done.  Both
   // Fourier buffers are double buffered ([ib & 1]); one task: FBf == FBl and there is no exchange.
@@ -1926,7 +2036,11 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
       // stream X: TRMTOL; FBf[ib&1] was last read by the FFT of batch ib-2
       if (piped) g_pipe.wait(3 * ib, sX);
       if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + 1, sX);
-      if (exchange(P, true, ldw, sX, FBl, FBf)) return EMI_ERR_RUNTIME;
+      if (exchange(P, true, ldw, sX, FBl, FBf)) {
+        if (piped) g_pipe.end(st);  // the three streams were forked from the caller's: join them before giving up
+        plan_end(P, st);
+        return EMI_ERR_RUNTIME;
+      }
       if (piped) g_pipe.signal(3 * ib + 2, sX);
     }
     // stream B: FFTs
@@ -1937,6 +2051,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     if (piped) g_pipe.signal(3 * ib + 1, sB);
   }
   if (piped) g_pipe.end(st);
+  if (plan_end(P, st)) return EMI_ERR_RUNTIME;
   if (host) hs.flush(st);
 #ifndef EMI_CPU_EMU
   EMI_CHECK(hipGetLastError());
@@ -1974,7 +2089,10 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     if (a.spsc3b && a.sc3b_nlev * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP3B MISSING");
   }
   if (if_gp == 0) return EMI_SUCCESS;
+  int uv_dim3 = 2;
+  if (check_extents(adj ? "INV_TRANSAD" : "DIR_TRANS", a, P.nspec2, nproma, ngpblks, nuv, 2, 1, &uv_dim3)) return EMI_ERR_ARG;
   if (set_lds_attrs()) return EMI_ERR_RUNTIME;
+  if (plan_begin(P, st)) return EMI_ERR_RUNTIME;
 
   HostStage hs(P.esz);
   const size_t ns2 = P.nspec2, gsz = (size_t)nproma * ngpblks;
@@ -1982,10 +2100,11 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   void *d_sc[4] = {hs.out(a.spscalar, ns2 * a.nf_scalar, host), hs.out(a.spsc2, ns2 * a.nf_sc2, host),
                      hs.out(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host), hs.out(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host)};
   const void *d_gp = hs.in(a.gp, gsz * a.gp_nfld, host, st);
-  const void *d_gpuv = hs.in(a.gpuv, gsz * nuv * 2, host && nuv, st);
+  const void *d_gpuv = hs.in(a.gpuv, gsz * nuv * uv_dim3, host && nuv, st);
   const void *d_gp2 = hs.in(a.gp2, gsz * a.nf_sc2, host, st);
   const void *d_gp3a = hs.in(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar, host, st);
   const void *d_gp3b = hs.in(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar, host, st);
+  if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "DIR_TRANS: cannot stage the host arrays through device memory (%s)", emi_last_error());
 
   // Fourier-space fields: u(nuv) v(nuv) scalars (dir_trans.F90:301, ftdir_ctl_mod.F90)
   std::vector<GridFld> gin;
@@ -1994,7 +2113,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     for (int i = 0; i < nuv; i++) {
       GridFld g{};
       if (d_gp) { g.base = (void *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
-      else { g.base = (void *)d_gpuv; g.nf_arr = nuv * 2; g.fidx = var * nuv + i; }
+      else { g.base = (void *)d_gpuv; g.nf_arr = nuv * uv_dim3; g.fidx = var * nuv + i; }
       g.mode = GM_ACOS;
       gin.push_back(g);
       gcount++;
@@ -2033,7 +2152,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   const int nbat = (int)batches.size();
   const bool piped = depth > 1 && nbat > 1;
   const int bfpad = roundup(maxb, 64);
-  if (ensure_work(P, bfpad, piped ? 2 : 1)) return EMI_ERR_RUNTIME;
+  if (ensure_work(P, bfpad, piped ? 2 : 1, st)) return EMI_ERR_RUNTIME;
   const int ldw_max = 2 * bfpad;  // row width of the widest batch; every batch has its own (2 x its fields rounded up to 64)
   struct Bat { size_t off_g, off_o, off_f; int ng, no, ldw; };
   // EMI_NO_FUSE_DIR: every field through W and k_postpack_dir (the path before the fused epilogue; A/B)
@@ -2088,6 +2207,9 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     memcpy(hdesc.data() + bt.off_f, bf.data(), bf.size() * sizeof(FuseDst));
     bats.push_back(bt);
   }
+  std::vector<LegMaps *> bmaps(nbat, nullptr);  // per batch: only the column tiles that hold fields (as INV_TRANS)
+  for (int ib = 0; ib < nbat; ib++)
+    if (leg_tilemaps(P, (bats[ib].ng + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
   if (upload_desc(P, hdesc, st)) return EMI_ERR_RUNTIME;
   emi_stream_t sA = st, sB = st, sX = st;
   if (piped) {
@@ -2097,9 +2219,6 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     sX = (emi_stream_t)g_pipe.sX;
     g_pipe.begin(st);
   }
-  std::vector<LegMaps *> bmaps(nbat, nullptr);  // per batch: only the column tiles that hold fields (as INV_TRANS)
-  for (int ib = 0; ib < nbat; ib++)
-    if (leg_tilemaps(P, (bats[ib].ng + 63) / 64, &bmaps[ib])) return EMI_ERR_RUNTIME;
   g_pt.begin(G.profile != 0, G.profile == 2);
   // events of batch ib: 3 ib = FFT done, 3 ib + 1 = Legendre done, 3 ib + 2 = exchange done (as INV_TRANS)
   const bool dist = P.nproc > 1;
@@ -2124,7 +2243,11 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
       // stream X: TRLTOM; FBl[ib&1] was last read by the Legendre transform of batch ib-2
       if (piped) g_pipe.wait(3 * ib, sX);
       if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + 1, sX);
-      if (exchange(P, false, ldw, sX, FBl, FBf)) return EMI_ERR_RUNTIME;
+      if (exchange(P, false, ldw, sX, FBl, FBf)) {
+        if (piped) g_pipe.end(st);
+        plan_end(P, st);
+        return EMI_ERR_RUNTIME;
+      }
       if (piped) g_pipe.signal(3 * ib + 2, sX);
     }
     // stream A: Legendre + spectral unpack
@@ -2145,6 +2268,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     g_pt.stop(iv, sA);
   }
   if (piped) g_pipe.end(st);
+  if (plan_end(P, st)) return EMI_ERR_RUNTIME;
   if (host) hs.flush(st);
 #ifndef EMI_CPU_EMU
   EMI_CHECK(hipGetLastError());
@@ -2154,7 +2278,11 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
 
 static int specnorm_sumsq(Plan &P, int mem_space, const void *spec, int nfld, double *sumsq) {
   HostStage hs(P.esz);
+  // SPECNORM has no stream argument: it runs on the null stream behind the last transform of this resolution
+  // (which may have been queued on a non-blocking stream, e.g. the DIR_TRANS that produced `spec`)
+  if (plan_begin(P, (emi_stream_t)0)) return EMI_ERR_RUNTIME;
   const void *d_sp = hs.in(spec, (size_t)P.nspec2 * nfld, mem_space == EMI_MEM_HOST, 0);
+  if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "SPECNORM: cannot stage the host array through device memory");
   void *d_out = nullptr;
   if (emi_dev_malloc(&d_out, (size_t)nfld * 8)) return EMI_ERR_RUNTIME;
   EMI_LAUNCH_P(P.esz, k_specnorm, nfld, 256, 256 * 8, (emi_stream_t)0, P.g, (long long)P.nspec2, (const RT *)d_sp, nfld, (double *)d_out);
@@ -2244,6 +2372,7 @@ extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {
   d.kproma = a.kproma;
   d.gp = a.gp, d.gp_nfld = a.gp_nfld, d.gpuv = a.gpuv, d.gp3a = a.gp3a, d.gp3b = a.gp3b, d.gp2 = a.gp2;
   d.stream = a.stream;
+  d.ext = a.ext;
   return dir_trans_impl(kresol, &d, true);
 }
 // DIR_TRANSAD (include/ectrans/dir_transad.h): arguments of DIR_TRANS with the intents swapped
@@ -2261,5 +2390,6 @@ extern "C" int emi_dir_transad(int kresol, const emi_dirtrans_t *ap) {
   a.gp = (void *)d.gp, a.gp_nfld = d.gp_nfld, a.gpuv = (void *)d.gpuv, a.gp3a = (void *)d.gp3a, a.gp3b = (void *)d.gp3b,
   a.gp2 = (void *)d.gp2;
   a.stream = d.stream;
+  a.ext = d.ext;
   return inv_trans_impl(kresol, &a, true);
 }

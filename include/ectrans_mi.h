@@ -97,6 +97,22 @@ int emi_inq_real_array(int kresol, const char *name, double *out, int len);
  * descending.  out == NULL only returns the sizes.                                        */
 int emi_inq_legendre(int kresol, int m, int symmetric, double *out, int *nrows, int *ncols);
 
+/* Extents (UBOUND) of the caller's arrays, so that the library can make the reference's own extent checks
+ * (inv_trans.F90:476-600, dir_trans.F90:370-491: 'SEC. DIMENSION OF PGPUV INCONSISTENT', 'THIRD DIMENSION OF PGPUV
+ * TOO SMALL', 'SEC. DIMENSION OF PGP2 INCONSISTENT', ...) before any kernel touches them.  Arrays that are absent
+ * have zero extents.  The leading extent of every grid array must EQUAL NPROMA at this boundary (the reference
+ * accepts a larger one; the Fortran shim then passes a packed copy); a PGPUV with more variables than the call
+ * produces (third extent > IF_UV_PAR) is addressed with its real extent.  emi_invtrans_t.ext / emi_dirtrans_t.ext
+ * == NULL: the caller vouches for the sizes (device-resident callers that computed them from TRANS_INQ).       */
+typedef struct {
+  int sp_dim2;   /* smallest NSPEC2-extent over the spectral arrays present (dimension 2 of all of them)      */
+  int gp[3];     /* UBOUND(PGP)   = nproma, fields, ngpblks                                                     */
+  int gpuv[4];   /* UBOUND(PGPUV) = nproma, levels, variables, ngpblks                                          */
+  int gp3a[4];   /* UBOUND(PGP3A)                                                                               */
+  int gp3b[4];   /* UBOUND(PGP3B)                                                                               */
+  int gp2[3];    /* UBOUND(PGP2)  = nproma, fields, ngpblks                                                     */
+} emi_extents_t;
+
 /* ---- INV_TRANS (trans/include/ectrans/inv_trans.h:12-163) --------------------------- */
 typedef struct {
   int mem_space;
@@ -119,7 +135,10 @@ typedef struct {
   void *gpuv;                 /* PGPUV(nproma, nf_uv, nvar_uv, ngpblks)                    */
   void *gp3a, *gp3b;          /* PGP3A(nproma, nlev, nvar[*3], ngpblks)                    */
   void *gp2;                  /* PGP2(nproma, nf_sc2[*3], ngpblks)                         */
-  void *stream;               /* hipStream_t, NULL: default stream                         */
+  void *stream;               /* hipStream_t, NULL: default stream.  Calls on one resolution handle are
+                               * serialised by the library whatever their streams (they share its work
+                               * buffers): a call waits, on the device, for the previous call of that handle */
+  const emi_extents_t *ext;   /* extents of the arrays above, NULL: unchecked                */
 } emi_invtrans_t;
 int emi_inv_trans(int kresol, const emi_invtrans_t *args);
 
@@ -142,6 +161,7 @@ typedef struct {
   const void *gpuv;  /* PGPUV(nproma, nf_uv, 2, ngpblks)                                   */
   const void *gp3a, *gp3b, *gp2;
   void *stream;
+  const emi_extents_t *ext;
 } emi_dirtrans_t;
 int emi_dir_trans(int kresol, const emi_dirtrans_t *args);
 

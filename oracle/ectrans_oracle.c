@@ -39,6 +39,8 @@ struct orc_trans {
   double *rn;                        /* [-1..ntmax+3] stored with +1 shift */
   double *rlapin;                    /* [-1..nsmax+2] stored with +1 shift */
   double **rpnma, **rpnms;           /* per m, column-major (idglu x ila|ils) */
+  int lazy;                          /* panels are rebuilt per wavenumber inside LTINV / LTDIR (orc_setup_lazy) */
+  void *pol;                         /* pol_t of INI_POL, kept for the lazy mode */
 };
 
 static void *xcalloc(size_t n, size_t s) {
@@ -589,11 +591,36 @@ static void setup_geom(orc_trans *t) {
     for (int jm = 0; jm <= NMEN(jgl) && jm <= nsmax; jm++) t->ndglu[jm] += 1;
 }
 
+/* RPNMA / RPNMS of one wavenumber by SUPOLF (suleg_mod.F90:609-662, 891-944) */
+static void supolf_panels(const orc_trans *t, const pol_t *pol, int im, double **ppa, double **pps) {
+  const int nsmax = t->nsmax, imaxn = t->ntmax + 1;
+  double *zlpol = xcalloc((size_t)imaxn + 3, 8);
+  int *icorr = xcalloc((size_t)imaxn + 3, sizeof(int));
+  int ila = (nsmax - im + 2) / 2, ils = (nsmax - im + 3) / 2;
+  int idglu = IMIN(t->ndgnh, t->ndglu[im]);
+  int isl = IMAX(t->ndgnh - t->ndglu[im] + 1, 1);
+  double *pa = xcalloc((size_t)idglu * ila, 8), *ps = xcalloc((size_t)idglu * ils, 8);
+  int inmaxa = ((imaxn - im) % 2 == 0) ? imaxn + 1 : imaxn; /* suleg_mod.F90:631-635 */
+  int inmaxs = ((imaxn - im) % 2 == 0) ? imaxn : imaxn + 1; /* suleg_mod.F90:913-917 */
+  for (int jgl = 1; jgl <= idglu; jgl++) {
+    double mu = t->rmu[isl + jgl - 1 - 1];
+    supolf(pol, im, inmaxa, mu, zlpol, 3, icorr);
+    for (int ji = 1; ji <= ila; ji++) /* column ILA-JI+1 <- n = m+2(ji-1)+1 */
+      pa[(size_t)(ila - ji) * idglu + (jgl - 1)] = zlpol[im + 2 * (ji - 1) + 1];
+    supolf(pol, im, inmaxs, mu, zlpol, 2, icorr);
+    for (int ji = 1; ji <= ils; ji++) ps[(size_t)(ils - ji) * idglu + (jgl - 1)] = zlpol[im + 2 * (ji - 1)];
+  }
+  free(zlpol);
+  free(icorr);
+  *ppa = pa;
+  *pps = ps;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* SETUP_TRANS (cpu/external/setup_trans.F90:169-428) -> SETUP_DIMS, SUMP_TRANS_PRELEG,  */
 /* PRE_SULEG, SULEG, SETUP_GEOM for NPROC=1                                              */
 /* ------------------------------------------------------------------------------------ */
-orc_trans *orc_setup(int nsmax, int ndgl, const int *nloen_in, int belusov, double ra) {
+static orc_trans *orc_setup_impl(int nsmax, int ndgl, const int *nloen_in, int belusov, double ra, int lazy) {
   if (ndgl <= 0 || ndgl % 2 != 0) return NULL; /* setup_trans.F90:268-270 */
   orc_trans *t = xcalloc(1, sizeof(*t));
   t->nsmax = nsmax;
@@ -671,36 +698,19 @@ orc_trans *orc_setup(int nsmax, int ndgl, const int *nloen_in, int belusov, doub
   /* Legendre panels RPNMA/RPNMS (suleg_mod.F90:609-615,721-726 | 891-897,1001-1006) */
   t->rpnma = xcalloc((size_t)nsmax + 1, sizeof(double *));
   t->rpnms = xcalloc((size_t)nsmax + 1, sizeof(double *));
-  int imaxn = t->ntmax + 1;
   pol_t pol = ini_pol(t->ntmax + 3); /* suleg_mod.F90:241 */
   if (!belusov) {
-#pragma omp parallel
-    {
-      double *zlpol = xcalloc((size_t)imaxn + 3, 8);
-      int *icorr = xcalloc((size_t)imaxn + 3, sizeof(int));
-#pragma omp for schedule(dynamic, 1)
-      for (int im = 0; im <= nsmax; im++) {
-        int ila = (nsmax - im + 2) / 2, ils = (nsmax - im + 3) / 2;
-        int idglu = IMIN(t->ndgnh, t->ndglu[im]);
-        int isl = IMAX(t->ndgnh - t->ndglu[im] + 1, 1);
-        double *pa = xcalloc((size_t)idglu * ila, 8), *ps = xcalloc((size_t)idglu * ils, 8);
-        int inmaxa = ((imaxn - im) % 2 == 0) ? imaxn + 1 : imaxn; /* suleg_mod.F90:631-635 */
-        int inmaxs = ((imaxn - im) % 2 == 0) ? imaxn : imaxn + 1; /* suleg_mod.F90:913-917 */
-        for (int jgl = 1; jgl <= idglu; jgl++) {
-          double mu = t->rmu[isl + jgl - 1 - 1];
-          supolf(&pol, im, inmaxa, mu, zlpol, 3, icorr);
-          for (int ji = 1; ji <= ila; ji++) /* column ILA-JI+1 <- n = m+2(ji-1)+1 */
-            pa[(size_t)(ila - ji) * idglu + (jgl - 1)] = zlpol[im + 2 * (ji - 1) + 1];
-          supolf(&pol, im, inmaxs, mu, zlpol, 2, icorr);
-          for (int ji = 1; ji <= ils; ji++)
-            ps[(size_t)(ils - ji) * idglu + (jgl - 1)] = zlpol[im + 2 * (ji - 1)];
-        }
-        t->rpnma[im] = pa;
-        t->rpnms[im] = ps;
-      }
-      free(zlpol);
-      free(icorr);
+    if (lazy) {
+      /* panels on demand (supolf_panels called from LTINV / LTDIR): nothing is stored, so a TCo2559 oracle needs
+       * megabytes instead of 51 GiB; the values are the same, operation for operation */
+      t->lazy = 1;
+      pol_t *keep = xcalloc(1, sizeof(pol_t));
+      *keep = pol;
+      t->pol = keep;
+      return t;
     }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int im = 0; im <= nsmax; im++) supolf_panels(t, &pol, im, &t->rpnma[im], &t->rpnms[im]);
   } else {
     /* Belousov: RPNM(lat, NPMS(m)+..) from SUPOL per latitude with INSMAX=NTMAX+1
      * (suleg_mod.F90:402-468); panels then cut out at suleg_mod.F90:745-766, 1025-1046:
@@ -747,8 +757,19 @@ orc_trans *orc_setup(int nsmax, int ndgl, const int *nloen_in, int belusov, doub
   return t;
 }
 
+orc_trans *orc_setup(int nsmax, int ndgl, const int *nloen_in, int belusov, double ra) {
+  return orc_setup_impl(nsmax, ndgl, nloen_in, belusov, ra, 0);
+}
+orc_trans *orc_setup_lazy(int nsmax, int ndgl, const int *nloen_in, double ra) {
+  return orc_setup_impl(nsmax, ndgl, nloen_in, 0, ra, 1);
+}
+
 void orc_free(orc_trans *t) {
   if (!t) return;
+  if (t->pol) {
+    end_pol((pol_t *)t->pol);
+    free(t->pol);
+  }
   for (int m = 0; m <= t->nsmax; m++) {
     free(t->rpnma[m]);
     free(t->rpnms[m]);
@@ -770,7 +791,7 @@ const int *orc_nasm0(const orc_trans *t) { return t->nasm0; }
 const double *orc_rpnma(const orc_trans *t, int m, int *rows, int *cols) {
   *rows = IMIN(t->ndgnh, t->ndglu[m]);
   *cols = (t->nsmax - m + 2) / 2;
-  return t->rpnma[m];
+  return t->rpnma[m]; /* NULL after orc_setup_lazy */
 }
 const double *orc_rpnms(const orc_trans *t, int m, int *rows, int *cols) {
   *rows = IMIN(t->ndgnh, t->ndglu[m]);
@@ -921,6 +942,11 @@ static void ltinv(const orc_trans *t, int km, int kf_uv, int kf_scalars, int kf_
   int iskip = (km == 0) ? 2 : 1;
   const double *pia = COL(ista);
   const double *rpa = t->rpnma[km], *rps = t->rpnms[km];
+  double *lazy_a = NULL, *lazy_s = NULL;
+  if (t->lazy) { /* orc_setup_lazy: this wavenumber's panels are built here and dropped at the end */
+    supolf_panels(t, (const pol_t *)t->pol, km, &lazy_a, &lazy_s);
+    rpa = lazy_a, rps = lazy_s;
+  }
   /* DGEMM('N','N') restated in blocks of ORC_NB columns: each panel column is read once per block instead of
    * once per output column.  For every output element the sum still runs over j = 1..ILA in ascending
    * order, one multiply and one add at a time (no contraction), so the values are those of the
@@ -965,6 +991,7 @@ static void ltinv(const orc_trans *t, int km, int kf_uv, int kf_scalars, int kf_
     }
   }
   free(zca), free(zcs);
+  free(lazy_a), free(lazy_s);
   free(zia);
   free(zepsnm);
 #undef COL
@@ -1092,6 +1119,11 @@ static void ltdir(const orc_trans *t, int km, int kf_fs, int kf_uv, int kf_scala
   int ila = (itmax - km + 2) / 2, ils = (itmax - km + 3) / 2;
   int iskip = (km == 0) ? 2 : 1;
   const double *rpa = t->rpnma[km], *rps = t->rpnms[km];
+  double *lazy_a = NULL, *lazy_s = NULL;
+  if (t->lazy) { /* orc_setup_lazy: this wavenumber's panels are built here and dropped at the end */
+    supolf_panels(t, (const pol_t *)t->pol, km, &lazy_a, &lazy_s);
+    rpa = lazy_a, rps = lazy_s;
+  }
   /* blocks of ORC_NB columns, operands stored [latitude][column] so that the loop over the columns of a
    * block is the vector loop; every dot product still runs over the latitudes in ascending order, one
    * multiply and one add at a time -- the values of the column-by-column loops                       */
@@ -1143,6 +1175,7 @@ static void ltdir(const orc_trans *t, int km, int kf_fs, int kf_uv, int kf_scala
     }
   }
   free(zba), free(zbs);
+  free(lazy_a), free(lazy_s);
 #define COL1(j) (zoa1 + (size_t)((j)-1) * nled4)
 #define COL2(j) (zoa2 + (size_t)((j)-1) * nled4)
   if (kf_uv > 0) { /* UVTVD (uvtvd_mod.F90:91-139) */

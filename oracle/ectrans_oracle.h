@@ -33,6 +33,10 @@ typedef struct orc_trans orc_trans;
  * belusov == 0  -> LDUSERPNM=.FALSE. (benchmark + transi; SUPOLF per m, suleg_mod.F90:635-662)
  * ra: planet radius (setup_trans0.F90:129 default 6371229.0). */
 orc_trans *orc_setup(int nsmax, int ndgl, const int *nloen, int belusov, double ra);
+/* Same as orc_setup(..., belusov = 0, ...) but without stored Legendre panels: LTINV / LTDIR rebuild the panels of
+ * their wavenumber with the same SUPOLF calls each time.  Identical results; for the TCo1279 / TCo2559 parity
+ * tests, whose 6.4 / 51 GiB of panels would otherwise sit in host memory.  orc_rpnma/orc_rpnms return NULL. */
+orc_trans *orc_setup_lazy(int nsmax, int ndgl, const int *nloen, double ra);
 void orc_free(orc_trans *t);
 
 /* TRANS_INQ subset (trans_inq.F90) */

@@ -28,6 +28,8 @@ def lib():
         ip = C.POINTER(C.c_int)
         L.orc_setup.restype = C.c_void_p
         L.orc_setup.argtypes = [C.c_int, C.c_int, ip, C.c_int, C.c_double]
+        L.orc_setup_lazy.restype = C.c_void_p
+        L.orc_setup_lazy.argtypes = [C.c_int, C.c_int, ip, C.c_double]
         L.orc_free.argtypes = [C.c_void_p]
         for f in ("orc_nspec2", "orc_ngptot"):
             getattr(L, f).restype = C.c_int
@@ -62,13 +64,17 @@ class Oracle:
     Array conventions (numpy, C-contiguous): spectral (nspec2, nfld); grid (nfld, ngptot).
     """
 
-    def __init__(self, nsmax, nloen, belusov=False, ra=6371229.0):
+    def __init__(self, nsmax, nloen, belusov=False, ra=6371229.0, lazy=False):
         self.L = lib()
         nloen = np.ascontiguousarray(nloen, dtype=np.int32)
         self.nsmax, self.ndgl = int(nsmax), int(nloen.size)
         self.nloen = nloen
-        self.h = self.L.orc_setup(self.nsmax, self.ndgl, nloen.ctypes.data_as(C.POINTER(C.c_int)),
-                                  int(belusov), float(ra))
+        # lazy: no stored Legendre panels (rebuilt per wavenumber inside the transforms; same values)
+        if lazy:
+            self.h = self.L.orc_setup_lazy(self.nsmax, self.ndgl, nloen.ctypes.data_as(C.POINTER(C.c_int)), float(ra))
+        else:
+            self.h = self.L.orc_setup(self.nsmax, self.ndgl, nloen.ctypes.data_as(C.POINTER(C.c_int)),
+                                      int(belusov), float(ra))
         if not self.h:
             raise ValueError("orc_setup failed")
         self.nspec2 = self.L.orc_nspec2(self.h)

@@ -220,3 +220,120 @@ def legpol_io_case(et, Oracle, xp, tmpdir, nsmax=21, precision=8):
             assert msg in str(err), (msg, str(err))
         else:
             raise AssertionError("no error for " + msg)
+
+
+def full_size_call_mode2(et, Oracle, nsmax, nlev, nfld, precision=8, tol=1e-11, tol_norm=1e-10, chunk=16, report=None, tol_rms=None):
+    """BASELINE-size parity through linearity (the reference's benchmark checks norms at the size it times,
+    ectrans-benchmark.F90:743-756, 847-871): the call-mode-2 arrays of bench.py / ectrans-benchmark.F90:450-479
+    (vor/div x nlev, nfld x nlev 3-D scalars, one surface field => KF = 2 nlev + nfld nlev + 1) are filled with
+    c_f x base field, c_f distinct per field, on the dense seed-20251114 spectrum; the oracle transforms the
+    1 vor/div pair + 3 scalar base fields, and EVERY field of the HIP result -- every column tile, every batch --
+    is compared with c_f x the oracle's field, in both directions, plus the per-field spectral norms.
+    Errors are relative to the field maximum: the largest over all elements of all fields (`inv`, `dir`) and the
+    largest per-field root-mean-square (`inv_rms`, `dir_rms`; an indexing error would show in both, fp32 rounding at
+    N = 2559 only in the tails of the first).  Returns a dict of the observed errors."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if precision == 8 else torch.float32
+    ndt = np.float64 if precision == 8 else np.float32
+    nloen = octahedral(nsmax)
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
+    res = {}
+    try:
+        o = Oracle(nsmax, nloen, lazy=True)
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        assert (ns2, ng) == (o.nspec2, o.ngptot)
+        rng = np.random.default_rng(20251114)
+        nb = 3
+        rnd = lambda a: a.astype(ndt).astype(np.float64)  # the oracle sees exactly the library's inputs
+        V, D = rnd(random_spectrum(rng, o.nasm0, nsmax, ns2, 1, True)), rnd(random_spectrum(rng, o.nasm0, nsmax, ns2, 1, True))
+        S = rnd(random_spectrum(rng, o.nasm0, nsmax, ns2, nb, False))
+        gref = o.inv_trans(spvor=V, spdiv=D, spsc=S)  # u, v, s0, s1, s2
+        gin = rnd(gref)
+        vr, dr, sr = o.dir_trans(gin, nuv=1, nsc=nb)
+        # distinct coefficients, both signs, O(1)
+        cuv = torch.tensor([(1.0 + 0.37 * l / nlev) * (-1) ** l for l in range(nlev)], dtype=tdt, device=dev)
+        c3 = torch.tensor([[(0.5 + (v * nlev + l + 1) / (nfld * nlev)) * (-1) ** (v + l) for l in range(nlev)] for v in range(nfld)],
+                          dtype=tdt, device=dev)
+        c2 = -1.75
+        base3 = torch.tensor([[(v * nlev + l) % nb for l in range(nlev)] for v in range(nfld)], device=dev)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=ndt)).to(dev)
+        tV, tD, tS = t(V[:, 0]), t(D[:, 0]), t(S.T)  # tS: (nb, ns2)
+        spvor, spdiv = tV[:, None] * cuv[None, :], tD[:, None] * cuv[None, :]
+        spsc3a = torch.empty((nfld, ns2, nlev), dtype=tdt, device=dev)
+        for v in range(nfld):
+            spsc3a[v] = tS[base3[v]].T * c3[v][None, :]
+        spsc2 = (c2 * tS[0])[:, None].contiguous()
+        gpuv = torch.zeros((1, 2, nlev, ng), dtype=tdt, device=dev)
+        gp3a = torch.zeros((1, nfld, nlev, ng), dtype=tdt, device=dev)
+        gp2 = torch.zeros((1, 1, ng), dtype=tdt, device=dev)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()  # the library sizes its field batches from the free HBM
+        et.inv_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+        torch.cuda.synchronize()
+
+        def cmp_rows(got, coef, refs, idx):
+            """got (nf, n) [any strides], coef (nf,), refs (k, n), idx (nf,): max_f max|got_f - c_f ref_idx(f)| / max|c_f ref_idx(f)|
+            in chunks of `chunk` fields with one temporary"""
+            rmax = refs.abs().amax(dim=1)
+            worst = 0.0
+            for i in range(0, got.shape[0], chunk):
+                c, ix = coef[i:i + chunk], idx[i:i + chunk]
+                d = refs[ix]
+                d.mul_(c[:, None]).sub_(got[i:i + chunk]).abs_()
+                worst = max(worst, float((d.amax(dim=1) / (c.abs() * rmax[ix])).max()))
+                rms[0] = max(rms[0], float((d.square_().mean(dim=1).sqrt() / (c.abs() * rmax[ix])).max()))
+                del d
+            return worst
+
+        rms = [0.0]
+
+        zero = lambda n: torch.zeros(n, dtype=torch.long, device=dev)
+        tg = t(gref)  # (5, ng)
+        e_inv = max(cmp_rows(gpuv[0, 0], cuv, tg[0:1], zero(nlev)), cmp_rows(gpuv[0, 1], cuv, tg[1:2], zero(nlev)),
+                    cmp_rows(gp2[0], torch.tensor([c2], dtype=tdt, device=dev), tg[2:3], zero(1)))
+        for v in range(nfld):
+            e_inv = max(e_inv, cmp_rows(gp3a[0, v], c3[v], tg[2:], base3[v]))
+        res["inv"], res["inv_rms"] = e_inv, rms[0]
+        rms[0] = 0.0
+        # ---- direct: exact images of the oracle's grid fields in, every spectral field against c_f x oracle
+        tgi = t(gin)
+        for l0 in range(0, nlev, chunk):
+            sl = slice(l0, min(nlev, l0 + chunk))
+            gpuv[0, 0, sl] = cuv[sl, None] * tgi[0][None, :]
+            gpuv[0, 1, sl] = cuv[sl, None] * tgi[1][None, :]
+            for v in range(nfld):
+                gp3a[0, v, sl] = c3[v, sl, None] * tgi[2 + base3[v, sl]]
+        gp2[0, 0] = c2 * tgi[2]
+        for a in (spvor, spdiv, spsc3a, spsc2):
+            a.zero_()
+        del tg, tgi
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        et.dir_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+        torch.cuda.synchronize()
+        tvr, tdr, tsr = t(vr[:, 0]), t(dr[:, 0]), t(sr.T)
+        e_dir = max(cmp_rows(spvor.T, cuv, tvr[None], zero(nlev)), cmp_rows(spdiv.T, cuv, tdr[None], zero(nlev)),
+                    cmp_rows(spsc2.T, torch.tensor([c2], dtype=tdt, device=dev), tsr[0:1], zero(1)))
+        for v in range(nfld):
+            e_dir = max(e_dir, cmp_rows(spsc3a[v].T, c3[v], tsr, base3[v]))
+        res["dir"], res["dir_rms"] = e_dir, rms[0]
+        # ---- spectral norms of every field against |c_f| x the oracle's norm (north star: <= 1e-10)
+        nv, nd, nsr = o.specnorm(vr)[0], o.specnorm(dr)[0], o.specnorm(sr)
+        e_n = max(np.abs(et.specnorm(r, spvor) / (cuv.abs().cpu().numpy() * nv) - 1.0).max(),
+                  np.abs(et.specnorm(r, spdiv) / (cuv.abs().cpu().numpy() * nd) - 1.0).max(),
+                  abs(et.specnorm(r, spsc2)[0] / (abs(c2) * nsr[0]) - 1.0))
+        for v in range(nfld):
+            want = c3[v].abs().cpu().numpy() * nsr[base3[v].cpu().numpy()]
+            e_n = max(e_n, np.abs(et.specnorm(r, spsc3a[v]) / want - 1.0).max())
+        res["norm"] = float(e_n)
+        # the reference benchmark's own criterion on the dense case: |norm(x0) / norm(dir(inv(x0))) - 1| -- here x0 and
+        # the direct transform of the oracle's inverse; on octahedral grids this carries the grid's truncation error
+        res["spectral_norm_rel_error"] = float(abs(o.specnorm(S[:, :1])[0] / nsr[0] - 1.0))
+        if report is not None:
+            report.update(res)
+        assert res["inv"] < tol and res["dir"] < tol and res["norm"] < tol_norm, res
+        assert tol_rms is None or (res["inv_rms"] < tol_rms and res["dir_rms"] < tol_rms), res
+        return res
+    finally:
+        et.trans_release(r)

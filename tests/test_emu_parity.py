@@ -285,3 +285,51 @@ def test_argument_errors_mirror_abort_trans(et):
     et.trans_release(r)
     with pytest.raises(et.TransError, match="unknown resolution"):
         et.trans_inq(r, "nspec2")
+
+
+def test_array_extent_checks_mirror_abort_trans(et):
+    """The extent checks of inv_trans.F90:476-600 / dir_trans.F90:370-491 on the shapes the caller really passes
+    (emi_extents_t): before this the library derived the middle extents from the flags and a PGPUV with too few
+    variables or a PGP2 of the wrong width was overrun silently."""
+    N = 8
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+    z = np.zeros
+    uv = dict(pspvor=z((ns2, 2)), pspdiv=z((ns2, 2)))
+    try:
+        with pytest.raises(et.TransError, match="THIRD DIMENSION OF PGPUV TOO SMALL"):  # LDVORGP needs 4 variables
+            et.inv_trans(r, pgpuv=z((1, 2, 2, ng)), ldvorgp=True, **uv)
+        with pytest.raises(et.TransError, match="SEC. DIMENSION OF PGPUV INCONSISTENT"):
+            et.inv_trans(r, pgpuv=z((1, 2, 3, ng)), **uv)
+        with pytest.raises(et.TransError, match="FOURTH DIMENSION OF PGPUV TOO SMALL"):
+            et.inv_trans(r, pgpuv=z((1, 2, 2, 100)), kproma=100, **uv)
+        with pytest.raises(et.TransError, match="FIRST DIMENSION OF PGPUV TOO SMALL"):
+            et.inv_trans(r, pgpuv=z((1, 2, 2, ng - 1)), **uv)
+        with pytest.raises(et.TransError, match="SEC. DIMENSION OF PGP2 INCONSISTENT"):  # LDSCDERS triples IF_SC2_G
+            et.inv_trans(r, pspsc2=z((ns2, 2)), pgp2=z((1, 2, ng)), ldscders=True)
+        with pytest.raises(et.TransError, match="THIRD DIMENSION OF PGP3A INCONSISTENT"):
+            et.inv_trans(r, pspsc3a=z((2, ns2, 3)), pgp3a=z((1, 3, 3, ng)))
+        with pytest.raises(et.TransError, match="SEC. DIMENSION OF PGP3A INCONSISTENT"):
+            et.inv_trans(r, pspsc3a=z((2, ns2, 3)), pgp3a=z((1, 2, 4, ng)))
+        with pytest.raises(et.TransError, match="SPECTRAL ARRAY TOO SMALL|nspec2"):
+            et.inv_trans(r, pspscalar=z((ns2 - 2, 1)), pgp=z((1, 1, ng)))
+        with pytest.raises(et.TransError, match="DIR_TRANS:SEC. DIMENSION OF PGPUV INCONSISTENT"):
+            et.dir_trans(r, pgpuv=z((1, 2, 3, ng)), **uv)
+        with pytest.raises(et.TransError, match="DIR_TRANS:THIRD DIMENSION OF PGP TOO SMALL"):
+            et.dir_trans(r, pspscalar=z((ns2, 1)), pgp=z((1, 1, 50)), kproma=50)
+        # a PGPUV with MORE variables than the call produces is legal (inv_trans.F90:497: only '<' aborts) and is
+        # addressed with its real extent: u, v land in variables 0, 1 of every block, the rest stays untouched
+        o = Oracle(N, nloen)
+        rng = np.random.default_rng(3)
+        from tests.common import random_spectrum, rel_err
+        vor, div = (random_spectrum(rng, o.nasm0, N, ns2, 2, True) for _ in range(2))
+        npr = 100
+        nb = (ng - 1) // npr + 1
+        gpuv = np.full((nb, 4, 2, npr), -3.5)
+        et.inv_trans(r, pspvor=vor, pspdiv=div, pgpuv=gpuv, kproma=npr)
+        gref = o.inv_trans(spvor=vor, spdiv=div)
+        got = np.concatenate([gpuv[b, :2].reshape(4, npr) for b in range(nb)], axis=1)[:, :ng]
+        assert rel_err(got, gref, axis=1) < TOL and np.all(gpuv[:, 2:] == -3.5)
+    finally:
+        et.trans_release(r)

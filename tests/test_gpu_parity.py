@@ -423,3 +423,40 @@ def test_alltoallv_hook_over_rccl_single_rank(dev):
     side.synchronize()
     assert rc == 0 and float(out.min()) == 40.0 and float(out.max()) == 40.0
     dist.destroy_process_group()
+
+
+def test_calls_on_different_streams_are_serialised(et, dev):
+    """Calls on one resolution share its descriptor and work buffers whatever stream each names: the library
+    orders every call behind the previous one of that resolution (a device-side event wait), and SPECNORM,
+    which has no stream argument, behind the last transform.  Two alternating non-blocking streams, no host
+    synchronisation in between, against the same calls run one by one."""
+    import torch
+    N = 399
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        nasm0 = et.trans_inq(r, "nasm0")
+        rng = np.random.default_rng(17)
+        nf = 96
+        to, back = dev
+        a, b = (to(random_spectrum(rng, nasm0, N, ns2, nf, False)) for _ in range(2))
+        ga, gb, ga0, gb0 = (torch.zeros((1, nf, ng), dtype=torch.float64, device="cuda:0") for _ in range(4))
+        sa, sb = torch.zeros_like(a), torch.zeros_like(b)
+        et.inv_trans(r, pspscalar=a, pgp=ga0)
+        torch.cuda.synchronize()
+        et.inv_trans(r, pspscalar=b, pgp=gb0)
+        torch.cuda.synchronize()
+        n0 = et.specnorm(r, a)
+        s1, s2 = torch.cuda.Stream(device="cuda:0"), torch.cuda.Stream(device="cuda:0")
+        torch.cuda.synchronize()
+        for _ in range(3):
+            et.inv_trans(r, pspscalar=a, pgp=ga, stream=s1.cuda_stream)
+            et.inv_trans(r, pspscalar=b, pgp=gb, stream=s2.cuda_stream)
+        et.dir_trans(r, pspscalar=sa, pgp=ga, stream=s1.cuda_stream)
+        n1 = et.specnorm(r, sa)  # null stream, right behind the direct transform on s1
+        torch.cuda.synchronize()
+        assert torch.equal(ga, ga0) and torch.equal(gb, gb0)
+        assert np.abs(n1 / n0 - 1.0).max() < 1e-10
+    finally:
+        et.trans_release(r)
