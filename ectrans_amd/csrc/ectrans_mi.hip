@@ -1031,6 +1031,8 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   g.nump = NU;
   g.nlat = NL;
   g.ngptot = P.ngptot;
+  // EMI_F32_M0_SINGLE=1: the fp32 library treats m = 0 like every other wavenumber (A/B against the reference's rule)
+  g.m0_wide = (P.esz == 4 && !(getenv("EMI_F32_M0_SINGLE") && atoi(getenv("EMI_F32_M0_SINGLE")))) ? 1 : 0;
   g.mval = d_mval;
   g.nmen = d_nmen;
   g.gpoff = d_gpoff;

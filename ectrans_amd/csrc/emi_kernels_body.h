@@ -178,31 +178,47 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
 //   the two k-rows a half-wave reads with one ds_read_b64 on disjoint bank halves.
 // ==========================================================================================
 
+// Accumulator of a Legendre tile.  WIDE = false: the library precision (v_mfma_f64_16x16x4_f64 in the fp64 library,
+// v_mfma_f32_16x16x4_f32 in the fp32 one).  WIDE = true (fp32 library, zonal wavenumber 0 only): the float operands
+// are promoted and the products accumulated in double on the fp64 matrix cores, one rounding to float in the
+// epilogue -- the reference's single-precision library computes the mean wavenumber this way ("DGEM for the mean to
+// improve mass conservation", cpu/internal/ledir_mod.F90:133-171; its GPU back-end also in the inverse transform,
+// gpu/internal/leinv_mod.F90:273).  The two instructions share the A / B lane maps; the accumulator rows differ.
+template <bool WIDE>
+struct LegAcc {
+  typedef acc4 type;
+  static EMI_DEVFN type mma(real_t a, real_t b, type c) { return emi_mfma_f64_16x16x4(a, b, c); }
+  static EMI_DEVFN int row(int l, int i) { return EMI_ACC_ROW(l, i); }
+};
+template <>
+struct LegAcc<true> {
+  typedef v4d type;
+  static EMI_DEVFN type mma(real_t a, real_t b, type c) { return emi_mfma_f64((double)a, (double)b, c); }
+  static EMI_DEVFN int row(int l, int i) { return (l >> 4) + 4 * i; }
+};
+
 // ---- inverse: FB[lat][m][col] = sum_n P[lat,n] W[m][n][col]; north = S+A, south = S-A
 // (leinv_mod.F90:92-186 DGEMM('N','N') x2, asre1b_mod.F90:83-102)
 // tile: 64 latitudes x 128 columns, both parities; wave (wm, wn) owns 32 lat x 64 col.
-EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const real_t *W, int ldw, real_t *FB, int ldf) {
+template <bool WIDE>
+EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, const int ct, const real_t *W, int ldw, real_t *FB, int ldf) {
+  typedef typename LegAcc<WIDE>::type acc_t;
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
   real_t *Bs = As + 2 * 8 * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int wm = w & 1, wn = w >> 1;
-  // host-built tile map (leg_tilemap): block -> (local wavenumber, latitude tile, column tile),
-  // 2-D blocked per XCD for L2 reuse; padding entries have x < 0
-  const int2 tm = tilemap[EMI_BID];
-  if (tm.x < 0) return;
-  const int m = tm.x, lt = tm.y >> 16, ct = tm.y & 0xffff;
   const int ld = g.ldp[m];
   const int lat0 = lt * 64, col0 = ct * LG_BN;
   const int nst = g.wrows[m] >> 4;
 
-  acc4 acc[2][2][4];
+  acc_t acc[2][2][4];
 #pragma unroll
   for (int p = 0; p < 2; p++)
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[p][i][j] = (acc4){0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < 4; j++) acc[p][i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
 
   // global -> register prefetch pointers (advance by one stage per iteration)
   const int arow = tid >> 5, ac2 = tid & 31;
@@ -254,7 +270,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-          for (int j = 0; j < 4; j++) acc[p][i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[p][i][j]);
+          for (int j = 0; j < 4; j++) acc[p][i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[p][i][j]);
       }
     EMI_PRIO_LO();
   }
@@ -264,18 +280,32 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      int j = lat0 + wm * 32 + i * 16 + EMI_ACC_ROW(l, q);
+      int j = lat0 + wm * 32 + i * 16 + LegAcc<WIDE>::row(l, q);
       if (j < ndglu) {
         real_t *pn = FB + (long long)g.legN[lb + j] * ldf + col0 + wn * 64 + (l & 15);
         real_t *ps = FB + (long long)g.legS[lb + j] * ldf + col0 + wn * 64 + (l & 15);
 #pragma unroll
         for (int jn = 0; jn < 4; jn++) {
-          real_t sv = acc[0][i][jn][q], av = acc[1][i][jn][q];
-          pn[jn * 16] = sv + av;
-          ps[jn * 16] = sv - av;
+          const auto sv = acc[0][i][jn][q], av = acc[1][i][jn][q];  // WIDE: the sum and difference in double too
+          pn[jn * 16] = (real_t)(sv + av);
+          ps[jn * 16] = (real_t)(sv - av);
         }
       }
     }
+}
+EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const real_t *W, int ldw, real_t *FB, int ldf) {
+  // host-built tile map (leg_tilemap): block -> (local wavenumber, latitude tile, column tile),
+  // 2-D blocked per XCD for L2 reuse; padding entries have x < 0
+  const int2 tm = tilemap[EMI_BID];
+  if (tm.x < 0) return;
+  const int m = tm.x, lt = tm.y >> 16, ct = tm.y & 0xffff;
+  if constexpr (sizeof(real_t) == 4) {
+    if (g.m0_wide && g.mval[m] == 0) {  // uniform over the workgroup
+      leg_inv_tile<true>(g, m, lt, ct, W, ldw, FB, ldf);
+      return;
+    }
+  }
+  leg_inv_tile<false>(g, m, lt, ct, W, ldw, FB, ldf);
 }
 
 // ---- direct: W[m][n][col] = sum_lat P[lat,n] * (FB_north +- FB_south)[lat][col]
@@ -284,9 +314,10 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 // tile: 64 k (n-pairs) x 2 parities x 128 columns; wave (par, wn) owns 64 k x 64 col.
 // FULL: all four 16-row groups of the tile are live (nine tiles in ten): the stage loop is then one
 // straight-line block, which lets the compiler interleave the LDS fragment reads with the MFMAs.
-template <bool FULL>
+template <bool FULL, bool WIDE>
 EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, const int ct, const int ni, const real_t *FB, const int zrow, int ldf,
                             real_t *W, int ldw, const FuseDst *fd) {
+  typedef typename LegAcc<WIDE>::type acc_t;
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
   real_t *Bs = As + 2 * 16 * LG_LDA;
@@ -298,11 +329,11 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   const int nst = (ndglu + 15) >> 4;  // stages of 16 latitudes: 32 MFMAs per wave between barriers
   const long long wb = g.wbase[m];
 
-  acc4 acc[4][4];
+  acc_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (acc4){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; j++) acc[i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
 
   // P^T tile: 16 latitudes x 64 k per parity, k contiguous in HBM (coalesced 512-B rows) and in LDS
   const int arow = tid >> 5, ac2 = tid & 31;  // latitude rows arow and arow+8 of the stage
@@ -392,7 +423,7 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
       for (int i = 0; i < 4; i++)
         if (FULL || i < ni) {  // the last k tile of a wavenumber: 16-row groups past the end are skipped
 #pragma unroll
-          for (int j = 0; j < 4; j++) acc[i][j] = emi_mfma_f64_16x16x4(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < 4; j++) acc[i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[i][j]);
         }
     }
     EMI_PRIO_LO();
@@ -425,16 +456,16 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      int k = k0 + i * 16 + EMI_ACC_ROW(l, q);
+      int k = k0 + i * 16 + LegAcc<WIDE>::row(l, q);
       if (k < nkpad) {
         const int r = 2 * k + par;
         real_t *pw = W + (wb + r) * ldw + col0 + wn * 64 + (l & 15);
 #pragma unroll
         for (int jn = 0; jn < 4; jn++) {
           if (ud[jn]) {
-            if (r <= rmax) ud[jn][(long long)r * us[jn]] = zero_im ? (real_t)0.0 : acc[i][jn][q];
+            if (r <= rmax) ud[jn][(long long)r * us[jn]] = zero_im ? (real_t)0.0 : (real_t)acc[i][jn][q];
           } else {
-            pw[jn * 16] = acc[i][jn][q];
+            pw[jn * 16] = (real_t)acc[i][jn][q];
           }
         }
       }
@@ -446,10 +477,16 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
   if (tm.x < 0) return;
   const int m = tm.x, kt = tm.y >> 16, ct = tm.y & 0xffff;
   const int left = ((g.wrows[m] >> 1) - kt * 64 + 15) >> 4;  // live 16-row groups of this tile
+  if constexpr (sizeof(real_t) == 4) {
+    if (g.m0_wide && g.mval[m] == 0) {  // fp32 library: the mean wavenumber in double (LegAcc)
+      leg_dir_tile<false, true>(g, m, kt, ct, left < 4 ? left : 4, FB, zrow, ldf, W, ldw, fd);
+      return;
+    }
+  }
   if (left >= 4)
-    leg_dir_tile<true>(g, m, kt, ct, 4, FB, zrow, ldf, W, ldw, fd);
+    leg_dir_tile<true, false>(g, m, kt, ct, 4, FB, zrow, ldf, W, ldw, fd);
   else
-    leg_dir_tile<false>(g, m, kt, ct, left, FB, zrow, ldf, W, ldw, fd);
+    leg_dir_tile<false, false>(g, m, kt, ct, left, FB, zrow, ldf, W, ldw, fd);
 }
 
 // ==========================================================================================

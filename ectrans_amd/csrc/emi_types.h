@@ -11,6 +11,7 @@ struct EmiGeomDev {
   // tasks each task owns the wavenumbers of its W-set (suwavedi_mod.F90:118-137) and a contiguous
   // latitude band.
   int nsmax, nump, nlat, ngptot;
+  int m0_wide;  // fp32 library: Legendre transforms of zonal wavenumber 0 accumulate in double (ledir_mod.F90:133-171)
   const int *mval;    // [nump] actual zonal wavenumber
   const int *nmen, *gpoff;  // [nlat]
   const int *nasm0;   // [nump] 0-based index of Re(m, n=m) in the (local) user spectral dimension

@@ -40,6 +40,7 @@ struct orc_trans {
   double *rlapin;                    /* [-1..nsmax+2] stored with +1 shift */
   double **rpnma, **rpnms;           /* per m, column-major (idglu x ila|ils) */
   int lazy;                          /* panels are rebuilt per wavenumber inside LTINV / LTDIR (orc_setup_lazy) */
+  int sp_mode;                       /* LEDIR as libtrans_sp computes it (orc_set_sp_mode) */
   void *pol;                         /* pol_t of INI_POL, kept for the lazy mode */
 };
 
@@ -764,6 +765,8 @@ orc_trans *orc_setup_lazy(int nsmax, int ndgl, const int *nloen_in, double ra) {
   return orc_setup_impl(nsmax, ndgl, nloen_in, 0, ra, 1);
 }
 
+void orc_set_sp_mode(orc_trans *t, int on) { t->sp_mode = on; }
+
 void orc_free(orc_trans *t) {
   if (!t) return;
   if (t->pol) {
@@ -1146,11 +1149,48 @@ static void ltdir(const orc_trans *t, int km, int kf_fs, int kf_uv, int kf_scala
           paia *= zacthe;
           psia *= zacthe;
         }
+        if (t->sp_mode) { /* float storage and float arithmetic of PRFI2B / LDFOU2 / ZB = PAIA * PW */
+          const float ffn = (float)fn, ffs = (float)fs, fw = (float)t->rw[jgl - 1];
+          float fps = ffn + ffs, fpa = ffn - ffs;
+          if (jk <= 4 * kf_uv) fpa *= (float)t->racthe[jgl - 1], fps *= (float)t->racthe[jgl - 1];
+          zba[(size_t)(j - 1) * ORC_NB + c] = (double)(fpa * fw);
+          zbs[(size_t)(j - 1) * ORC_NB + c] = (double)(fps * fw);
+          continue;
+        }
         zba[(size_t)(j - 1) * ORC_NB + c] = paia * t->rw[jgl - 1];
         zbs[(size_t)(j - 1) * ORC_NB + c] = psia * t->rw[jgl - 1];
       }
     }
     /* LEDIR GEMM('T','N') (ledir_mod.F90:130,204) + scatter (ledir_mod.F90:181-187,255-261) */
+    if (t->sp_mode) {
+      /* the single-precision library (JPRB = JPRM): operands are stored in float -- the Fourier coefficients, ZB =
+       * PAIA * PW (ledir_mod.F90:118-124, a float product) and the Legendre matrices -- and the GEMM is SGEMM, except
+       * for the mean wavenumber m = 0: "DGEM for the mean to improve mass conservation" (ledir_mod.F90:133-171):
+       * operands promoted to double, DGEMM, result rounded to float.  The float sums run in the restated GEMM's
+       * order (one multiply, one add at a time); the double ones need no order to be right to a float ulp.      */
+      for (int par = 0; par < 2; par++) {
+        const int il = par ? ils : ila, i0 = par ? is : ia;
+        const double *rp = par ? rps : rpa, *zb0 = par ? zbs : zba;
+        for (int j = 1; j <= il; j++) {
+          const double *row = rp + (size_t)(j - 1) * idglu;
+          for (int c = 0; c < nb; c++) {
+            const int jk = 1 + (c0 + c) * iskip;
+            float out;
+            if (km == 0) {
+              double acc = 0.0;
+              for (int k = 0; k < idglu; k++) acc += (double)(float)row[k] * (double)(float)zb0[(size_t)k * ORC_NB + c];
+              out = (float)acc;
+            } else {
+              float acc = 0.0f;
+              for (int k = 0; k < idglu; k++) acc += (float)row[k] * (float)zb0[(size_t)k * ORC_NB + c];
+              out = acc;
+            }
+            A2(zoa1, nled4, i0 + (j - 1) * 2, jk) = (double)out;
+          }
+        }
+      }
+      continue;
+    }
     for (int j = 1; j <= ila; j++) {
       double sv[ORC_NB];
       const double *row = rpa + (size_t)(j - 1) * idglu;

@@ -37,6 +37,11 @@ orc_trans *orc_setup(int nsmax, int ndgl, const int *nloen, int belusov, double 
  * their wavenumber with the same SUPOLF calls each time.  Identical results; for the TCo1279 / TCo2559 parity
  * tests, whose 6.4 / 51 GiB of panels would otherwise sit in host memory.  orc_rpnma/orc_rpnms return NULL. */
 orc_trans *orc_setup_lazy(int nsmax, int ndgl, const int *nloen, double ra);
+/* on != 0: orc_dir_trans computes LEDIR the way the reference's SINGLE-precision library does (ledir_mod.F90:118-171):
+ * float operands, SGEMM for m >= 1, and for m = 0 "DGEM for the mean to improve mass conservation" -- operands
+ * promoted to double, DGEMM, one rounding to float.  Everything else (FFT, UVTVD, setup) stays double: the mode
+ * exists to pin the m = 0 behaviour of the fp32 product library, not to emulate libtrans_sp bit for bit. */
+void orc_set_sp_mode(orc_trans *t, int on);
 void orc_free(orc_trans *t);
 
 /* TRANS_INQ subset (trans_inq.F90) */

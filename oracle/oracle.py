@@ -30,6 +30,7 @@ def lib():
         L.orc_setup.argtypes = [C.c_int, C.c_int, ip, C.c_int, C.c_double]
         L.orc_setup_lazy.restype = C.c_void_p
         L.orc_setup_lazy.argtypes = [C.c_int, C.c_int, ip, C.c_double]
+        L.orc_set_sp_mode.argtypes = [C.c_void_p, C.c_int]
         L.orc_free.argtypes = [C.c_void_p]
         for f in ("orc_nspec2", "orc_ngptot"):
             getattr(L, f).restype = C.c_int
@@ -140,6 +141,10 @@ class Oracle:
         sc = np.zeros((self.nspec2, nsc)) if nsc else None
         self.L.orc_dir_trans(self.h, nuv, nsc, _dp(gp), _dp(vor), _dp(div), _dp(sc))
         return vor, div, sc
+
+    def set_sp_mode(self, on=True):
+        """dir_trans computes LEDIR as libtrans_sp does: float operands, SGEMM, m = 0 in double (ledir_mod.F90:133-171)"""
+        self.L.orc_set_sp_mode(self.h, int(on))
 
     def specnorm(self, sp):
         sp = np.ascontiguousarray(sp, dtype=np.float64)

@@ -333,3 +333,30 @@ def test_array_extent_checks_mirror_abort_trans(et):
         assert rel_err(got, gref, axis=1) < TOL and np.all(gpuv[:, 2:] == -3.5)
     finally:
         et.trans_release(r)
+
+
+def test_fp32_library_mean_wavenumber_in_double(et):
+    """The reference's single-precision library computes the Legendre transform of zonal wavenumber 0 in double ("DGEM for
+    the mean to improve mass conservation", ledir_mod.F90:133-171).  The fp32 library does the same on the fp64 matrix
+    cores (LegAcc<true>); against the oracle's sp mode (float operands, double accumulation for m = 0) the m = 0 column
+    agrees to half a float ulp of its maximum and the global mean (0, 0) to one ulp."""
+    N = 21
+    nloen = octahedral(N)
+    o = Oracle(N, nloen)
+    rng = np.random.default_rng(1)
+    from tests.common import random_spectrum
+    s = random_spectrum(rng, o.nasm0, N, o.nspec2, 3, False)
+    s[0, :] = 250.0  # a 250 K-like field
+    g = o.inv_trans(spsc=s).astype(np.float32)
+    r = et.setup_trans(N, len(nloen), nloen, precision=4)
+    try:
+        out = np.zeros((o.nspec2, 3), dtype=np.float32)
+        et.dir_trans(r, pspscalar=out, pgp=g.reshape(1, 3, -1).copy())
+        o.set_sp_mode(True)
+        _, _, ref = o.dir_trans(g.astype(np.float64), nsc=3)
+        m0 = slice(0, 2 * (N + 1), 2)
+        ulp = float(np.finfo(np.float32).eps)
+        assert np.abs(out[m0] - ref[m0]).max() <= 0.5 * ulp * np.abs(ref[m0]).max()
+        assert np.abs(out[0] / ref[0] - 1.0).max() <= ulp
+    finally:
+        et.trans_release(r)

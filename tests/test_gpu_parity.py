@@ -460,3 +460,42 @@ def test_calls_on_different_streams_are_serialised(et, dev):
         assert np.abs(n1 / n0 - 1.0).max() < 1e-10
     finally:
         et.trans_release(r)
+
+
+def test_fp32_library_mean_wavenumber_in_double(et, dev, monkeypatch):
+    """fp32 library, zonal wavenumber 0 on the fp64 matrix cores with promoted operands (the reference's sp build:
+    "DGEM for the mean to improve mass conservation", cpu/internal/ledir_mod.F90:133-171): the global mean -- coefficient
+    (0, 0) -- of TCo399 fields with a 250 K mean matches the oracle's sp mode (float operands, double accumulation for
+    m = 0) to one float ulp and the whole m = 0 column to one ulp of its maximum; with EMI_F32_M0_SINGLE=1 (m = 0 like
+    every other wavenumber: 400 float additions) the mean is visibly worse."""
+    to, back = dev
+    N = 399
+    nloen = octahedral(N)
+    o = Oracle(N, nloen, lazy=True)
+    rng = np.random.default_rng(2)
+    nf = 4
+    s = random_spectrum(rng, o.nasm0, N, o.nspec2, nf, False)
+    s[0, :] = 250.0 + np.arange(nf)
+    g = o.inv_trans(spsc=s).astype(np.float32)
+    o.set_sp_mode(True)
+    _, _, ref = o.dir_trans(g.astype(np.float64), nsc=nf)
+    ulp = float(np.finfo(np.float32).eps)
+    m0 = slice(0, 2 * (N + 1), 2)
+    err = {}
+    for single in (False, True):
+        if single:
+            monkeypatch.setenv("EMI_F32_M0_SINGLE", "1")
+        r = et.setup_trans(N, len(nloen), nloen, precision=4)
+        try:
+            out = to(np.zeros((o.nspec2, nf), dtype=np.float32))
+            et.dir_trans(r, pspscalar=out, pgp=to(g.reshape(1, nf, -1)))
+            got = back(out).astype(np.float64)
+            err[single] = (np.abs(got[0] / ref[0] - 1.0).max() / ulp, np.abs(got[m0] - ref[m0]).max() / np.abs(ref[m0]).max() / ulp)
+            if not single:  # the inverse transform of m = 0 runs in double too (as the reference's GPU back-end, leinv_mod.F90:273)
+                gp = to(np.zeros((1, nf, o.ngptot), dtype=np.float32))
+                et.inv_trans(r, pspscalar=to(s.astype(np.float32)), pgp=gp)
+                assert rel_err(back(gp)[0].astype(np.float64), o.inv_trans(spsc=s.astype(np.float32).astype(np.float64)), axis=1) < 3e-5
+        finally:
+            et.trans_release(r)
+    assert err[False][0] <= 1.0 and err[False][1] <= 1.0, err
+    assert err[True][0] > err[False][0], err
