@@ -85,6 +85,19 @@ def build(force=False):
     return _LIBPATH
 
 
+def source_hash():
+    """First 16 hex digits of the SHA-256 over the library sources (csrc/* and the C-ABI header): profiles/*_pmc_traffic.json
+    is stamped with it, and bench.py quotes a counter file only for the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "ectrans_mi.h"))
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _bind(L):
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
     L.emi_init.argtypes = [C.POINTER(_Init)]
@@ -109,6 +122,7 @@ def _bind(L):
     L.emi_set_alltoallv.argtypes = [C.c_void_p, C.c_void_p]
     L.emi_set_profile.argtypes = [C.c_int]
     L.emi_last_phase_launches.argtypes = [ip]
+    L.emi_crc64.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
     return L
 
 

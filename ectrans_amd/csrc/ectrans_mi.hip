@@ -2355,6 +2355,26 @@ extern "C" int emi_set_max_batch(int max_fields) {
   return EMI_SUCCESS;
 }
 
+// CRC-64/ECMA-182, table driven (ectrans-benchmark.F90:1455-1600 calls fiat's crc64, un-vendored)
+extern "C" int emi_crc64(const void *data, size_t bytes, unsigned long long *crc) {
+  if ((!data && bytes) || !crc) EMI_FAIL(EMI_ERR_ARG, "emi_crc64: null argument");
+  static unsigned long long tab[256];
+  static bool init = false;
+  if (!init) {
+    for (int i = 0; i < 256; i++) {
+      unsigned long long c = (unsigned long long)i << 56;
+      for (int k = 0; k < 8; k++) c = (c & 0x8000000000000000ULL) ? (c << 1) ^ 0x42F0E1EBA9EA3693ULL : (c << 1);
+      tab[i] = c;
+    }
+    init = true;
+  }
+  unsigned long long c = *crc;
+  const unsigned char *p = (const unsigned char *)data;
+  for (size_t i = 0; i < bytes; i++) c = tab[((c >> 56) ^ p[i]) & 0xff] ^ (c << 8);
+  *crc = c;
+  return EMI_SUCCESS;
+}
+
 extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *args) { return inv_trans_impl(kresol, args, false); }
 extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *args) { return dir_trans_impl(kresol, args, false); }
 

@@ -216,6 +216,14 @@ int emi_set_profile(int on);
 /* Upper bound on Fourier-space fields per batch (0: from free HBM).                         */
 int emi_set_max_batch(int max_fields);
 
+/* ---- checksum dumps of the benchmark harness (src/programs/ectrans-benchmark.F90:1455-1600) ----------
+ * CRC-64 of `bytes` bytes continued from *crc (the harness carries one value through the fields of an array).
+ * The reference calls fiat's `crc64`, which is not vendored under /root/reference; this is CRC-64/ECMA-182
+ * (polynomial 0x42F0E1EBA9EA3693, no reflection, no final xor).  What the reference's test checks is that the
+ * dump of one decomposition is byte-identical to the dump of another (tests/compare_checksums.py:11-60), which
+ * holds for any CRC; host memory only.                                                                    */
+int emi_crc64(const void *data, size_t bytes, unsigned long long *crc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,10 @@ def main():
     fd, wd, out = sys.argv[1:4]
     label = sys.argv[5] if len(sys.argv) > 5 and sys.argv[4] == "--label" else ""
     rd, wr = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
-    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) " + label,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import ectrans_amd
+    res = {"source_hash": ectrans_amd.source_hash(),  # bench.py quotes this file only for the build it was taken on
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) " + label,
            "corrections": "KiB -> bytes; read bytes = 2 x FETCH_SIZE (gfx950, 16 B/lane loads); WRITE_SIZE exact; "
                           "Infinity-Cache hits included (upper bound of HBM bytes)",
            "kernels": {}}
