@@ -337,3 +337,60 @@ def full_size_call_mode2(et, Oracle, nsmax, nlev, nfld, precision=8, tol=1e-11, 
         return res
     finally:
         et.trans_release(r)
+
+
+def adjoint_matrix_case(et, Oracle, xp, nsmax=10, seed=3, precision=8):
+    """INV_TRANSAD / DIR_TRANSAD against an ORACLE adjoint (the dot-product test above only shows that the HIP forward
+    and adjoint are a pair).  The dense matrices of the oracle's forward transforms are formed column by column on a tiny
+    grid -- A: (vor, div, scalar) -> (u, v, scalar) for INV_TRANS, B: (u, v, scalar) -> (vor, div, scalar) for DIR_TRANS --
+    and transposed with the inner products of the reference's adjoint tests (test_invtrans_adjoint.F90:243-315: plain
+    sum over grid points; SPECNORM weights w in spectral space):  A* = W^+ A^T,  B* = B^T W.  Returns the two errors
+    relative to the largest element."""
+    to0, back0 = xp
+    dt = np.float32 if precision == 4 else np.float64
+    to = lambda a: to0(np.ascontiguousarray(a, dtype=dt))
+    back = lambda a: np.asarray(back0(a), dtype=np.float64)
+    nloen = octahedral(nsmax)
+    o = Oracle(nsmax, nloen)
+    ns2, ng = o.nspec2, o.ngptot
+    w = spec_weights(o.nasm0, nsmax, ns2)
+    winv = np.where(w > 0, 1.0 / np.maximum(w, 1e-300), 0.0)
+    eye_s, z_s = np.eye(ns2), np.zeros((ns2, ns2))
+    # A: columns = (vor basis | div basis | scalar basis); rows = (u | v | scalar) grid points
+    g = o.inv_trans(spvor=np.concatenate([eye_s, z_s], axis=1), spdiv=np.concatenate([z_s, eye_s], axis=1), spsc=eye_s)
+    nuv = 2 * ns2  # oracle grid field order: u(nuv) v(nuv) scalars(ns2)
+    A = np.zeros((3 * ng, 3 * ns2))
+    A[0:ng, 0:2 * ns2] = g[0:nuv].T          # u from (vor | div)
+    A[ng:2 * ng, 0:2 * ns2] = g[nuv:2 * nuv].T  # v
+    A[2 * ng:, 2 * ns2:] = g[2 * nuv:].T     # scalar
+    # B: columns = (u basis | v basis | scalar basis) grid; rows = (vor | div | scalar) spectral
+    eye_g, z_g = np.eye(ng), np.zeros((ng, ng))
+    gp = np.concatenate([np.concatenate([eye_g, z_g]), np.concatenate([z_g, eye_g]), eye_g])  # u(2ng) v(2ng) scalars(ng)
+    vr, dr, sr = o.dir_trans(gp, nuv=2 * ng, nsc=ng)
+    B = np.zeros((3 * ns2, 3 * ng))
+    B[0:ns2, 0:2 * ng] = vr
+    B[ns2:2 * ns2, 0:2 * ng] = dr
+    B[2 * ns2:, 2 * ng:] = sr
+    W3, Winv3 = np.tile(w, 3), np.tile(winv, 3)
+    rng = np.random.default_rng(seed)
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
+    try:
+        nf = 2  # two independent right-hand sides per field kind
+        # ---- INV_TRANSAD: y on the grid (u, v, scalar) -> (vor, div, scalar) = W^+ A^T y
+        y = rng.uniform(-1, 1, (3, nf, ng))
+        want = Winv3[:, None] * (A.T @ y.transpose(0, 2, 1).reshape(3 * ng, nf))
+        pgp = to(np.concatenate([y[0], y[1], y[2]])[None])  # PGP fields: u(nf) v(nf) scalars(nf)
+        v, d, s = (to(np.zeros((ns2, nf))) for _ in range(3))
+        et.inv_transad(r, pspvor=v, pspdiv=d, pspscalar=s, pgp=pgp)
+        got = np.concatenate([back(v), back(d), back(s)])
+        e_inv = np.abs(got - want).max() / np.abs(want).max()
+        # ---- DIR_TRANSAD: y in spectral space (vor, div, scalar) -> grid (u, v, scalar) = B^T W y
+        ys = rng.uniform(-1, 1, (3, ns2, nf))
+        want = B.T @ (W3[:, None] * ys.reshape(3 * ns2, nf))
+        gout = to(np.zeros((1, 3 * nf, ng)))
+        et.dir_transad(r, pspvor=to(ys[0]), pspdiv=to(ys[1]), pspscalar=to(ys[2]), pgp=gout)
+        got = back(gout)[0].reshape(3, nf, ng).transpose(0, 2, 1).reshape(3 * ng, nf)
+        e_dir = np.abs(got - want).max() / np.abs(want).max()
+        return e_inv, e_dir
+    finally:
+        et.trans_release(r)

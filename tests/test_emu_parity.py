@@ -360,3 +360,11 @@ def test_fp32_library_mean_wavenumber_in_double(et):
         assert np.abs(out[0] / ref[0] - 1.0).max() <= ulp
     finally:
         et.trans_release(r)
+
+
+def test_adjoints_match_transposed_oracle_matrices(et):
+    """INV_TRANSAD / DIR_TRANSAD against the explicit weighted transposes of the ORACLE's forward operators at T8/O9
+    (tests/common.py::adjoint_matrix_case) -- an adjoint oracle that does not involve the HIP forward transform."""
+    from tests.common import adjoint_matrix_case
+    e_inv, e_dir = adjoint_matrix_case(et, Oracle, XP, nsmax=8)
+    assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)

@@ -499,3 +499,15 @@ def test_fp32_library_mean_wavenumber_in_double(et, dev, monkeypatch):
             et.trans_release(r)
     assert err[False][0] <= 1.0 and err[False][1] <= 1.0, err
     assert err[True][0] > err[False][0], err
+
+
+@pytest.mark.parametrize("nsmax,precision", [(10, 8), (21, 8), (10, 4)])
+def test_adjoints_match_transposed_oracle_matrices(et, dev, nsmax, precision):
+    """INV_TRANSAD / DIR_TRANSAD against an oracle adjoint: the dense matrices of the ORACLE's forward INV_TRANS /
+    DIR_TRANS (vor, div, scalar <-> u, v, scalar), formed column by column at T10/O11 and T21/O22 and transposed with
+    the inner products of the reference's adjoint tests (tests/common.py::adjoint_matrix_case).  Unlike the dot-product
+    identity this cannot be satisfied by a wrong-but-adjoint pair of HIP kernels."""
+    from tests.common import adjoint_matrix_case
+    e_inv, e_dir = adjoint_matrix_case(et, Oracle, dev, nsmax=nsmax, precision=precision)
+    tol = 1e-12 if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
