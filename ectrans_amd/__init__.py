@@ -252,7 +252,7 @@ def real_dtype(kresol):
 _INT_SCALARS = ("nspec2", "nspec2g", "nspec2mx", "nspec", "nspecg", "ngptot", "ngptotg", "ngptotmx", "nump", "ndgl",
                 "nsmax", "ndlon", "nproc", "myproc", "nfrstlat", "nlstlat")
 _INT_ARRAYS = {"nloen": "ndgl", "nmen": "ndgl", "ndglu": "nsmax+1", "nasm0": "nsmax+1", "myms": "nump",
-               "procm": "nsmax+1", "latlo": "nproc+1"}
+               "procm": "nsmax+1", "latlo": "nproc+1", "fftwork": "ndgl"}
 _REAL_ARRAYS = {"rmu": "ndgl", "pmu": "ndgl", "rgw": "ndgl", "pgw": "ndgl", "racthe": "ndgl"}
 
 

@@ -305,29 +305,42 @@ static int build_fft_plans(Plan &P) {
     if (pl.blue) {
       pl.S = emi::next_235(2 * pl.sz - 1);
       emi::factorize_smooth(pl.S, fac);
-      // A specialised kernel with the last two factors merged into one composite radix 6, 9 or 10 (one LDS round
-      // trip fewer) is preferred when there is one (EMI_FFT_MERGE=0: never).  Even NLOEN only: odd rows run the
-      // generic kernels, which have no such butterflies.  Measured at TCo1279: inverse 103.8 -> 101.1 ms, direct
-      // 99.3 -> 96.3 ms per direction.
-      std::vector<int> fm;
-      const char *mg = getenv("EMI_FFT_MERGE");
-      if (!(mg && atoi(mg) == 0) && !pl.cmode && !getenv("EMI_FFT_NO_HOT") && emi::merge_tail(fac, fm)) {
+      // Specialised kernels (EMI_HOT_PLAN_LIST): the work length and factor list of the cheapest one that is long
+      // enough -- cost model S x (passes + 1), as next_235 -- replace the generic choice when they cost no more: that
+      // covers the merged tails (8, 8, 8, 6 | 9 | 10: one LDS round trip fewer than 8, 8, 8, 2, 3 ...; EMI_FFT_MERGE=0
+      // keeps the plain lists) and any work length of the list that is not of the form 2^a {1,3,5,9,15}
+      // (EMI_FFT_FINE=0 skips those; there are none at present, see emi_types.h).
+      // Even NLOEN only: odd rows run the generic kernels, which have no composite butterflies.  The plan must be the
+      // one for the fields-per-workgroup this work length gets (the 40-KiB rule further down).
+      const char *mg = getenv("EMI_FFT_MERGE"), *fine = getenv("EMI_FFT_FINE");
+      const bool no_merge = mg && atoi(mg) == 0, no_fine = fine && atoi(fine) == 0;
+      if (!pl.cmode && !getenv("EMI_FFT_NO_HOT")) {
         static const int hp[][9] = {
 #define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_) {pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_},
             EMI_HOT_PLAN_LIST(EMI_HOT_ROW)
 #undef EMI_HOT_ROW
         };
-        // fields per workgroup of this work length (the rule further down): the specialised kernel must be
-        // the one for exactly that shape, there is no generic kernel to fall back to with a composite radix
-        int fbk_m = 16;
-        while (fbk_m > 1 && (size_t)fbk_m * FFT_LDS_ELEMS(pl.S) * 2 * P.esz > 40960) fbk_m >>= 1;
+        long long best = (long long)pl.S * (long long)(fac.size() + 1);
+        const int *pick = nullptr;
         for (const auto &r : hp) {
-          bool same = r[1] == pl.S && r[2] == (int)fm.size() && r[8] == fbk_m;
-          for (size_t i = 0; same && i < fm.size(); i++) same = r[3 + i] == fm[i];
-          if (same) {
-            fac = fm;
-            break;
+          if (r[1] < 2 * pl.sz - 1) continue;
+          bool composite = false;
+          for (int i = 0; i < r[2]; i++) composite = composite || r[3 + i] == 6 || r[3 + i] > 8;
+          const bool is235 = r[1] == emi::next_235(r[1]);  // one of the 2^a {1,3,5,9,15} lengths
+          if (!is235 && no_fine) continue;
+          if (is235 && composite && no_merge) continue;
+          int fbk_r = 16;
+          while (fbk_r > 1 && (size_t)fbk_r * FFT_LDS_ELEMS(r[1]) * 2 * P.esz > 40960) fbk_r >>= 1;
+          if (fbk_r != r[8]) continue;
+          const long long cost = (long long)r[1] * (r[2] + 1);
+          if (cost <= best) {  // list order: a merged tail (ids 22-27) comes after the plain list of its length
+            best = cost;
+            pick = r;
           }
+        }
+        if (pick) {
+          pl.S = pick[1];
+          fac.assign(pick + 3, pick + 3 + pick[2]);
         }
       }
     }
@@ -390,6 +403,7 @@ static int build_fft_plans(Plan &P) {
       }
     }
     if (ft && atoi(ft) >= 64) nthr = std::min(1024, roundup(atoi(ft), 64));
+    const int nthr_rule = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);  // what the specialised kernels are compiled for (hot_threads)
     // specialised kernel for this work length?  (Bluestein, even NLOEN, one field per workgroup)
     int hot = 0;
     if (pl.blue && !pl.cmode && !getenv("EMI_FFT_NO_HOT")) {
@@ -403,6 +417,7 @@ static int build_fft_plans(Plan &P) {
         for (int i = 0; same && i < pl.nfac; i++) same = r[3 + i] == pl.fac[i];
         if (same) hot = r[0];
       }
+      if (hot) nthr = nthr_rule;  // the specialised kernels are compiled for this size: EMI_FFT_THREADS only reaches the generic ones
     }
     for (int i = 0; i < pl.nfac; i++)
       if (!hot && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
@@ -1237,6 +1252,11 @@ extern "C" int emi_inq_int_array(int kresol, const char *name, int *out, int len
     v = &tmp;
   } else if (s == "latlo") {  // [nproc+1] 0-based first latitude of every task's band
     v = &P->latlo;
+  } else if (s == "fftwork") {  // [ndgl] work length of the FFT of every latitude of this task (0 elsewhere): NLOEN/2 or NLOEN,
+    // or the Bluestein length; diagnostic (tests check which specialised kernel a row length selects)
+    tmp.assign(P->ndgl, 0);
+    for (int j = 0; j < P->nlat; j++) tmp[P->lat0 + j] = P->fplans[P->planid[j]].S;
+    v = &tmp;
   } else
     EMI_FAIL(EMI_ERR_ARG, "emi_inq_int_array: unknown name '%s'", s.c_str());
   if (len < (int)v->size()) EMI_FAIL(EMI_ERR_ARG, "TRANS_INQ: %s TOO SMALL (%d < %zu)", s.c_str(), len, v->size());

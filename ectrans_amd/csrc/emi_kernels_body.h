@@ -854,6 +854,55 @@ EMI_DEVFN int blue_conv(real2 *a, int nfl, int fs, const FftPlanDev &pl, const F
   return run_dit(a, nfl, fs, L, pl, T, 1, last < 1 ? 1 : last, r0, +1);
 }
 
+// ---- specialised kernels: butterfly legs by BYTE offset into the workgroup's LDS block ------------------------
+// The FFT kernels are bound by vector-instruction issue (tools/valu_lds_probe.hip: 16 waves per CU overlap their LDS
+// traffic with the arithmetic of the others almost completely, so a pass costs what its vector instructions cost), and a
+// third of the vector instructions of a pass used to be address arithmetic: a shift, an AND, an XOR and a scaled add per
+// leg for FPAD(base + t lenp), 64-bit adds for the twiddle addresses.  With the stride known at compile time the
+// swizzled position of leg t is one XOR with a constant, or an immediate offset of the LDS instruction:
+//   LENP = 1  (R = 8, base = 8 q):          FPAD(base) ^ t
+//   LENP = 8  (R = 8, base = 64 b + j):     (base ^ 8 (b & 1)) ^ 9 t
+//   LENP = 64:                              FPAD(base) ^ 8 (t & 1), + 64 t
+//   LENP a multiple of 128:                 FPAD(base) + t LENP
+// (a field's array starts at a multiple of 64 complex numbers -- every work length is one -- so the XORs, which stay
+// below that, act on the byte offset), and the twiddles of leg t are read through a per-leg uniform base (scalar registers) plus the
+// 32-bit lane offset.
+template <int R, int LENP>
+struct HotLegs {
+  static constexpr int KIND = (LENP == 1 && R == 8) ? 1 : (LENP == 8 && R == 8) ? 2 : (LENP == 64) ? 3 : (LENP % 128 == 0) ? 4 : 0;
+  static constexpr int SH = (sizeof(real2) == 16) ? 4 : 3;  // log2 of the bytes per complex number
+  int b0, b1;
+  EMI_DEVFN HotLegs(int fo, int base) {
+    if constexpr (KIND == 2)
+      b0 = fo + ((base ^ ((base >> 3) & 8)) << SH);
+    else if constexpr (KIND == 0)
+      b0 = base;  // element index; the field offset is added in at()
+    else
+      b0 = fo + (FPAD(base) << SH);
+    b1 = (KIND == 3) ? (b0 ^ (8 << SH)) : fo;
+  }
+  EMI_DEVFN int at(int t) const {
+    if constexpr (KIND == 1)
+      return b0 ^ (t << SH);
+    else if constexpr (KIND == 2)
+      return b0 ^ ((9 * t) << SH);
+    else if constexpr (KIND == 3)
+      return ((t & 1) ? b1 : b0) + ((64 * t) << SH);
+    else if constexpr (KIND == 4)
+      return b0 + ((t * LENP) << SH);
+    else
+      return b1 + (FPAD(b0 + t * LENP) << SH);
+  }
+};
+EMI_DEVFN real2 hot_ld(int boff) {
+  EMI_LDS_DECL;
+  return *(const real2 *)(EMI_LDS_PTR + boff);
+}
+EMI_DEVFN void hot_st(int boff, real2 v) {
+  EMI_LDS_DECL;
+  *(real2 *)(EMI_LDS_PTR + boff) = v;
+}
+
 // Grid arrays are blocked (ngpblks, nfld, nproma).  One latitude row of one field starts at point
 // gp0 of the task's grid; GridRow resolves the NPROMA block of gp0 once (the only 64-bit division),
 // every element then costs an add and a compare unless the row crosses a block boundary.
@@ -887,7 +936,9 @@ EMI_DEVFN bool grid_pair_ok(const GridRow &r, unsigned o) {
 // Bluestein: z_i = a'_i * conj(chirp_i) / L.
 // BLUE (specialised kernels: always Bluestein): i = j + t lenp < sz <= (S+1)/2 only for t < (R+1)/2 -- the other
 // outputs, their chirp values and the part of the butterfly that only feeds them are never generated.
-template <int R, int BLUE = 0>
+// LENP > 0 (specialised kernels): the stride at compile time -- legs by byte offset (HotLegs), tables through per-leg
+// uniform bases
+template <int R, int BLUE = 0, int LENP = 0>
 EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, const real2 *tw, const real2 *ptw, const FftPlanDev &pl,
                                 const real2 *chirp, const GridFld *flds, int f0, long long gp0, int nproma) {
   constexpr int NOUT = BLUE ? (R + 1) / 2 : R;
@@ -903,24 +954,29 @@ EMI_DEVFN void dit_last_to_grid(real2 *a, int nfl, int fs, int S, int lenp, cons
       EMI_OPAQUE(j);
       real2 v[R], w[R], ch[NOUT];
       if (lenp > 1) {
-        const real2 *pw_ = ptw + j;
 #pragma unroll
-        for (int t = 1; t < R; t++) w[t] = pw_[(t - 1) * lenp];
+        for (int t = 1; t < R; t++) w[t] = (ptw + (t - 1) * lenp)[(unsigned)j];
       }
+      if constexpr (LENP > 0) {
+        const HotLegs<R, LENP> L(fl * fs * (int)sizeof(real2), j);
 #pragma unroll
-      for (int t = 0; t < R; t++) v[t] = af[FPAD(j + t * lenp)];
+        for (int t = 0; t < R; t++) v[t] = hot_ld(L.at(t));
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; t++) v[t] = af[FPAD(j + t * lenp)];
+      }
       if (lenp > 1) {
 #pragma unroll
         for (int t = 1; t < R; t++) v[t] = cmulc(v[t], w[t]);  // inverse: conjugate twiddles
       }
       if (pl.blue && R <= 8) {  // chirp values of the outputs: in flight during the butterfly
 #pragma unroll
-        for (int t = 0; t < NOUT; t++) ch[t] = (j + t * lenp < sz) ? chirp[j + t * lenp] : mk2(0.0, 0.0);
+        for (int t = 0; t < NOUT; t++) ch[t] = (j + t * lenp < sz) ? (chirp + t * lenp)[(unsigned)j] : mk2(0.0, 0.0);
       }
       butterfly<R>(v, tw, S, +1);
       if (pl.blue && R > 8) {  // composite radices: no registers to spare during the butterfly
 #pragma unroll
-        for (int t = 0; t < NOUT; t++) ch[t] = (j + t * lenp < sz) ? chirp[j + t * lenp] : mk2(0.0, 0.0);
+        for (int t = 0; t < NOUT; t++) ch[t] = (j + t * lenp < sz) ? (chirp + t * lenp)[(unsigned)j] : mk2(0.0, 0.0);
       }
 #pragma unroll
       for (int t = 0; t < NOUT; t++) {
@@ -1177,6 +1233,117 @@ EMI_DEVFN constexpr int hot_lenp(int pc, int ip) {  // stride of factor ip = pro
   return l;
 }
 
+// one butterfly q of the field at byte offset fo: fft_bfly_at with the stride and the work length known at compile time
+template <int R, int LENP, int S, int DIF, int MASK, int TW, int NOUT, int NZ>
+EMI_DEVFN void hot_bfly_at(int fo, int q, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
+  constexpr int len = LENP * R;
+  int blk = 0, j = q;
+  if constexpr (len != S) {  // the last pass spans the whole array: block 0
+    blk = (int)((unsigned)q / (unsigned)LENP);
+    j = q - blk * LENP;
+  }
+  const int base = blk * len + j;
+  real2 w[R];
+  if (TW) {
+#pragma unroll
+    for (int t = 1; t < R; t++) w[t] = (ptw + (t - 1) * LENP)[(unsigned)j];
+  }
+  const HotLegs<R, LENP> L(fo, base);
+  real2 v[R];
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+    if (t >= NZ)
+      v[t] = mk2(0.0, 0.0);
+    else if (MASK)
+      v[t] = (base + t * LENP < nvalid) ? hot_ld(L.at(t)) : mk2(0.0, 0.0);
+    else
+      v[t] = hot_ld(L.at(t));
+  }
+  if (TW) {
+    if (sgn > 0) {
+#pragma unroll
+      for (int t = 1; t < R; t++) w[t].y = -w[t].y;
+    }
+  }
+  if (TW && !DIF) {
+#pragma unroll
+    for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
+  }
+  if constexpr (NZ < R && NZ == R / 2 && (R == 8 || R == 4))
+    butterfly_hz<R>(v, sgn);
+  else
+    butterfly<R>(v, tw, S, sgn);
+  if (TW && DIF) {
+#pragma unroll
+    for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < NOUT; t++) hot_st(L.at(t), v[t]);
+}
+// FLAT as fft_pass_body; fsb: bytes between the fields of the workgroup
+// NT: threads of the workgroup (a compile-time property of the plan, hot_threads): with one field per workgroup the
+// butterfly loop has a compile-time trip count and disappears
+template <int NT, int R, int LENP, int S, int DIF, int MASK, int TW, int FLAT, int NOUT = R, int NZ = R>
+EMI_DEVFN void hot_pass_body(int nfl, int fsb, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
+  constexpr int nb = S / R;
+  if (FLAT) {
+    for (int idx = EMI_TID; idx < nfl * nb; idx += NT) {
+      const int fl = (int)((unsigned)idx / (unsigned)nb), q = idx - fl * nb;
+      hot_bfly_at<R, LENP, S, DIF, MASK, TW, NOUT, NZ>(fl * fsb, q, tw, ptw, sgn, nvalid);
+    }
+  } else {
+    for (int fl = 0; fl < nfl; fl++) {
+      // several sweeps (2560, 4608, 5120 ...): a real loop -- unrolled, the sweeps' registers overlap and spill
+#pragma nounroll
+      for (int q0 = 0; q0 < nb; q0 += NT) {
+        const int q = q0 + EMI_TID;
+        if (q0 + NT <= nb || q < nb) hot_bfly_at<R, LENP, S, DIF, MASK, TW, NOUT, NZ>(fl * fsb, q, tw, ptw, sgn, nvalid);
+      }
+    }
+  }
+}
+// blue_middle_at for the specialised kernels (first factor 8: contiguous runs of 8, no zero padding left at this point)
+template <int R, int S>
+EMI_DEVFN void hot_middle_at(int fo, int q, const real2 *tw, const real2 *bh, int conj_b) {
+  constexpr int nb = S / R;
+  real2 v[R], b[R];
+#pragma unroll
+  for (int t = 0; t < R; t++) b[t] = (bh + t * nb)[(unsigned)q];  // filter values, table [t][q]
+  const HotLegs<R, 1> L(fo, q * R);
+#pragma unroll
+  for (int t = 0; t < R; t++) v[t] = hot_ld(L.at(t));
+  butterfly<R>(v, tw, S, -1);
+#pragma unroll
+  for (int t = 0; t < R; t++) v[t] = conj_b ? cmulc(v[t], b[t]) : cmul(v[t], b[t]);
+  butterfly<R>(v, tw, S, +1);
+#pragma unroll
+  for (int t = 0; t < R; t++) hot_st(L.at(t), v[t]);
+}
+template <int NT, int R, int S, int FLAT>
+EMI_DEVFN void hot_middle(int nfl, int fsb, const real2 *tw, const real2 *bh, int conj_b) {
+  constexpr int nb = S / R;
+  if (FLAT) {
+    for (int idx = EMI_TID; idx < nfl * nb; idx += NT) {
+      const int fl = (int)((unsigned)idx / (unsigned)nb), q = idx - fl * nb;
+      hot_middle_at<R, S>(fl * fsb, q, tw, bh, conj_b);
+    }
+  } else {
+    for (int fl = 0; fl < nfl; fl++) {
+#pragma nounroll
+      for (int q0 = 0; q0 < nb; q0 += NT) {
+        const int q = q0 + EMI_TID;
+        if (q0 + NT <= nb || q < nb) hot_middle_at<R, S>(fl * fsb, q, tw, bh, conj_b);
+      }
+    }
+  }
+}
+
+// threads of the workgroup of plan pc in this precision: the host's rule (build_fft_plans: 256 / 512 / 1024 for <= 40 / 80 /
+// 160 KiB of LDS), which it applies to exactly the (work length, fields per workgroup) a specialised kernel is matched with
+EMI_DEVFN constexpr int hot_threads(int pc) {
+  const long long need = (long long)hot_plan(pc).nfl * FFT_LDS_ELEMS(hot_plan(pc).S) * (long long)sizeof(real2);
+  return need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);
+}
 // forward Bluestein chain on one field: DIF passes nfac-1..1, fused middle, DIT passes 1..last-1
 // Workgroup barriers are only needed where data crosses waves.  With the butterfly -> thread map
 // q = tid + i * nthreads used by every pass, the radix-8 butterflies q = 64 w .. 64 w + 63 of wave w
@@ -1208,10 +1375,10 @@ EMI_DEVFN void hot_dif(real2 *a, int nfl, int fs, const FftPlanDev &pl, const re
     if constexpr (IP == H.nfac - 1) {
       // first pass: the chirped row occupies sz <= S/2 elements, i.e. only the legs t < R/2 of an even radix
       constexpr int R = H.fac[IP], NZ = (R % 2 == 0) ? R / 2 : R;
-      fft_pass_body<R, 1, 1, 1, (H.nfl > 1), R, NZ>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, nvalid);
+      hot_pass_body<hot_threads(PC), R, hot_lenp(PC, IP), H.S, 1, 1, 1, (H.nfl > 1), R, NZ>(nfl, fs * (int)sizeof(real2), tw, ptw + pl.ptw_off[IP], -1, nvalid);
     }
     else
-      fft_pass_body<H.fac[IP], 1, 0, 1, (H.nfl > 1)>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], -1, H.S);
+      hot_pass_body<hot_threads(PC), H.fac[IP], hot_lenp(PC, IP), H.S, 1, 0, 1, (H.nfl > 1)>(nfl, fs * (int)sizeof(real2), tw, ptw + pl.ptw_off[IP], -1, H.S);
     HOT_SYNC(IP, IP - 1);
     hot_dif<PC, IP - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
   }
@@ -1222,7 +1389,7 @@ EMI_DEVFN void hot_dit(real2 *a, int nfl, int fs, const FftPlanDev &pl, const re
   if constexpr (IP < END) {
     // the very last pass of the convolution (direct transform): only the first half of its outputs is read
     constexpr int R = H.fac[IP], NOUT = (IP == H.nfac - 1) ? (R + 1) / 2 : R;
-    fft_pass_body<R, 0, 0, 1, (H.nfl > 1), NOUT>(a, nfl, fs, H.S, hot_lenp(PC, IP), tw, ptw + pl.ptw_off[IP], +1, H.S);
+    hot_pass_body<hot_threads(PC), R, hot_lenp(PC, IP), H.S, 0, 0, 1, (H.nfl > 1), NOUT>(nfl, fs * (int)sizeof(real2), tw, ptw + pl.ptw_off[IP], +1, H.S);
     if constexpr (IP + 1 < H.nfac)
       HOT_SYNC(IP, IP + 1);
     else
@@ -1236,7 +1403,7 @@ EMI_DEVFN void hot_conv(real2 *a, int nfl, int fs, const FftPlanDev &pl, const F
   const real2 *tw = (const real2 *)T.tw + pl.tw_off, *bh = (const real2 *)T.bhat + pl.bhat_off;
   const real2 *ptw = (const real2 *)T.ptw;
   hot_dif<PC, H.nfac - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
-  blue_middle<H.fac[0], (H.nfl > 1)>(a, nfl, fs, H.S, tw, bh, conj_b, H.S);
+  hot_middle<hot_threads(PC), H.fac[0], H.S, (H.nfl > 1)>(nfl, fs * (int)sizeof(real2), tw, bh, conj_b);
   HOT_SYNC(0, 1);
   hot_dit<PC, 1, LASTDIT ? H.nfac : H.nfac - 1>(a, nfl, fs, pl, tw, ptw);
 }
@@ -1286,7 +1453,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   EMI_SYNC();
   hot_conv<PC, 0>(a, nfl, fs, pl, T, 1, sz);
   constexpr int last = H.nfac - 1;
-  dit_last_to_grid<H.fac[last], 1>(a, nfl, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
+  dit_last_to_grid<H.fac[last], 1, hot_lenp(PC, last)>(a, nfl, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
                                 (const real2 *)T.ptw + pl.ptw_off[last], pl, chirp, flds, f0, g.gpoff[lat], nproma);
   (void)n;
 }

@@ -119,7 +119,10 @@ struct FftLaunchDev {
 // 40-KiB rule gives in fp64 (both checked when a plan is matched).  1-8: the rows that carry TCo1279;
 // 9-12: the longer rows of TCo2559 (fp32: up to 10240 points fit the LDS); 13-21: the short rows, several
 // fields per workgroup (most of TCo399); 22-27: plans 3, 5, 6, 16, 17, 19 with their last two factors merged into
-// one composite radix (6, 9, 10: one LDS round trip fewer), preferred when present (emi::merge_tail).
+// one composite radix (6, 9, 10: one LDS round trip fewer), preferred when present.
+// (Measured and rejected, round 2: nine intermediate work lengths 64 R3 R4 -- 1600, 1728, 1920, 2304, 2880, 3200, 3456,
+// 3840, 5184 as 8, 8, R3, R4 -- cut the summed work length of TCo1279's long rows by 4.5 %, but their third pass is
+// not wave-local and their lanes fill worse: FFT phase 197.9 ms against 197.4 ms without them.)
 #define EMI_HOT_PLAN_LIST(X)          \
   X(1, 2048, 4, 8, 8, 8, 4, 1, 1)     \
   X(2, 2560, 4, 8, 8, 8, 5, 1, 1)     \
