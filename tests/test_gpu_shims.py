@@ -110,3 +110,23 @@ def test_bench_multi_rank_launch(ngpus):
     assert abs(out["roofline"]["peak"] - ngpus * 78.6) < 1e-9 and 0 < out["roofline"]["frac"] < 1
     assert out["config"]["world_size"] == ngpus and out["config"]["backend"] == "gloo"
     assert out["spectral_norm_rel_error"] < 1e-12
+
+
+def test_native_rccl_transport():
+    """ectrans_amd/rccl/emi_rccl_hook.c: the all-to-all-v as grouped ncclSend / ncclRecv on the library's stream, for hosts
+    without Python (tests/rccl/test_rccl_hook.c, the RCCL twin of the MPI host).  One task here exercises
+    ncclCommInitRank, SPECNORM's ncclAllReduce path and the exchange entry itself; with `mpiexec -n 2` the unique id
+    travels by MPI_Bcast -- RCCL refuses two tasks on one device, so on a one-GPU box that run reports it and is
+    accepted as skipped."""
+    import shutil
+    d = os.path.join(ROOT, "ectrans_amd", "rccl")
+    subprocess.check_call(["make", "-s", "-C", d, "all", "test_rccl_hook"])
+    p = subprocess.run([os.path.join(d, "test_rccl_hook")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL HOOK OK rank 0 of 1" in p.stdout, p.stdout + p.stderr
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if os.path.exists(mpiexec) and os.path.exists("/opt/conda/lib/libmpi.so"):
+        subprocess.check_call(["make", "-s", "-C", d, "test_rccl_hook_mpi"])
+        env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        p = subprocess.run([mpiexec, "-n", "2", os.path.join(d, "test_rccl_hook_mpi")], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert p.stdout.count("RCCL HOOK OK") == 2 or p.stdout.count("RCCL REFUSED") == 2, p.stdout + p.stderr
