@@ -123,6 +123,12 @@ def _bind(L):
     L.emi_set_profile.argtypes = [C.c_int]
     L.emi_last_phase_launches.argtypes = [ip]
     L.emi_crc64.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
+    L.emi_set_host_collectives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emi_dist_spec.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, ip, C.c_void_p]
+    L.emi_gath_spec.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, C.c_void_p]
+    L.emi_dist_grid.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, ip, C.c_int, C.c_void_p]
+    L.emi_gath_grid.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, C.c_int, C.c_void_p]
+    L.emi_inq_tasks.argtypes = [ip, ip]
     return L
 
 
@@ -192,6 +198,8 @@ def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, mypr
         dev = ("cuda:%d" % device) if device is not None and device >= 0 else "cpu"
         hook = alltoallv if alltoallv is not None else _dist.make_alltoallv_hook(group, dev)
         _chk(lib().emi_set_alltoallv(C.cast(hook, C.c_void_p), None))
+        bc, ag = _dist.make_host_collectives(group, dev)  # DIST_x / GATH_x, SPECNORM over several tasks
+        _chk(lib().emi_set_host_collectives(C.cast(bc, C.c_void_p), C.cast(ag, C.c_void_p), None))
         _DIST.update(nproc=kprtrw, group=group, device=dev)
     else:
         _DIST.update(nproc=1, group=None, device=None)
@@ -433,103 +441,79 @@ def _global_spec_index(kresol):
 
 
 def _roots(k, nfld, what):
-    k = np.broadcast_to(np.asarray(k, dtype=np.int64), (nfld,)) if np.ndim(k) <= 1 else None
-    if k is None or k.min() < 1 or k.max() > _DIST["nproc"]:
+    k = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.int32), (nfld,))) if np.ndim(k) <= 1 else None
+    if k is None or (nfld and (k.min() < 1 or k.max() > _DIST["nproc"])):
         raise TransError("%s: task numbers must be 1..%d" % (what, _DIST["nproc"]))
     return k
 
 
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
 def dist_spec(kresol, pspecg, kfdistg, kfrom=1):
-    """DIST_SPEC (dist_spec.h:11): global spectral fields `pspecg` (nspec2g, kfdistg), field f held by
-    task kfrom[f] (1-based; None elsewhere), -> this task's (nspec2, kfdistg) local array."""
+    """DIST_SPEC (dist_spec.h:11) over emi_dist_spec: global spectral fields `pspecg` (nspec2g, kfdistg), field f held
+    by task kfrom[f] (1-based; the columns of other tasks' fields are not read, the array may be None on a task that is
+    the source of none), -> this task's (nspec2, kfdistg) local array."""
     dt = real_dtype(kresol)
-    ns2g = trans_inq(kresol, "nspec2g")
+    ns2g, ns2, me = trans_inq(kresol, "nspec2g"), trans_inq(kresol, "nspec2"), trans_inq(kresol, "myproc")
     kfrom = _roots(kfrom, kfdistg, "DIST_SPEC:KFROM")
-    idx = _global_spec_index(kresol)
-    out = np.zeros((idx.size, kfdistg), dtype=dt)
-    me = trans_inq(kresol, "myproc")
-    for root in np.unique(kfrom):
-        f = np.flatnonzero(kfrom == root)
-        if _DIST["nproc"] == 1:
-            g = _np(pspecg)[:, f]
-        else:
-            from . import dist as _dist
-            src = np.ascontiguousarray(_np(pspecg)[:, f]) if me == root else None
-            if me == root and src.shape[0] != ns2g:
-                raise TransError("DIST_SPEC: PSPECG must have shape (nspec2g=%d, nfld)" % ns2g)
-            g = _dist.broadcast_from(src, (ns2g, f.size), np.dtype(dt), int(root) - 1, _DIST["group"], _DIST["device"])
-        out[:, f] = g[idx]
+    mine = np.flatnonzero(kfrom == me)
+    g = None
+    if mine.size:
+        a = _np(pspecg)
+        if a.shape[0] != ns2g:
+            raise TransError("DIST_SPEC: PSPECG must have shape (nspec2g=%d, nfld)" % ns2g)
+        g = np.ascontiguousarray(a[:, mine].T, dtype=dt)  # [n_mine][nspec2g]
+    out = np.zeros((ns2, kfdistg), dtype=dt)
+    _chk(lib().emi_dist_spec(kresol, None if g is None else g.ctypes.data, kfdistg, _iptr(kfrom), None, out.ctypes.data))
     return out
 
 
 def gath_spec(kresol, pspec, kfgathg, kto=1):
-    """GATH_SPEC (gath_spec.h:11): local (nspec2, kfgathg) -> global (nspec2g, kfgathg) on task kto[f]
-    (returned array holds the fields this task is the target of; None if it is the target of none)."""
+    """GATH_SPEC (gath_spec.h:11) over emi_gath_spec: local (nspec2, kfgathg) -> global (nspec2g, n_mine) holding the
+    fields this task is the target of (None if it is the target of none)."""
     dt = real_dtype(kresol)
     ns2g, me = trans_inq(kresol, "nspec2g"), trans_inq(kresol, "myproc")
     kto = _roots(kto, kfgathg, "GATH_SPEC:KTO")
     loc = np.ascontiguousarray(_np(pspec), dtype=dt)
-    full = np.zeros((ns2g, kfgathg), dtype=dt)
-    if _DIST["nproc"] == 1:
-        full[_global_spec_index(kresol)] = loc
-        return full
-    from . import dist as _dist
-    nmx = trans_inq(kresol, "nspec2mx")
-    idxs = _dist.all_gather_padded(_global_spec_index(kresol)[:, None].astype(np.int64), nmx, _DIST["group"], _DIST["device"])
-    cnts = _dist.all_gather_padded(np.array([[loc.shape[0]]], dtype=np.int64), 1, _DIST["group"], _DIST["device"])
-    parts = _dist.all_gather_padded(loc, nmx, _DIST["group"], _DIST["device"])
-    for i, (ix, c, p) in enumerate(zip(idxs, cnts, parts)):
-        c = int(c[0, 0])
-        full[ix[:c, 0]] = p[:c]
-    mine = np.flatnonzero(kto == me)
-    return full if mine.size == kfgathg else (full[:, mine] if mine.size else None)
+    nm = int((kto == me).sum())
+    g = np.zeros((nm, ns2g), dtype=dt) if nm else None
+    _chk(lib().emi_gath_spec(kresol, None if g is None else g.ctypes.data, kfgathg, _iptr(kto), loc.ctypes.data))
+    return None if g is None else np.ascontiguousarray(g.T)
 
 
 def gath_grid(kresol, pgp, kfgathg, kto=1):
-    """GATH_GRID (gath_grid.h:11): local blocked grid array (ngpblks, kfgathg, nproma) -> global
-    (kfgathg, ngptotg) on task kto[f]."""
+    """GATH_GRID (gath_grid.h:11) over emi_gath_grid: local blocked grid array (ngpblks, kfgathg, nproma) -> global
+    (n_mine, ngptotg) of the fields this task is the target of (None if none)."""
     dt = real_dtype(kresol)
-    ngl, ngg, me = trans_inq(kresol, "ngptot"), trans_inq(kresol, "ngptotg"), trans_inq(kresol, "myproc")
+    ngg, me = trans_inq(kresol, "ngptotg"), trans_inq(kresol, "myproc")
     kto = _roots(kto, kfgathg, "GATH_GRID:KTO")
-    a = _np(pgp)
-    loc = np.ascontiguousarray(np.concatenate([a[b] for b in range(a.shape[0])], axis=1)[:, :ngl].T, dtype=dt)  # (ngptot, nfld)
-    if _DIST["nproc"] == 1:
-        return np.ascontiguousarray(loc.T)
-    from . import dist as _dist
-    nmx = trans_inq(kresol, "ngptotmx")
-    cnts = _dist.all_gather_padded(np.array([[ngl]], dtype=np.int64), 1, _DIST["group"], _DIST["device"])
-    parts = _dist.all_gather_padded(loc, nmx, _DIST["group"], _DIST["device"])
-    full = np.concatenate([p[:int(c[0, 0])] for p, c in zip(parts, cnts)], axis=0)
-    if full.shape[0] != ngg:
-        raise TransError("GATH_GRID: gathered %d points, expected %d" % (full.shape[0], ngg))
-    mine = np.flatnonzero(kto == me)
-    return np.ascontiguousarray(full.T) if mine.size == kfgathg else (np.ascontiguousarray(full[:, mine].T) if mine.size else None)
+    loc = np.ascontiguousarray(_np(pgp), dtype=dt)
+    if loc.ndim != 3 or loc.shape[1] != kfgathg:
+        raise TransError("GATH_GRID: PGP must have shape (ngpblks, kfgathg=%d, nproma)" % kfgathg)
+    nm = int((kto == me).sum())
+    g = np.zeros((nm, ngg), dtype=dt) if nm else None
+    _chk(lib().emi_gath_grid(kresol, None if g is None else g.ctypes.data, kfgathg, _iptr(kto), loc.shape[2], loc.ctypes.data))
+    return g
 
 
 def dist_grid(kresol, pgpg, kfdistg, kfrom=1, kproma=None):
-    """DIST_GRID (dist_grid.h:11): global (kfdistg, ngptotg) on task kfrom[f] -> this task's blocked
-    (ngpblks, kfdistg, nproma) array."""
+    """DIST_GRID (dist_grid.h:11) over emi_dist_grid: global (kfdistg, ngptotg) on task kfrom[f] -> this task's blocked
+    (ngpblks, kfdistg, nproma) array (padding of the last block zero)."""
     dt = real_dtype(kresol)
     ngl, ngg, me = trans_inq(kresol, "ngptot"), trans_inq(kresol, "ngptotg"), trans_inq(kresol, "myproc")
     kfrom = _roots(kfrom, kfdistg, "DIST_GRID:KFROM")
-    nloen, lat0 = trans_inq(kresol, "nloen"), trans_inq(kresol, "nfrstlat") - 1
-    gp0 = int(nloen[:lat0].sum())
-    loc = np.zeros((kfdistg, ngl), dtype=dt)
-    for root in np.unique(kfrom):
-        f = np.flatnonzero(kfrom == root)
-        if _DIST["nproc"] == 1:
-            g = _np(pgpg)[f]
-        else:
-            from . import dist as _dist
-            src = np.ascontiguousarray(_np(pgpg)[f]) if me == root else None
-            g = _dist.broadcast_from(src, (f.size, ngg), np.dtype(dt), int(root) - 1, _DIST["group"], _DIST["device"])
-        loc[f] = g[:, gp0:gp0 + ngl]
+    mine = np.flatnonzero(kfrom == me)
+    g = None
+    if mine.size:
+        a = _np(pgpg)
+        if a.shape[-1] != ngg:
+            raise TransError("DIST_GRID: PGPG must have shape (nfld, ngptotg=%d)" % ngg)
+        g = np.ascontiguousarray(a[mine], dtype=dt)
     nproma = int(kproma) if kproma else ngl
-    nb = (ngl - 1) // nproma + 1
-    out = np.zeros((nb, kfdistg, nproma), dtype=dt)
-    for b in range(nb):
-        w = min(nproma, ngl - b * nproma)
-        out[b, :, :w] = loc[:, b * nproma:b * nproma + w]
+    out = np.zeros(((ngl - 1) // nproma + 1, kfdistg, nproma), dtype=dt)
+    _chk(lib().emi_dist_grid(kresol, None if g is None else g.ctypes.data, kfdistg, _iptr(kfrom), None, nproma, out.ctypes.data))
     return out
 
 

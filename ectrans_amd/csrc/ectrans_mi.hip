@@ -236,6 +236,9 @@ static struct {
   int profile = 0;  // 1: phase timers per call; 2: accumulated over the calls since emi_set_profile(2)
   emi_alltoallv_fn a2a = nullptr;
   void *a2a_user = nullptr;
+  emi_bcast_fn hc_bcast = nullptr;  // host collectives for DIST_x / GATH_x with several tasks
+  emi_allgatherv_fn hc_gather = nullptr;
+  void *hc_user = nullptr;
 } G;
 
 static Plan *get_plan(int kresol) {
@@ -2318,8 +2321,21 @@ extern "C" int emi_specnorm(int kresol, int mem_space, const void *spec, int nfl
   Plan *Pp = get_plan(kresol);
   if (!Pp) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: unknown resolution %d", kresol);
   if (!spec || nfld <= 0 || !norms) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
-  if (Pp->nproc > 1) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: with several tasks use emi_specnorm_partial and sum over tasks");
+  if (Pp->nproc > 1 && !G.hc_gather)
+    EMI_FAIL(EMI_ERR_STATE, "SPECNORM: several tasks and no host collectives (emi_set_host_collectives): use emi_specnorm_partial and sum over tasks");
   if (specnorm_sumsq(*Pp, mem_space, spec, nfld, norms)) return EMI_ERR_RUNTIME;
+  if (Pp->nproc > 1) {  // spnormc_mod.F90:49-85 gathers the partial sums on the master; here every task gets the norms
+    const int NP = Pp->nproc;
+    std::vector<double> all((size_t)NP * nfld);
+    std::vector<long long> cnt(NP, (long long)nfld * 8), dsp(NP);
+    for (int t = 0; t < NP; t++) dsp[t] = (long long)t * nfld * 8;
+    if (G.hc_gather(G.hc_user, norms, cnt[0], all.data(), cnt.data(), dsp.data(), NP)) EMI_FAIL(EMI_ERR_RUNTIME, "SPECNORM: all-gather-v failed");
+    for (int i = 0; i < nfld; i++) {
+      double s = 0.0;
+      for (int t = 0; t < NP; t++) s += all[(size_t)t * nfld + i];  // task order: the same sum on every task
+      norms[i] = s;
+    }
+  }
   for (int i = 0; i < nfld; i++) norms[i] = std::sqrt(norms[i]);
   return EMI_SUCCESS;
 }
@@ -2373,6 +2389,196 @@ extern "C" int emi_set_profile(int on) {
 extern "C" int emi_set_max_batch(int max_fields) {
   G.max_batch = max_fields;
   return EMI_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------
+// DIST_SPEC / GATH_SPEC / DIST_GRID / GATH_GRID: host-side re-layouts + two host collectives
+// ------------------------------------------------------------------------------------------
+extern "C" int emi_set_host_collectives(emi_bcast_fn bcast, emi_allgatherv_fn allgatherv, void *user) {
+  G.hc_bcast = bcast;
+  G.hc_gather = allgatherv;
+  G.hc_user = user;
+  return EMI_SUCCESS;
+}
+extern "C" int emi_inq_tasks(int *nproc, int *myproc) {
+  if (!G.init) EMI_FAIL(EMI_ERR_STATE, "emi_inq_tasks: SETUP_TRANS0 has not been called");
+  if (nproc) *nproc = G.nproc;
+  if (myproc) *myproc = G.myproc;
+  return EMI_SUCCESS;
+}
+namespace {
+struct TaskLayout {  // global <-> per-task positions of one resolution
+  std::vector<long long> iasm0g;              // [N+1] global start of wavenumber m
+  std::vector<std::vector<int>> ms;           // [task] its wavenumbers, ascending
+  std::vector<std::vector<long long>> start;  // [task][i] local start of ms[task][i]
+  std::vector<long long> nspec2, gp0, ngp;    // [task]
+};
+TaskLayout task_layout(const Plan &P) {
+  TaskLayout L;
+  const int N = P.nsmax, NP = P.nproc;
+  L.iasm0g.assign(N + 2, 0);
+  for (int m = 0; m <= N; m++) L.iasm0g[m + 1] = L.iasm0g[m] + 2LL * (N - m + 1);
+  L.ms.assign(NP, {});
+  L.start.assign(NP, {});
+  L.nspec2.assign(NP, 0);
+  for (int m = 0; m <= N; m++) {
+    const int t = P.procm[m];
+    L.ms[t].push_back(m);
+    L.start[t].push_back(L.nspec2[t]);
+    L.nspec2[t] += 2LL * (N - m + 1);
+  }
+  std::vector<long long> cum(P.ndgl + 1, 0);
+  for (int j = 0; j < P.ndgl; j++) cum[j + 1] = cum[j] + P.nloen[j];
+  L.gp0.assign(NP, 0);
+  L.ngp.assign(NP, 0);
+  for (int t = 0; t < NP; t++) {
+    L.gp0[t] = cum[P.latlo[t]];
+    L.ngp[t] = cum[P.latlo[t + 1]] - cum[P.latlo[t]];
+  }
+  return L;
+}
+int check_tasks(const Plan &P, const int *k, int nfld, const char *who) {
+  if (nfld < 0 || (nfld > 0 && !k)) EMI_FAIL(EMI_ERR_ARG, "%s: task list missing", who);
+  for (int f = 0; f < nfld; f++)
+    if (k[f] < 1 || k[f] > P.nproc) EMI_FAIL(EMI_ERR_ARG, "%s: task %d of field %d outside 1..%d", who, k[f], f + 1, P.nproc);
+  if (P.nproc > 1 && (!G.hc_bcast || !G.hc_gather))
+    EMI_FAIL(EMI_ERR_STATE, "%s: %d tasks but no host collectives registered (emi_set_host_collectives)", who, P.nproc);
+  return 0;
+}
+int slot_of(const int *ksort, int f, int nfld, const char *who, int *slot) {
+  *slot = ksort ? ksort[f] - 1 : f;
+  if (*slot < 0 || *slot >= nfld) EMI_FAIL(EMI_ERR_ARG, "%s: KSORT(%d) = %d outside 1..%d", who, f + 1, *slot + 1, nfld);
+  return 0;
+}
+}  // namespace
+
+// global fields on their source tasks -> every task's share.  One broadcast per source task.
+template <bool SPEC>
+static int dist_impl(int kresol, const void *glob, int nfld, const int *kfrom, const int *ksort, int kproma, void *loc, const char *who) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "%s: unknown resolution %d", who, kresol);
+  Plan &P = *Pp;
+  if (check_tasks(P, kfrom, nfld, who)) return EMI_ERR_ARG;
+  if (!loc) EMI_FAIL(EMI_ERR_ARG, "%s: local array missing", who);
+  const TaskLayout L = task_layout(P);
+  const size_t esz = P.esz;
+  const long long nglob = SPEC ? (long long)P.nspec2g : (long long)P.ngptotg;
+  const int nproma = kproma > 0 ? kproma : P.ngptot;
+  std::vector<char> tmp;
+  long long mine_done = 0;  // global fields of this task consumed so far
+  for (int root = 0; root < P.nproc; root++) {
+    std::vector<int> fl;
+    for (int f = 0; f < nfld; f++)
+      if (kfrom[f] == root + 1) fl.push_back(f);
+    if (fl.empty()) continue;
+    const long long bytes = (long long)fl.size() * nglob * (long long)esz;
+    const char *buf;
+    if (root == P.me) {
+      if (!glob) EMI_FAIL(EMI_ERR_ARG, "%s: this task is the source of %zu fields but passes no global array", who, fl.size());
+      buf = (const char *)glob + (size_t)mine_done * nglob * esz;
+      mine_done += (long long)fl.size();
+      if (P.nproc > 1 && G.hc_bcast(G.hc_user, (void *)buf, bytes, root)) EMI_FAIL(EMI_ERR_RUNTIME, "%s: broadcast failed", who);
+    } else {
+      tmp.resize((size_t)bytes);
+      if (G.hc_bcast(G.hc_user, tmp.data(), bytes, root)) EMI_FAIL(EMI_ERR_RUNTIME, "%s: broadcast failed", who);
+      buf = tmp.data();
+    }
+    for (size_t i = 0; i < fl.size(); i++) {
+      int slot;
+      if (slot_of(ksort, fl[i], nfld, who, &slot)) return EMI_ERR_ARG;
+      const char *g = buf + i * (size_t)nglob * esz;
+      if (SPEC) {  // PSPEC(nfld, nspec2): element (slot, isp)
+        const std::vector<int> &ms = L.ms[P.me];
+        for (size_t k = 0; k < ms.size(); k++) {
+          const long long cnt = 2LL * (P.nsmax - ms[k] + 1), gs = L.iasm0g[ms[k]], ls = L.start[P.me][k];
+          for (long long e = 0; e < cnt; e++) memcpy((char *)loc + ((size_t)(ls + e) * nfld + slot) * esz, g + (size_t)(gs + e) * esz, esz);
+        }
+      } else {  // PGP(nproma, nfld, ngpblks): point p -> block p / nproma
+        const long long g0 = L.gp0[P.me], ng = L.ngp[P.me];
+        for (long long p0 = 0; p0 < ng; p0 += nproma) {
+          const long long w = std::min<long long>(nproma, ng - p0), blk = p0 / nproma;
+          memcpy((char *)loc + ((size_t)(blk * nfld + slot) * nproma) * esz, g + (size_t)(g0 + p0) * esz, (size_t)w * esz);
+        }
+      }
+    }
+  }
+  return EMI_SUCCESS;
+}
+
+// every task's share -> global fields on their target tasks.  One all-gather-v of the packed local fields.
+template <bool SPEC>
+static int gath_impl(int kresol, void *glob, int nfld, const int *kto, int kproma, const void *loc, const char *who) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "%s: unknown resolution %d", who, kresol);
+  Plan &P = *Pp;
+  if (check_tasks(P, kto, nfld, who)) return EMI_ERR_ARG;
+  if (!loc) EMI_FAIL(EMI_ERR_ARG, "%s: local array missing", who);
+  const TaskLayout L = task_layout(P);
+  const size_t esz = P.esz;
+  const int NP = P.nproc, nproma = kproma > 0 ? kproma : P.ngptot;
+  const long long nglob = SPEC ? (long long)P.nspec2g : (long long)P.ngptotg;
+  auto nloc = [&](int t) { return SPEC ? L.nspec2[t] : L.ngp[t]; };
+  // pack [field][local element]
+  std::vector<char> mine((size_t)nfld * nloc(P.me) * esz);
+  for (int f = 0; f < nfld; f++) {
+    char *dst = mine.data() + (size_t)f * nloc(P.me) * esz;
+    if (SPEC) {
+      for (long long e = 0; e < nloc(P.me); e++) memcpy(dst + (size_t)e * esz, (const char *)loc + ((size_t)e * nfld + f) * esz, esz);
+    } else {
+      for (long long p0 = 0; p0 < nloc(P.me); p0 += nproma) {
+        const long long w = std::min<long long>(nproma, nloc(P.me) - p0), blk = p0 / nproma;
+        memcpy(dst + (size_t)p0 * esz, (const char *)loc + ((size_t)(blk * nfld + f) * nproma) * esz, (size_t)w * esz);
+      }
+    }
+  }
+  std::vector<char> all;
+  std::vector<long long> cnt(NP), dsp(NP);
+  const char *base = mine.data();
+  if (NP > 1) {
+    long long tot = 0;
+    for (int t = 0; t < NP; t++) {
+      cnt[t] = (long long)nfld * nloc(t) * (long long)esz;
+      dsp[t] = tot;
+      tot += cnt[t];
+    }
+    all.resize((size_t)tot);
+    if (G.hc_gather(G.hc_user, mine.data(), cnt[P.me], all.data(), cnt.data(), dsp.data(), NP)) EMI_FAIL(EMI_ERR_RUNTIME, "%s: all-gather-v failed", who);
+    base = all.data();
+  } else {
+    dsp[0] = 0;
+  }
+  long long i_mine = 0;
+  for (int f = 0; f < nfld; f++) {
+    if (kto[f] != P.me + 1) continue;
+    if (!glob) EMI_FAIL(EMI_ERR_ARG, "%s: this task is the target of field %d but passes no global array", who, f + 1);
+    char *g = (char *)glob + (size_t)i_mine * nglob * esz;
+    i_mine++;
+    for (int t = 0; t < NP; t++) {
+      const char *src = base + dsp[t] + (size_t)f * nloc(t) * esz;
+      if (SPEC) {
+        for (size_t k = 0; k < L.ms[t].size(); k++) {
+          const long long cnte = 2LL * (P.nsmax - L.ms[t][k] + 1);
+          memcpy(g + (size_t)L.iasm0g[L.ms[t][k]] * esz, src + (size_t)L.start[t][k] * esz, (size_t)cnte * esz);
+        }
+      } else {
+        memcpy(g + (size_t)L.gp0[t] * esz, src, (size_t)L.ngp[t] * esz);
+      }
+    }
+  }
+  return EMI_SUCCESS;
+}
+
+extern "C" int emi_dist_spec(int kresol, const void *specg, int nfld, const int *kfrom, const int *ksort, void *spec) {
+  return dist_impl<true>(kresol, specg, nfld, kfrom, ksort, 0, spec, "DIST_SPEC");
+}
+extern "C" int emi_gath_spec(int kresol, void *specg, int nfld, const int *kto, const void *spec) {
+  return gath_impl<true>(kresol, specg, nfld, kto, 0, spec, "GATH_SPEC");
+}
+extern "C" int emi_dist_grid(int kresol, const void *gpg, int nfld, const int *kfrom, const int *ksort, int kproma, void *gp) {
+  return dist_impl<false>(kresol, gpg, nfld, kfrom, ksort, kproma, gp, "DIST_GRID");
+}
+extern "C" int emi_gath_grid(int kresol, void *gpg, int nfld, const int *kto, int kproma, const void *gp) {
+  return gath_impl<false>(kresol, gpg, nfld, kto, kproma, gp, "GATH_GRID");
 }
 
 // CRC-64/ECMA-182, table driven (ectrans-benchmark.F90:1455-1600 calls fiat's crc64, un-vendored)

@@ -91,6 +91,53 @@ def make_alltoallv_hook(group=None, device=None):
     return cb
 
 
+_BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int)
+_GATHV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int)
+
+
+def make_host_collectives(group=None, device=None):
+    """(bcast, allgatherv) callbacks for emi_set_host_collectives: host bytes over torch.distributed (the DIST_x / GATH_x
+    routines and SPECNORM with several tasks; not on the transform path)."""
+    import torch
+    import torch.distributed as dist
+
+    def as_np(ptr, nbytes):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes),)) if nbytes else np.zeros(0, dtype=np.uint8)
+
+    def bcast(user, buf, nbytes, root):
+        try:
+            a = as_np(buf, nbytes)
+            t = _comm_tensor(a, group, device)
+            dist.broadcast(t, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
+            if dist.get_rank(group) != root:
+                a[:] = t.cpu().numpy()
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            return -1
+
+    def gathv(user, sb, sbytes, rb, rbytes, displs, nproc):
+        try:
+            me = dist.get_rank(group)
+            out = as_np(rb, max(int(displs[r]) + int(rbytes[r]) for r in range(nproc)))
+            for r in range(nproc):  # one broadcast per task: pieces of any size
+                piece = out[int(displs[r]):int(displs[r]) + int(rbytes[r])]
+                if r == me:
+                    piece[:] = as_np(sb, sbytes)
+                t = _comm_tensor(piece, group, device)
+                dist.broadcast(t, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+                if r != me:
+                    piece[:] = t.cpu().numpy()
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            return -1
+
+    cb = (_BCAST(bcast), _GATHV(gathv))
+    _keep.append(cb)
+    return cb
+
+
 def all_reduce_sum(values, group=None, device=None):
     """Sum a small numpy vector over tasks (SPECNORM's gather, spnormc_mod.F90:49-85)."""
     import torch

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/ectrans_mi.h"
 
@@ -60,6 +61,28 @@ static int hook(void *user, const void *sendbuf, const long long *sc, const long
   return rcode;
 }
 
+/* host collectives of DIST_x / GATH_x (emi_set_host_collectives): bytes over MPI in chunks of at most 1 GiB / int counts */
+static int hc_bcast(void *user, void *buf, long long bytes, int root) {
+  (void)user;
+  for (long long off = 0; off < bytes; off += (1LL << 30)) {
+    const long long n = bytes - off < (1LL << 30) ? bytes - off : (1LL << 30);
+    if (MPI_Bcast((char *)buf + off, (int)n, MPI_BYTE, root, g_comm) != MPI_SUCCESS) return -1;
+  }
+  return 0;
+}
+static int hc_allgatherv(void *user, const void *sendbuf, long long sendbytes, void *recvbuf, const long long *recvbytes, const long long *displs,
+                         int nproc) {
+  (void)user;
+  int me = 0;
+  MPI_Comm_rank(g_comm, &me);
+  /* one broadcast per task: counts of any size, no int overflow of displacements */
+  for (int r = 0; r < nproc; r++) {
+    if (r == me) memcpy((char *)recvbuf + displs[r], sendbuf, (size_t)sendbytes);
+    if (hc_bcast(NULL, (char *)recvbuf + displs[r], recvbytes[r], r)) return -1;
+  }
+  return 0;
+}
+
 int emi_mpi_attach(MPI_Comm comm, int kmax_resol, int kprintlev, double prad, int device) {
   int rank = 0, size = 1, ndev = 0;
   MPI_Comm_dup(comm, &g_comm);
@@ -77,6 +100,8 @@ int emi_mpi_attach(MPI_Comm comm, int kmax_resol, int kprintlev, double prad, in
   cfg.myproc = rank + 1;
   cfg.device = device;
   int rc = emi_set_alltoallv(size > 1 ? hook : NULL, NULL);
+  if (rc) return rc;
+  rc = emi_set_host_collectives(hc_bcast, hc_allgatherv, NULL);
   if (rc) return rc;
   return emi_init(&cfg);
 }

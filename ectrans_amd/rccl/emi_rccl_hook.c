@@ -60,6 +60,29 @@ int emi_rccl_alltoallv(void *user, const void *sendbuf, const long long *sc, con
   return 0;
 }
 
+/* host collectives of DIST_x / GATH_x (emi_set_host_collectives) over RCCL: the bytes are staged through device memory */
+static int hc_bcast(void *user, void *buf, long long bytes, int root) {
+  (void)user;
+  if (g_nproc == 1 || bytes == 0) return 0;
+  void *d = NULL;
+  HIP_TRY(hipMalloc(&d, (size_t)bytes));
+  if (root == g_me) HIP_TRY(hipMemcpy(d, buf, (size_t)bytes, hipMemcpyHostToDevice));
+  RCCL_TRY(ncclBroadcast(d, d, (size_t)bytes, ncclChar, root, g_comm, (hipStream_t)0));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)0));
+  if (root != g_me) HIP_TRY(hipMemcpy(buf, d, (size_t)bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(d));
+  return 0;
+}
+static int hc_allgatherv(void *user, const void *sendbuf, long long sendbytes, void *recvbuf, const long long *recvbytes, const long long *displs,
+                         int nproc) {
+  (void)user;
+  for (int r = 0; r < nproc; r++) {
+    if (r == g_me) memcpy((char *)recvbuf + displs[r], sendbuf, (size_t)sendbytes);
+    if (hc_bcast(NULL, (char *)recvbuf + displs[r], recvbytes[r], r)) return -1;
+  }
+  return 0;
+}
+
 int emi_rccl_get_unique_id(void *id) {
   ncclUniqueId u;
   if (!id) return EMI_ERR_ARG;
@@ -84,6 +107,8 @@ static int attach_common(int nproc, int myproc, int kmax_resol, int kprintlev, d
   g_nproc = nproc;
   g_me = myproc - 1;
   int rc = emi_set_alltoallv(nproc > 1 ? emi_rccl_alltoallv : NULL, NULL);
+  if (rc) return rc;
+  rc = emi_set_host_collectives(hc_bcast, hc_allgatherv, NULL);
   if (rc) return rc;
   return emi_init(&cfg);
 }

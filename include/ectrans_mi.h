@@ -193,6 +193,29 @@ int emi_set_alltoallv(emi_alltoallv_fn fn, void *user);
 /* This task's share of the SPECNORM sums (spnormd_mod.F90); sum over tasks, then sqrt.          */
 int emi_specnorm_partial(int kresol, int mem_space, const void *spec, int nfld, double *sumsq /* host */);
 
+/* ---- DIST_SPEC / GATH_SPEC / DIST_GRID / GATH_GRID (trans/include/ectrans/dist_spec.h, gath_spec.h, dist_grid.h,
+ * gath_grid.h; trans/cpu/internal/dist_spec_control_mod.F90, gath_spec_control_mod.F90, dist_grid_ctl_mod.F90,
+ * gath_grid_ctl_mod.F90) -- global fields on single tasks <-> the distributed arrays of the transforms.  HOST arrays
+ * of the resolution's precision, not on the transform path.  Global spectral order: m = 0..N, n = m..N, (re, im)
+ * (dist_spec_control_mod.F90:158-161); global grid order: latitudes north to south = the tasks' bands in task order.
+ *   specg / gpg : the global fields this task is the source (kfrom[f] == myproc) or the target (kto[f] == myproc) of,
+ *                 one after the other in field order: [n_mine][nspec2g] / [n_mine][ngptotg]  (= PGPG(ngptotg, n_mine))
+ *   spec        : PSPEC(nfld, nspec2);   gp : PGP(nproma, nfld, ngpblks), elements past NGPTOT are left alone
+ *   kfrom / kto : task (1-based) of every field; ksort (or NULL): field f lands in slot ksort[f] (1-based) of spec / gp
+ * With several tasks the host supplies two collectives over its tasks (an MPI or RCCL transport registers them, see
+ * ectrans_amd/mpi and ectrans_amd/rccl): a broadcast and an all-gather-v of host bytes.                              */
+typedef int (*emi_bcast_fn)(void *user, void *buf, long long bytes, int root /* 0-based */);
+typedef int (*emi_allgatherv_fn)(void *user, const void *sendbuf, long long sendbytes, void *recvbuf, const long long *recvbytes,
+                                 const long long *displs, int nproc);
+int emi_set_host_collectives(emi_bcast_fn bcast, emi_allgatherv_fn allgatherv, void *user);
+int emi_dist_spec(int kresol, const void *specg, int nfld, const int *kfrom, const int *ksort, void *spec);
+int emi_gath_spec(int kresol, void *specg, int nfld, const int *kto, const void *spec);
+int emi_dist_grid(int kresol, const void *gpg, int nfld, const int *kfrom, const int *ksort, int kproma, void *gp);
+int emi_gath_grid(int kresol, void *gpg, int nfld, const int *kto, int kproma, const void *gp);
+/* What emi_init was given (EMI_ERR_STATE before it): a Fortran host whose transport attached first (emi_mpi_attach,
+ * emi_rccl_attach) learns its task number from here in SETUP_TRANS0.                                                 */
+int emi_inq_tasks(int *nproc, int *myproc);
+
 /* ---- TRANS_RELEASE / TRANS_END (trans/cpu/external/trans_release.F90, trans_end.F90) -- */
 int emi_release(int kresol);
 int emi_finalize(void);

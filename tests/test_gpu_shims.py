@@ -130,3 +130,21 @@ def test_native_rccl_transport():
         p = subprocess.run([mpiexec, "-n", "2", os.path.join(d, "test_rccl_hook_mpi")], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, p.stdout + p.stderr
         assert p.stdout.count("RCCL HOOK OK") == 2 or p.stdout.count("RCCL REFUSED") == 2, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("ntasks", [1, 2, 3])
+def test_fortran_shim_several_tasks(ntasks):
+    """The Fortran drop-in with several tasks (tests/fortran/test_shim_mpi.F90 under mpiexec): the MPI transport is
+    attached first, SETUP_TRANS0 takes MYPROC / NPROC from the library, and DIST_SPEC -> INV_TRANS -> GATH_GRID ->
+    DIST_GRID -> DIR_TRANS -> GATH_SPEC between different source / target tasks returns the dense global fields;
+    SPECNORM gives every task the global norms (dist_spec_control_mod.F90, gath_grid_ctl_mod.F90, spnormc_mod.F90).
+    Skipped without MPI."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec) or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI installation")
+    d = os.path.join(ROOT, "ectrans_amd", "fortran")
+    subprocess.check_call(["make", "-s", "-C", d, "test_shim_mpi"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([mpiexec, "-n", str(ntasks), os.path.join(d, "test_shim_mpi")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and p.stdout.count("FORTRAN SHIM MPI OK") == ntasks, p.stdout + p.stderr
