@@ -134,6 +134,8 @@ static int upload(const std::vector<T> &h, T **d) {
 struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a workgroup size, fields per workgroup and kernel
   int nthr = 0, fbk = 0;
   int hot = 0;  // > 0: specialised kernel k_fft_*_hot<hot> (EMI_HOT_PLAN_LIST)
+  int gmem = 0;  // 1: the work array does not fit the LDS; k_fft_*_gm on a global scratch buffer (elems: complex numbers per workgroup)
+  long long gm_elems = 0;
   std::vector<int> lats;
   int *d_lats = nullptr;
   size_t lds = 0;
@@ -188,6 +190,8 @@ struct Plan {
   size_t cap_W = 0, cap_FBL = 0, cap_FBF = 0;
   void *d_desc = nullptr;
   size_t cap_desc = 0;
+  char *d_fftscr = nullptr;  // work arrays of the rows that exceed the LDS (k_fft_*_gm)
+  size_t cap_fftscr = 0;
   // Calls on one resolution share d_desc, W and the Fourier buffers, whatever stream each call names: every call
   // starts by making its stream wait for the event the previous call of this resolution recorded at its end.
 #ifndef EMI_CPU_EMU
@@ -393,7 +397,10 @@ static int build_fft_plans(Plan &P) {
     while (fbk > 1 && fbk * per_field > 40960) fbk >>= 1;
     pl.fbk = fbk;
     size_t need = fbk * per_field;
-    if (need > 160 * 1024) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d needs %zu B of LDS (> 160 KiB)", n, need);
+    // a row whose work array exceeds the 160 KiB of LDS (fp64: more than 10240 complex points -- the four longest rows of
+    // TCo2559, or any caller grid: the reference takes any KLOEN, ftdir_mod.F90:67-84) runs the same passes on a slice
+    // of a global scratch buffer (k_fft_*_gm): slow per row, but such rows are few
+    const bool gmem = need > 160 * 1024;
     int nthr = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);
     const char *ft = getenv("EMI_FFT_THREADS");
     if (ft && atoi(ft) == -1) {
@@ -409,7 +416,7 @@ static int build_fft_plans(Plan &P) {
     const int nthr_rule = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);  // what the specialised kernels are compiled for (hot_threads)
     // specialised kernel for this work length?  (Bluestein, even NLOEN, one field per workgroup)
     int hot = 0;
-    if (pl.blue && !pl.cmode && !getenv("EMI_FFT_NO_HOT")) {
+    if (pl.blue && !pl.cmode && !gmem && !getenv("EMI_FFT_NO_HOT")) {
       static const int hp[][9] = {
 #define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_) {pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_},
           EMI_HOT_PLAN_LIST(EMI_HOT_ROW)
@@ -426,13 +433,14 @@ static int build_fft_plans(Plan &P) {
       if (!hot && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
     int cls = -1;
     for (size_t c = 0; c < P.fclass.size(); c++)
-      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot) cls = (int)c;
+      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot && P.fclass[c].gmem == (gmem ? 1 : 0)) cls = (int)c;
     if (cls < 0) {
       cls = (int)P.fclass.size();
       P.fclass.emplace_back();
       P.fclass[cls].nthr = nthr;
       P.fclass[cls].fbk = fbk;
       P.fclass[cls].hot = hot;
+      P.fclass[cls].gmem = gmem ? 1 : 0;
     }
     pl.lds_class = cls;
     int id = (int)P.fplans.size();
@@ -514,7 +522,10 @@ static int build_fft_plans(Plan &P) {
     const FftPlanDev &pl = P.fplans[P.planid[j]];
     FftClass &fc = P.fclass[pl.lds_class];
     fc.lats.push_back(j);
-    fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 2 * P.esz);
+    if (fc.gmem)
+      fc.gm_elems = std::max(fc.gm_elems, (long long)pl.fbk * FFT_LDS_ELEMS(pl.S));
+    else
+      fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 2 * P.esz);
   }
   void *d_tw, *d_rtw, *d_chirp, *d_bhat, *d_ptw;
   uint16_t *d_perm;
@@ -1162,6 +1173,7 @@ extern "C" int emi_release(int kresol) {
   emi_dev_free(P->d_FBL);
   if (P->d_FBF != P->d_FBL) emi_dev_free(P->d_FBF);
   emi_dev_free(P->d_desc);
+  emi_dev_free(P->d_fftscr);
   P->active = false;
   delete P;
   G.plans[kresol - 1] = nullptr;
@@ -1622,7 +1634,7 @@ struct PhaseTimer {
 };
 static PhaseTimer g_pt;
 
-static void launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
+static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
                        emi_stream_t st) {
   for (size_t c = 0; c < P.fclass.size(); c++) {
     FftClass &fc = P.fclass[c];
@@ -1631,6 +1643,32 @@ static void launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, i
     const long long nblocks = (long long)fc.lats.size() * nchunk;
     FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0};
     const int nthr = fc.nthr;
+    if (fc.gmem) {  // work arrays in global memory, one slice per workgroup
+      const size_t needb = (size_t)nblocks * fc.gm_elems * 2 * P.esz;
+      if (needb > P.cap_fftscr) {
+        plan_quiesce(P);
+        emi_stream_sync(0);
+        emi_dev_free(P.d_fftscr);
+        P.d_fftscr = nullptr;
+        P.cap_fftscr = 0;
+        void *q = nullptr;
+        if (emi_dev_malloc(&q, needb)) EMI_FAIL(EMI_ERR_RUNTIME, "cannot allocate %.2f GiB of FFT scratch for the rows that exceed the LDS", needb / 1073741824.0);
+        P.d_fftscr = (char *)q;
+        P.cap_fftscr = needb;
+      }
+      if (inverse) {
+        if (P.esz == 8)
+          EMI_LAUNCH(emi_f64::k_fft_inv_gm, nblocks, nthr, 0, st, P.g, P.ftab, lc, d_flds, nfld, (const double *)FB, ldf, nproma, (d2 *)P.d_fftscr, fc.gm_elems);
+        else
+          EMI_LAUNCH(emi_f32::k_fft_inv_gm, nblocks, nthr, 0, st, P.g, P.ftab, lc, d_flds, nfld, (const float *)FB, ldf, nproma, (f2 *)P.d_fftscr, fc.gm_elems);
+      } else {
+        if (P.esz == 8)
+          EMI_LAUNCH(emi_f64::k_fft_dir_gm, nblocks, nthr, 0, st, P.g, P.ftab, lc, d_flds, nfld, (double *)FB, ldf, nproma, (d2 *)P.d_fftscr, fc.gm_elems);
+        else
+          EMI_LAUNCH(emi_f32::k_fft_dir_gm, nblocks, nthr, 0, st, P.g, P.ftab, lc, d_flds, nfld, (float *)FB, ldf, nproma, (f2 *)P.d_fftscr, fc.gm_elems);
+      }
+      continue;
+    }
     switch (fc.hot) {
 #define EMI_HOT_LAUNCH(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_)                                                                                       \
   case pc_:                                                                                                                                    \
@@ -1648,6 +1686,7 @@ static void launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, i
           EMI_LAUNCH_P(P.esz, k_fft_dir, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
     }
   }
+  return 0;
 }
 
 // Two library-owned streams software-pipeline the field batches of one call: the Legendre kernels
@@ -2071,7 +2110,11 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     // stream B: FFTs
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sB);
     iv = g_pt.start(2, sB);
-    launch_fft(P, true, adj, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    if (launch_fft(P, true, adj, d_bg, bt.ng, FBf, ldw, nproma, sB)) {
+      if (piped) g_pipe.end(st);
+      plan_end(P, st);
+      return EMI_ERR_RUNTIME;
+    }
     g_pt.stop(iv, sB);
     if (piped) g_pipe.signal(3 * ib + 1, sB);
   }
@@ -2261,7 +2304,11 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     // (several tasks) of batch ib-2
     if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + (dist ? 2 : 1), sB);
     int iv = g_pt.start(2, sB);
-    launch_fft(P, false, adj, d_bg, bt.ng, FBf, ldw, nproma, sB);
+    if (launch_fft(P, false, adj, d_bg, bt.ng, FBf, ldw, nproma, sB)) {
+      if (piped) g_pipe.end(st);
+      plan_end(P, st);
+      return EMI_ERR_RUNTIME;
+    }
     g_pt.stop(iv, sB);
     if (piped) g_pipe.signal(3 * ib, sB);
     if (dist) {

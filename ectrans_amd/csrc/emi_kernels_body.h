@@ -1024,10 +1024,11 @@ EMI_DEVFN real2 fsc_load(const real_t *FB, int row, int ldf, const GridFld &gf, 
   return x;
 }
 
-EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
-                              int ldf, int nproma) {
-  EMI_LDS_DECL;
-  real2 *a = (real2 *)EMI_LDS_PTR;
+// `a`: the work array of the workgroup -- its LDS block (k_fft_inv), or, for rows whose work array exceeds the 160 KiB of
+// LDS (fp64 rows beyond 10240 complex points: TCo2559, or any caller grid), a slice of a global scratch buffer
+// (k_fft_inv_gm); the passes are the same code, the workgroup barrier orders global accesses as it orders LDS ones
+EMI_DEVFN void fft_inv_body(const EmiGeomDev &g, const FftTabDev &T, const FftLaunchDev &Lc, const GridFld *flds, int nfld, const real_t *FB,
+                            int ldf, int nproma, real2 *a) {
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
   const int lat = Lc.lats[li];
@@ -1123,16 +1124,24 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunc
   FFT_DISPATCH(dit_last_to_grid_any, rl, a, nfl, fs, S, lenp, tw, (const real2 *)T.ptw + pl.ptw_off[pl.nfac - 1], pl, chirp, flds, f0, gp0, nproma);
 }
 
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+                              int ldf, int nproma) {
+  EMI_LDS_DECL;
+  fft_inv_body(g, T, Lc, flds, nfld, FB, ldf, nproma, (real2 *)EMI_LDS_PTR);
+}
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_gm(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+                                 int ldf, int nproma, real2 *scratch, long long stride) {
+  fft_inv_body(g, T, Lc, flds, nfld, FB, ldf, nproma, scratch + (long long)EMI_BID * stride);
+}
+
 // ==========================================================================================
 // k_fft_dir: TRGTOL local copy + FTDIR (ftdir_mod.F90:67-84; r2c, scaled 1/NLOEN at
 // tpm_fftw.F90:317-321) + FOURIER_OUT (fourier_out_mod.F90:64-76).  The Gaussian weight
 // (ledir_mod.F90:118-124) and LDFOU2's 1/(a cos) (ldfou2_mod.F90:90-96) only depend on the
 // latitude and are folded into the same scale factor.
 // ==========================================================================================
-EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
-                              int nproma) {
-  EMI_LDS_DECL;
-  real2 *a = (real2 *)EMI_LDS_PTR;
+EMI_DEVFN void fft_dir_body(const EmiGeomDev &g, const FftTabDev &T, const FftLaunchDev &Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+                            int nproma, real2 *a) {
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
   const int lat = Lc.lats[li];
@@ -1205,6 +1214,16 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunc
       *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * (f0 + fl)) = cscale(x, sc);
     }
   }
+}
+
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+                              int nproma) {
+  EMI_LDS_DECL;
+  fft_dir_body(g, T, Lc, flds, nfld, FB, ldf, nproma, (real2 *)EMI_LDS_PTR);
+}
+EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_gm(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+                                 int nproma, real2 *scratch, long long stride) {
+  fft_dir_body(g, T, Lc, flds, nfld, FB, ldf, nproma, scratch + (long long)EMI_BID * stride);
 }
 
 // ==========================================================================================

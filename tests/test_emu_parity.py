@@ -368,3 +368,16 @@ def test_adjoints_match_transposed_oracle_matrices(et):
     from tests.common import adjoint_matrix_case
     e_inv, e_dir = adjoint_matrix_case(et, Oracle, XP, nsmax=8)
     assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
+
+
+def test_rows_longer_than_the_lds(et):
+    """Rows whose FFT work array exceeds the 160 KiB of LDS (fp64: more than 10240 complex points) run the same passes on a
+    global scratch buffer (k_fft_*_gm) -- the reference takes any KLOEN (ftdir_mod.F90:67-84).  Row lengths 20484 ... 20500
+    (Bluestein work length 24576 = 384 KiB), mixed with an ordinary row, NPROMA blocks."""
+    half = [20484, 20492, 300, 20500]
+    nloen = np.array(half + half[::-1], dtype=np.int32)
+    r = et.setup_trans(5, len(nloen), nloen)
+    assert list(et.trans_inq(r, "fftwork")[:4]) == [24576, 24576, 150, 24576]
+    et.trans_release(r)
+    e_inv, e_dir = run_case(et, Oracle, XP, 5, nloen, 1, 1, dict(scders=True), 3000)
+    assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)

@@ -80,3 +80,31 @@ def test_per_latitude_row_relative_error_tco399(et):
         assert worst < 1e-10, worst
     finally:
         et.trans_release(r)
+
+
+def test_tco2559_fp64_sets_up_and_matches_oracle(et):
+    """TCo2559 in fp64 (round 1: EMI_ERR_UNSUPPORTED, its four longest rows need 196 KiB work arrays): set-up (2 x 51 GiB of
+    Legendre panels) and 3 dense fields through both directions against the lazy-panel oracle."""
+    import torch
+    N = 2559
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    try:
+        o = Oracle(N, nloen, lazy=True)
+        rng = np.random.default_rng(20251114)
+        vor, div = (random_spectrum(rng, o.nasm0, N, o.nspec2, 1, True) for _ in range(2))
+        sc = random_spectrum(rng, o.nasm0, N, o.nspec2, 1, False)
+        gref = o.inv_trans(spvor=vor, spdiv=div, spsc=sc)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+        gp = torch.zeros((1, 3, o.ngptot), dtype=torch.float64, device="cuda:0")
+        et.inv_trans(r, pspvor=to(vor), pspdiv=to(div), pspscalar=to(sc), pgp=gp)
+        g = gp[0].cpu().numpy()
+        e_inv = (np.abs(g - gref).max(axis=1) / np.abs(gref).max(axis=1)).max()
+        v2, d2, s2 = (torch.zeros((o.nspec2, 1), dtype=torch.float64, device="cuda:0") for _ in range(3))
+        et.dir_trans(r, pspvor=v2, pspdiv=d2, pspscalar=s2, pgp=to(gref[None]))
+        ref = o.dir_trans(gref, nuv=1, nsc=1)
+        e_dir = max(float(np.abs(a.cpu().numpy() - b).max() / np.abs(b).max()) for a, b in zip((v2, d2, s2), ref))
+        assert e_inv < 1e-11 and e_dir < 1e-11, (e_inv, e_dir)
+    finally:
+        et.trans_release(r)
+        torch.cuda.empty_cache()

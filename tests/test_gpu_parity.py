@@ -511,3 +511,16 @@ def test_adjoints_match_transposed_oracle_matrices(et, dev, nsmax, precision):
     e_inv, e_dir = adjoint_matrix_case(et, Oracle, dev, nsmax=nsmax, precision=precision)
     tol = 1e-12 if precision == 8 else 3e-5
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+@pytest.mark.parametrize("half,precision", [([10244, 10248, 10252, 10256, 5136, 20484], 8), ([20484, 20500, 40964, 1284], 4)])
+def test_rows_longer_than_the_lds(et, dev, half, precision):
+    """Any KLOEN (ftdir_mod.F90:67-84): rows whose Bluestein work array exceeds the 160 KiB of LDS -- in fp64 everything
+    beyond 10240 complex points, i.e. the four longest rows of TCo2559 (10244 ... 10256) -- run the passes on a global
+    scratch buffer (k_fft_inv_gm / k_fft_dir_gm) instead of returning EMI_ERR_UNSUPPORTED; mixed with rows that use
+    the specialised LDS kernels, derivatives on, against the oracle."""
+    from oracle.oracle import Oracle as O
+    nloen = np.array(half + half[::-1], dtype=np.int32)
+    e_inv, e_dir = run_case(et, O, dev, 7, nloen, 2, 3, dict(scders=True, uvder=True), 10000, precision=precision)
+    tol = TOL if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
