@@ -44,7 +44,8 @@ class _LegpolIO(C.Structure):
 
 class _Setup(C.Structure):
     _fields_ = [("ksmax", C.c_int), ("kdgl", C.c_int), ("kloen", C.POINTER(C.c_int)), ("kdlon", C.c_int),
-                ("precision", C.c_int), ("lduseflt", C.c_int), ("ldll", C.c_int), ("ldstretch", C.c_int)]
+                ("precision", C.c_int), ("lduseflt", C.c_int), ("ldll", C.c_int), ("ldstretch", C.c_int),
+                ("lduserpnm", C.c_int)]
 
 
 class _Ext(C.Structure):  # emi_extents_t
@@ -211,7 +212,7 @@ _PREC = {}  # kresol -> array dtype name of that resolution
 
 
 def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, pstret=None, precision=8,
-                cdio_legpol=None, cdlegpolfname=None, klegpolptr=None, klegpolptr_len=None):
+                cdio_legpol=None, cdlegpolfname=None, klegpolptr=None, klegpolptr_len=None, lduserpnm=False):
     """SETUP_TRANS (setup_trans.h:12-115); returns KRESOL.
 
     cdio_legpol: "writef" writes the Legendre polynomials of this setup to `cdlegpolfname`, "readf" takes
@@ -232,6 +233,7 @@ def setup_trans(ksmax, kdgl, kloen=None, kdlon=0, lduseflt=False, ldll=False, ps
             raise TransError("SETUP_TRANS: KLOEN TOO SHORT")
         cfg.kloen = keep.ctypes.data_as(C.POINTER(C.c_int))
     cfg.lduseflt, cfg.ldll = int(bool(lduseflt)), int(bool(ldll))
+    cfg.lduserpnm = int(bool(lduserpnm))  # True: Belousov's generator (the Fortran API's default); False: SUPOLF, as the benchmark
     cfg.ldstretch = int(pstret is not None and abs(pstret - 1.0) > 100 * np.finfo(float).eps)
     kresol = C.c_int(0)
     if cdio_legpol is None:

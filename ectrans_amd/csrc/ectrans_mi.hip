@@ -974,7 +974,28 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   // recurrence, supolf_mod.F90:124-142) on the host.  EMI_LEGPOL_HOST=1 computes every panel on the
   // host threads instead (the two paths agree bit for bit, tests/test_gpu_parity.py).
   // With CDIO_LEGPOL = readf / membuf every panel is taken from the file or segment instead (read_legpol_mod.F90:120-215).
-  const bool legpol_host = lp_read || (getenv("EMI_LEGPOL_HOST") && atoi(getenv("EMI_LEGPOL_HOST")));
+  const bool belousov = cfg->lduserpnm != 0 && !lp_read;  // LDUSERPNM: SUPOL per latitude on the host threads
+  const bool legpol_host = lp_read || belousov || (getenv("EMI_LEGPOL_HOST") && atoi(getenv("EMI_LEGPOL_HOST")));
+  std::vector<std::vector<double>> belpan;  // [ml] the panels [par][k][j] filled latitude by latitude
+  if (belousov) {
+    const int nmaxb = N + 1;  // INSMAX = NTMAX + 1 (suleg_mod.F90:402-410)
+    const emi::BelousovTables BT = emi::belousov_tables(nmaxb);
+    belpan.resize(NU);
+    for (int ml = 0; ml < NU; ml++) belpan[ml].assign((size_t)2 * (P.wrows[ml] / 2) * P.ldp[ml], 0.0);
+    emi::parallel_for(P.ndgnh, [&](int j) {
+      std::vector<double> pol((size_t)(nmaxb + 1) * (nmaxb + 1), 0.0);
+      emi::belousov_latitude(BT, P.rmu[j], pol.data());
+      for (int ml = 0; ml < NU; ml++) {
+        const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
+        if (j < isl0) continue;
+        const int ld = P.ldp[ml], nk = P.wrows[ml] / 2;
+        double *pan = belpan[ml].data();
+        for (int par = 0; par < 2; par++)
+          for (int k = 0; m + 2 * k + par <= N + 1; k++)
+            pan[((size_t)par * nk + k) * ld + (j - isl0)] = pol[(size_t)m * (nmaxb + 1) + (m + 2 * k + par)];
+      }
+    });
+  }
   if (emi_dev_memset(dP, 0, (size_t)P.p_elems * esz, 0) || emi_dev_memset(dPT, 0, (size_t)P.pt_elems * esz, 0)) {
     delete pp;
     return EMI_ERR_RUNTIME;
@@ -990,7 +1011,9 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       const int nmax = N + 2;
       std::vector<double> pan((size_t)2 * nk * ld, 0.0), col(nmax + 1);
       std::vector<int> corr(nmax + 1);
-      if (lp_read) {
+      if (belousov) {
+        pan.swap(belpan[ml]);
+      } else if (lp_read) {
         // reference column c holds n descending: row k of the panel (n = m + 2k + par) is column nc-1-k
         for (int par = 0; par < 2; par++) {
           const int nc = par ? (N - m + 2) / 2 : (N - m + 3) / 2;

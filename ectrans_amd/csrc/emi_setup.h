@@ -225,6 +225,91 @@ inline void legendre_column(const LegCoef &c, double mu_in, int par, double *out
 }
 
 // ---------------------------------------------------------------------------------------
+// Belousov's generator (SETUP_TRANS with LDUSERPNM=.TRUE., the default of the Fortran API): every
+// P_n^m(mu), m <= n <= nmax, of ONE latitude (supol_mod.F90:86-167): m = 0, 1 from the Fourier series
+// of the ordinary Legendre polynomials (coefficient table of suleg_mod.F90:251-263), the diagonal by
+// Belousov's equation (23), the rest by his three-term recurrence (17) with the coefficients of
+// tpm_pol.F90:43-52.  pol[m * (nmax + 1) + n].
+// ---------------------------------------------------------------------------------------
+struct BelousovTables {
+  int nmax = 0;
+  std::vector<double> fn;             // [(nmax+1)^2]  fn[n * (nmax+1) + k]: coefficient of cos(k theta) in P_n
+  std::vector<double> c17, d17, e17;  // [(nmax+1)^2]  recurrence coefficients, index m * (nmax+1) + n
+  std::vector<double> a1, h23;        // [nmax+1]      1 / sqrt(n (n+1)),  sqrt((2n+1) / (2n))
+};
+inline BelousovTables belousov_tables(int nmax) {
+  BelousovTables T;
+  T.nmax = nmax;
+  const size_t ld = (size_t)nmax + 1;
+  T.fn.assign(ld * ld, 0.0);
+  T.fn[0] = 2.0;
+  for (int n = 1; n <= nmax; n++) {
+    double top = 2.0;
+    for (int j = 1; j <= n; j++) top *= std::sqrt(1.0 - 0.25 / ((double)j * (double)j));
+    const int odd = n & 1;
+    double *row = T.fn.data() + (size_t)n * ld;
+    row[n] = top;
+    for (int j = 2; j <= n - odd; j += 2) row[n - j] = row[n - j + 2] * (double)((j - 1) * (2 * n - j + 2)) / (double)(j * (2 * n - j + 1));
+  }
+  T.c17.assign(ld * ld, 0.0);
+  T.d17.assign(ld * ld, 0.0);
+  T.e17.assign(ld * ld, 0.0);
+  for (int n = 3; n <= nmax; n++)
+    for (int m = 2; m <= n - 1; m++) {
+      const double dn = n, dm = m;
+      T.c17[(size_t)m * ld + n] = std::sqrt(((2 * dn + 1) * (dn + dm - 1) * (dn + dm - 3)) / ((2 * dn - 3) * (dn + dm) * (dn + dm - 2)));
+      T.d17[(size_t)m * ld + n] = std::sqrt(((2 * dn + 1) * (dn + dm - 1) * (dn - dm + 1)) / ((2 * dn - 1) * (dn + dm) * (dn + dm - 2)));
+      T.e17[(size_t)m * ld + n] = std::sqrt(((2 * dn + 1) * (dn - dm)) / ((2 * dn - 1) * (dn + dm)));
+    }
+  T.a1.assign(ld, 0.0);
+  T.h23.assign(ld, 0.0);
+  for (int n = 1; n <= nmax; n++) {
+    T.a1[n] = 1.0 / std::sqrt((double)n * (double)(n + 1));
+    T.h23[n] = std::sqrt((double)(2 * n + 1) / (double)(2 * n));
+  }
+  return T;
+}
+inline void belousov_latitude(const BelousovTables &T, double mu, double *pol) {
+  const int nmax = T.nmax;
+  const size_t ld = (size_t)nmax + 1;
+  double x = mu;
+  const double theta = std::acos(x);
+  double sita = std::sqrt(1.0 - x * x), rsita;
+  if (std::fabs(sita) <= std::sqrt(2.220446049250313e-16)) {  // closer than a metre to the pole
+    x = 1.0;
+    sita = 0.0;
+    rsita = 0.0;
+  } else {
+    rsita = 1.0 / sita;
+  }
+  pol[0] = 1.0;
+  // m = 0, 1: series over the cosines / sines of the same parity as n
+  for (int n = 1; n <= nmax; n++) {
+    const double *f = T.fn.data() + (size_t)n * ld;
+    const int odd = n & 1;
+    double p0 = odd ? 0.0 : 0.5 * f[0], p1 = 0.0;
+    for (int k = 2 - odd; k <= n; k += 2) {
+      p0 += f[k] * std::cos((double)k * theta);
+      p1 += T.a1[n] * f[k] * (double)k * std::sin((double)k * theta);
+    }
+    pol[n] = p0;
+    pol[ld + n] = p1;
+  }
+  // diagonal, with the reference's flush of values that have underflowed relative to 1 / sin
+  const double floor_ = rsita * 2.2250738585072014e-308;
+  for (int n = 2; n <= nmax; n++) {
+    double v = pol[(size_t)(n - 1) * ld + (n - 1)] * sita * T.h23[n];
+    if (std::fabs(v) < floor_) v = 0.0;
+    pol[(size_t)n * ld + n] = v;
+  }
+  for (int n = 3; n <= nmax; n++)
+    for (int m = 2; m <= n - 1; m++)
+      pol[(size_t)m * ld + n] = T.c17[(size_t)m * ld + n] * pol[(size_t)(m - 2) * ld + (n - 2)] -
+                                T.d17[(size_t)m * ld + n] * pol[(size_t)(m - 2) * ld + (n - 1)] * x +
+                                T.e17[(size_t)m * ld + n] * pol[(size_t)m * ld + (n - 1)] * x;
+}
+
+// ---------------------------------------------------------------------------------------
 // FFT planning
 // ---------------------------------------------------------------------------------------
 // Factor list in DIT order.  Powers of two first (radix 8, then one of 4/2), odd radices last, so

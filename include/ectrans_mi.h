@@ -64,6 +64,9 @@ typedef struct {
   /* options the reference GPU backend also refuses (gpu/external/setup_trans.F90:309,442):
    * a non-zero value returns EMI_ERR_UNSUPPORTED */
   int lduseflt, ldll, ldstretch;
+  int lduserpnm;     /* LDUSERPNM: 1 = Belousov's generator for the Legendre polynomials (supol_mod.F90; the
+                      * default of the Fortran API), 0 = the per-wavenumber recurrence SUPOLF (what the
+                      * benchmark and transi pass; computed on the device).  The two agree to ~1e-12.       */
 } emi_setup_t;
 int emi_setup(const emi_setup_t *cfg, int *kresol);
 

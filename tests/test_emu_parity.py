@@ -381,3 +381,26 @@ def test_rows_longer_than_the_lds(et):
     et.trans_release(r)
     e_inv, e_dir = run_case(et, Oracle, XP, 5, nloen, 1, 1, dict(scders=True), 3000)
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
+
+
+def test_belousov_generator_lduserpnm(et):
+    """SETUP_TRANS(LDUSERPNM=.TRUE.), the default of the Fortran API: Belousov's generator SUPOL (supol_mod.F90:86-167,
+    tpm_pol.F90:31-99) instead of the per-wavenumber SUPOLF recurrence.  Panels against the oracle's restatement of SUPOL
+    (1e-14) -- and measurably different from the SUPOLF panels (1e-13 ... 1e-12), so the switch is real -- and a
+    transform through them."""
+    N = 47
+    nloen = octahedral(N)
+    ob, of = Oracle(N, nloen, belusov=True), Oracle(N, nloen)
+    r = et.setup_trans(N, len(nloen), nloen, lduserpnm=True)
+    try:
+        e_b = e_f = 0.0
+        for m in range(N + 1):
+            for sym in (False, True):
+                a, b, c = et.legendre_panel(r, m, sym), ob.rpnm(m, sym), of.rpnm(m, sym)
+                if a.size:
+                    e_b, e_f = max(e_b, np.abs(a - b).max()), max(e_f, np.abs(a - c).max())
+        assert e_b <= 1e-14 and 1e-14 < e_f < 1e-11, (e_b, e_f)
+    finally:
+        et.trans_release(r)
+    e_inv, e_dir = run_case(et, lambda *a, **k: Oracle(*a, belusov=True, **k), XP, N, nloen, 1, 1, setup_kw=dict(lduserpnm=True))
+    assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)

@@ -524,3 +524,38 @@ def test_rows_longer_than_the_lds(et, dev, half, precision):
     e_inv, e_dir = run_case(et, O, dev, 7, nloen, 2, 3, dict(scders=True, uvder=True), 10000, precision=precision)
     tol = TOL if precision == 8 else 3e-5
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+def test_belousov_generator_lduserpnm(et, dev, golden_dir):
+    """LDUSERPNM=.TRUE. (the Fortran API's default, setup_trans.F90:231): Belousov's SUPOL as the generator of the Legendre
+    panels.  Against the oracle's SUPOL at T159 (panels 1e-14, transforms 1e-11) and against the reference's golden
+    vectors (1e-10, as test_ectrans4py.py:133-158)."""
+    to, back = dev
+    N = 159
+    nloen = octahedral(N)
+    ob = Oracle(N, nloen, belusov=True)
+    r = et.setup_trans(N, len(nloen), nloen, lduserpnm=True)
+    try:
+        for m in (0, 1, 2, 57, 158, 159):
+            for sym in (False, True):
+                a, b = et.legendre_panel(r, m, sym), ob.rpnm(m, sym)
+                assert a.shape == b.shape and np.abs(a - b).max(initial=0.0) <= 1e-14
+    finally:
+        et.trans_release(r)
+    e_inv, e_dir = run_case(et, lambda *a, **k: Oracle(*a, belusov=True, **k), dev, N, nloen, 2, 3, setup_kw=dict(lduserpnm=True))
+    assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
+    d = os.path.join(golden_dir, "tl149")
+    nl = np.load(os.path.join(d, "lon_number_by_lat.npy")).astype(np.int32)
+    sp = np.load(os.path.join(d, "tl149-c24-s1t@sp.npy"))
+    gpll = np.load(os.path.join(d, "tl149-c24-s1t@sp2gp.npy"))
+    gp_ref = np.concatenate([gpll[i, : nl[i]] for i in range(nl.size)])
+    r = et.setup_trans(148, 150, nl, lduserpnm=True)
+    try:
+        gp = to(np.zeros((1, 1, gp_ref.size)))
+        et.inv_trans(r, pspscalar=to(sp.reshape(-1, 1)), pgp=gp)
+        assert np.abs(back(gp)[0, 0] - gp_ref).max() < 1e-10
+        s2 = to(np.zeros((sp.size, 1)))
+        et.dir_trans(r, pspscalar=s2, pgp=to(gp_ref.reshape(1, 1, -1)))
+        assert np.abs(back(s2)[:, 0] - sp).max() < 1e-10
+    finally:
+        et.trans_release(r)
