@@ -379,16 +379,19 @@ def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
 
 
 def inv_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
+                ldscders=False, ldvorgp=False, lddivgp=False, lduvder=False,
                 kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
     """INV_TRANSAD (inv_transad.h:12): adjoint of INV_TRANS -- reads pgp*, writes psp* (overwritten).
     Inner products: plain sum in grid-point space, SPECNORM weights (1 for m = 0, 2 for m > 0) in
-    spectral space, as tests/trans/test_invtrans_adjoint.F90:243-315."""
+    spectral space, as tests/trans/test_invtrans_adjoint.F90:243-315.  With ldscders / ldvorgp / lddivgp / lduvder the
+    grid arrays carry the derivative / vorticity / divergence inputs in INV_TRANS's layout (inv_trans.h:66-76)."""
     a, space, keep = _Inv(), [None, real_dtype(kresol)], []
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
     nproma = int(kproma) if kproma else ngptot
     _fill_spec(a, space, keep, pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2, nspec2)
     _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, (ngptot - 1) // nproma + 1,
                (pspvor, pspdiv, pspscalar, pspsc3a, pspsc3b, pspsc2))
+    a.ldscders, a.ldvorgp, a.lddivgp, a.lduvder = int(ldscders), int(ldvorgp), int(lddivgp), int(lduvder)
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream

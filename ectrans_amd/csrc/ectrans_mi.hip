@@ -2153,7 +2153,10 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
 // DIR_TRANS, and INV_TRANSAD when adj: the adjoint of INV_TRANS is the same grid -> spectral pipeline
 // without the Gaussian weight and the 1/NLOEN (ftinvad_mod.F90:77-83: "change of metric") and with the
 // adjoint of VDTUV (= -RLAPIN x UVTVD) in place of UVTVD.
-static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
+struct AdjOpts {  // INV_TRANSAD: the options of the INV_TRANS it is the adjoint of
+  bool scders = false, vorgp = false, divgp = false, uvder = false;
+};
+static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const AdjOpts *ao = nullptr) {
   Plan *Pp = get_plan(kresol);
   if (!Pp) EMI_FAIL(EMI_ERR_STATE, "DIR_TRANS: unknown resolution %d", kresol);
   if (!ap) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS: null argument block");
@@ -2168,7 +2171,12 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
   const int nsc = (int)sc.size();
   const int nproma = a.kproma > 0 ? a.kproma : P.ngptot;
   const int ngpblks = (P.ngptot - 1) / nproma + 1;
-  const int if_gp = 2 * nuv + nsc;  // dir_trans.F90:303
+  // INV_TRANSAD with derivative / vorticity / divergence inputs: the grid arrays have INV_TRANS's layout
+  // (inv_trans.F90:352-387: [vor][div] u v scalars [N-S derivatives] [u, v E-W derivatives] [scalar E-W derivatives])
+  const bool a_scd = ao && ao->scders && nsc > 0, a_uvd = ao && ao->uvder && nuv > 0;
+  const bool a_div = ao && (ao->divgp || ao->vorgp) && nuv > 0, a_vor = ao && ao->vorgp && nuv > 0;
+  const int nvar_uv = 2 + (a_vor ? 1 : 0) + (a_div ? 1 : 0) + (a_uvd ? 2 : 0), dmul = a_scd ? 3 : 1;
+  const int if_gp = 2 * nuv + nsc + (a_scd ? 2 * nsc : 0) + (a_vor ? nuv : 0) + (a_div ? nuv : 0) + (a_uvd ? 2 * nuv : 0);  // dir_trans.F90:303
   if (a.gp) {
     if (a.gpuv || a.gp3a || a.gp3b || a.gp2) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP AND PGPUV/PGP3A/PGP3B/PGP2 CAN NOT BOTH BE PRESENT");
     if (a.gp_nfld < if_gp) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:SECOND DIMENSION OF PGP TOO SMALL (%d < %d)", a.gp_nfld, if_gp);
@@ -2180,8 +2188,8 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
     if (a.spsc3b && a.sc3b_nlev * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANS:PGP3B MISSING");
   }
   if (if_gp == 0) return EMI_SUCCESS;
-  int uv_dim3 = 2;
-  if (check_extents(adj ? "INV_TRANSAD" : "DIR_TRANS", a, P.nspec2, nproma, ngpblks, nuv, 2, 1, &uv_dim3)) return EMI_ERR_ARG;
+  int uv_dim3 = nvar_uv;
+  if (check_extents(adj ? "INV_TRANSAD" : "DIR_TRANS", a, P.nspec2, nproma, ngpblks, nuv, nvar_uv, dmul, &uv_dim3)) return EMI_ERR_ARG;
   if (set_lds_attrs()) return EMI_ERR_RUNTIME;
   if (plan_begin(P, st)) return EMI_ERR_RUNTIME;
 
@@ -2192,49 +2200,86 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
                      hs.out(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host), hs.out(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host)};
   const void *d_gp = hs.in(a.gp, gsz * a.gp_nfld, host, st);
   const void *d_gpuv = hs.in(a.gpuv, gsz * nuv * uv_dim3, host && nuv, st);
-  const void *d_gp2 = hs.in(a.gp2, gsz * a.nf_sc2, host, st);
-  const void *d_gp3a = hs.in(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar, host, st);
-  const void *d_gp3b = hs.in(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar, host, st);
+  const void *d_gp2 = hs.in(a.gp2, gsz * a.nf_sc2 * dmul, host, st);
+  const void *d_gp3a = hs.in(a.gp3a, gsz * a.sc3a_nlev * a.sc3a_nvar * dmul, host, st);
+  const void *d_gp3b = hs.in(a.gp3b, gsz * a.sc3b_nlev * a.sc3b_nvar * dmul, host, st);
   if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "DIR_TRANS: cannot stage the host arrays through device memory (%s)", emi_last_error());
 
-  // Fourier-space fields: u(nuv) v(nuv) scalars (dir_trans.F90:301, ftdir_ctl_mod.F90)
+  // Fourier-space fields: u(nuv) v(nuv) scalars (dir_trans.F90:301, ftdir_ctl_mod.F90); INV_TRANSAD with options adds
+  // the grid vorticity / divergence, the N-S derivatives of the scalars and the E-W derivatives as further fields
   std::vector<GridFld> gin;
-  int gcount = 0;
-  for (int var = 0; var < 2 && nuv; var++)
-    for (int i = 0; i < nuv; i++) {
-      GridFld g{};
-      if (d_gp) { g.base = (void *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
-      else { g.base = (void *)d_gpuv; g.nf_arr = nuv * uv_dim3; g.fidx = var * nuv + i; }
-      g.mode = GM_ACOS;
-      gin.push_back(g);
-      gcount++;
-    }
-  for (int i = 0; i < nsc; i++) {
+  int gcount = 0, uvvar = 0;
+  auto src_uv = [&](int i, int mode) {  // next u/v-shaped variable of PGP / PGPUV
     GridFld g{};
-    const ScalarRef &r = sc[i];
     if (d_gp) { g.base = (void *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
-    else if (r.arr == 1) { g.base = (void *)d_gp2; g.nf_arr = a.nf_sc2; g.fidx = r.lev; }
-    else if (r.arr == 2) { g.base = (void *)d_gp3a; g.nf_arr = a.sc3a_nlev * a.sc3a_nvar; g.fidx = r.var * a.sc3a_nlev + r.lev; }
-    else { g.base = (void *)d_gp3b; g.nf_arr = a.sc3b_nlev * a.sc3b_nvar; g.fidx = r.var * a.sc3b_nlev + r.lev; }
-    g.mode = GM_PLAIN;
-    gin.push_back(g);
+    else { g.base = (void *)d_gpuv; g.nf_arr = nuv * uv_dim3; g.fidx = uvvar * nuv + i; }
+    g.mode = mode;
     gcount++;
+    return g;
+  };
+  auto src_sc = [&](int isc, int kder, int mode) {  // scalar isc, derivative block kder (0 value, 1 N-S, 2 E-W: trltog_mod.F90:632-690)
+    GridFld g{};
+    const ScalarRef &r = sc[isc];
+    if (d_gp) { g.base = (void *)d_gp; g.nf_arr = a.gp_nfld; g.fidx = gcount; }
+    else if (r.arr == 1) { g.base = (void *)d_gp2; g.nf_arr = a.nf_sc2 * dmul; g.fidx = r.lev + kder * a.nf_sc2; }
+    else if (r.arr == 2) { g.base = (void *)d_gp3a; g.nf_arr = a.sc3a_nlev * a.sc3a_nvar * dmul; g.fidx = (r.var + kder * a.sc3a_nvar) * a.sc3a_nlev + r.lev; }
+    else { g.base = (void *)d_gp3b; g.nf_arr = a.sc3b_nlev * a.sc3b_nvar * dmul; g.fidx = (r.var + kder * a.sc3b_nvar) * a.sc3b_nlev + r.lev; }
+    g.mode = mode;
+    gcount++;
+    return g;
+  };
+  // field numbers: u_i = i, v_i = nuv + i, scalar_j = 2 nuv + j (as DIR_TRANS), then the adjoint-only inputs
+  std::vector<GridFld> g_vor, g_div, g_u, g_v, g_sc, g_ns, g_uew, g_vew, g_scew;
+  if (nuv) {
+    if (a_vor) { for (int i = 0; i < nuv; i++) g_vor.push_back(src_uv(i, GM_PLAIN)); uvvar++; }
+    if (a_div) { for (int i = 0; i < nuv; i++) g_div.push_back(src_uv(i, GM_PLAIN)); uvvar++; }
+    for (int i = 0; i < nuv; i++) g_u.push_back(src_uv(i, GM_ACOS));
+    uvvar++;
+    for (int i = 0; i < nuv; i++) g_v.push_back(src_uv(i, GM_ACOS));
+    uvvar++;
   }
-  // batches: atoms {u_i, v_i} and {scalar_j}
+  for (int i = 0; i < nsc; i++) g_sc.push_back(src_sc(i, 0, GM_PLAIN));
+  if (a_scd) for (int i = 0; i < nsc; i++) g_ns.push_back(src_sc(i, 1, GM_ACOS));
+  if (a_uvd) {
+    for (int i = 0; i < nuv; i++) g_uew.push_back(src_uv(i, GM_EWDER_UV));
+    uvvar++;
+    for (int i = 0; i < nuv; i++) g_vew.push_back(src_uv(i, GM_EWDER_UV));
+    uvvar++;
+  }
+  if (a_scd) for (int i = 0; i < nsc; i++) g_scew.push_back(src_sc(i, 2, GM_EWDER));
+  std::vector<int> i_vor(nuv, -1), i_div(nuv, -1), i_uew(nuv, -1), i_vew(nuv, -1), i_ns(nsc, -1), i_scew(nsc, -1);
+  for (auto *v : {&g_u, &g_v, &g_sc}) gin.insert(gin.end(), v->begin(), v->end());
+  auto add = [&](const std::vector<GridFld> &v, std::vector<int> &idx) {
+    for (size_t i = 0; i < v.size(); i++) {
+      idx[i] = (int)gin.size();
+      gin.push_back(v[i]);
+    }
+  };
+  add(g_vor, i_vor), add(g_div, i_div), add(g_uew, i_uew), add(g_vew, i_vew), add(g_ns, i_ns), add(g_scew, i_scew);
+  const int kf_total = (int)gin.size();
+  // batches of whole atoms: {u_i, v_i [, their adjoint-only companions]} and {scalar_j [, its N-S and E-W inputs]}
   const int natoms = nuv + nsc;
-  const int depth = pipeline_depth(P, 2 * nuv + nsc);
-  const int cap = pick_batch(P, 2 * nuv + nsc, depth);
+  const int depth = pipeline_depth(P, kf_total);
+  const int cap = pick_batch(P, kf_total, depth);
   std::vector<std::vector<int>> batches;  // Fourier field indices
   {
     std::vector<int> cur;
     for (int at = 0; at < natoms; at++) {
-      int need = at < nuv ? 2 : 1;
-      if (!cur.empty() && (int)cur.size() + need > cap) {
+      std::vector<int> fl;
+      if (at < nuv) {
+        fl = {at, nuv + at};
+        for (int x : {i_vor[at], i_div[at], i_uew[at], i_vew[at]})
+          if (x >= 0) fl.push_back(x);
+      } else {
+        fl = {2 * nuv + (at - nuv)};
+        for (int x : {i_ns[at - nuv], i_scew[at - nuv]})
+          if (x >= 0) fl.push_back(x);
+      }
+      if (!cur.empty() && (int)(cur.size() + fl.size()) > cap) {
         batches.push_back(cur);
         cur.clear();
       }
-      if (at < nuv) { cur.push_back(at); cur.push_back(nuv + at); }
-      else cur.push_back(2 * nuv + (at - nuv));
+      cur.insert(cur.end(), fl.begin(), fl.end());
     }
     if (!cur.empty()) batches.push_back(cur);
   }
@@ -2259,28 +2304,35 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj) {
       loc[b[i]] = (int)i;
       bg.push_back(gin[b[i]]);
     }
+    auto at_ = [&](int x) { return x >= 0 ? loc[x] : -1; };  // field number -> position in this batch's W
     for (size_t i = 0; i < b.size(); i++) {
       int f = b[i];
       if (f < nuv) {  // u_i -> vor_i and div_i outputs
         SpecDst v{};
         v.dst = d_vor; v.stride = a.nf_uv; v.idx = f; v.kind = adj ? SPO_VOR_AD : SPO_VOR; v.src0 = loc[f]; v.src1 = loc[nuv + f];
+        v.src2 = at_(i_uew[f]); v.src3 = at_(i_vew[f]); v.src4 = at_(i_vor[f]);
         bo.push_back(v);
-        v.dst = d_div; v.kind = adj ? SPO_DIV_AD : SPO_DIV;
+        v.dst = d_div; v.kind = adj ? SPO_DIV_AD : SPO_DIV; v.src4 = at_(i_div[f]);
         bo.push_back(v);
-      } else if (f >= 2 * nuv) {
-        const ScalarRef &r = sc[f - 2 * nuv];
+      } else if (f >= 2 * nuv && f < 2 * nuv + nsc) {
+        const int isc = f - 2 * nuv;
+        const ScalarRef &r = sc[isc];
         SpecDst sd{};
-        sd.kind = SPO_COPY; sd.src0 = (int)i;
+        sd.kind = SPO_COPY; sd.src0 = (int)i; sd.src1 = sd.src2 = sd.src3 = sd.src4 = -1;
         switch (r.arr) {
           case 0: sd.dst = d_sc[0]; sd.stride = a.nf_scalar; sd.idx = r.lev; break;
           case 1: sd.dst = d_sc[1]; sd.stride = a.nf_sc2; sd.idx = r.lev; break;
           case 2: sd.dst = (char *)d_sc[2] + (size_t)r.var * ns2 * a.sc3a_nlev * P.esz; sd.stride = a.sc3a_nlev; sd.idx = r.lev; break;
           default: sd.dst = (char *)d_sc[3] + (size_t)r.var * ns2 * a.sc3b_nlev * P.esz; sd.stride = a.sc3b_nlev; sd.idx = r.lev; break;
         }
-        if (fuse_dir)
-          bf[i] = FuseDst{sd.dst, sd.stride, sd.idx};  // written by the epilogue of k_leg_dir
-        else
+        if (a_scd) {  // value + adjoint of SPNSDE on the N-S input + (-i m) x the E-W input: k_postpack_dir
+          sd.kind = SPO_SC_AD; sd.src1 = at_(i_ns[isc]); sd.src2 = at_(i_scew[isc]);
           bo.push_back(sd);
+        } else if (fuse_dir) {
+          bf[i] = FuseDst{sd.dst, sd.stride, sd.idx};  // written by the epilogue of k_leg_dir
+        } else {
+          bo.push_back(sd);
+        }
       }
     }
     Bat bt{};
@@ -2678,8 +2730,6 @@ extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *args) { return di
 extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {
   if (!ap) EMI_FAIL(EMI_ERR_ARG, "INV_TRANSAD: null argument block");
   const emi_invtrans_t &a = *ap;
-  if (a.ldscders || a.ldvorgp || a.lddivgp || a.lduvder)
-    EMI_FAIL(EMI_ERR_UNSUPPORTED, "INV_TRANSAD: LDSCDERS/LDVORGP/LDDIVGP/LDUVDER are not supported by the adjoint");
   emi_dirtrans_t d{};
   d.mem_space = a.mem_space;
   d.spvor = (void *)a.spvor, d.spdiv = (void *)a.spdiv, d.nf_uv = a.nf_uv;
@@ -2691,7 +2741,11 @@ extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {
   d.gp = a.gp, d.gp_nfld = a.gp_nfld, d.gpuv = a.gpuv, d.gp3a = a.gp3a, d.gp3b = a.gp3b, d.gp2 = a.gp2;
   d.stream = a.stream;
   d.ext = a.ext;
-  return dir_trans_impl(kresol, &d, true);
+  // LDSCDERS / LDVORGP / LDDIVGP / LDUVDER: the grid arrays then carry the derivative / vorticity / divergence inputs in
+  // INV_TRANS's layout (ltinvad_mod.F90:149-225, spnsdead_mod.F90, fscad_mod.F90)
+  AdjOpts ao;
+  ao.scders = a.ldscders != 0, ao.vorgp = a.ldvorgp != 0, ao.divgp = a.lddivgp != 0 || a.ldvorgp != 0, ao.uvder = a.lduvder != 0;
+  return dir_trans_impl(kresol, &d, true, &ao);
 }
 // DIR_TRANSAD (include/ectrans/dir_transad.h): arguments of DIR_TRANS with the intents swapped
 extern "C" int emi_dir_transad(int kresol, const emi_dirtrans_t *ap) {

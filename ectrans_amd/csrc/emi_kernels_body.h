@@ -142,19 +142,43 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
     if (n > N) return;
     SpecDst s = flds[f];
     real2 out;
+    const real_t zkm = (real_t)m;
+    // W[row][field], with the adjoint of an east-west derivative added: the Fourier-space factor i m / (a cos) of FSC
+    // (fsc_mod.F90:163-187) has the adjoint -i m / (a cos); 1 / (a cos) was applied by k_fft_dir, -i m is applied here
+    auto wget = [&](long long rw, int fld, int fld_ew) {
+      real2 x = *(const real2 *)(W + rw * ldw + 2 * fld);
+      if (fld_ew >= 0) {
+        const real2 e = *(const real2 *)(W + rw * ldw + 2 * fld_ew);
+        x.x += zkm * e.y;  // -i m (e.x + i e.y) = m e.y - i m e.x
+        x.y -= zkm * e.x;
+      }
+      return x;
+    };
     if (s.kind == SPO_COPY) {
       out = *(const real2 *)(W + row * ldw + 2 * s.src0);
+    } else if (s.kind == SPO_SC_AD) {
+      out = wget(row, s.src0, s.src2);
+      if (s.src1 >= 0) {
+        // adjoint of SPNSDE (spnsde_mod.F90:95-114: d_n = -(n-1) e_n f_{n-1} + (n+2) e_{n+1} f_{n+1}, n = m .. N+1):
+        // f*_n = -n e_{n+1} d_{n+1} + (n+1) e_n d_{n-1}   (spnsdead_mod.F90:97-103)
+        const double *eps = g.eps + g.ebase[ml] - m;
+        const real2 dp = *(const real2 *)(W + (row + 1) * ldw + 2 * s.src1);
+        const real2 dm = (n - 1 >= m) ? *(const real2 *)(W + (row - 1) * ldw + 2 * s.src1) : mk2(0, 0);
+        const real_t a = -(real_t)n * (real_t)eps[n + 1], b = (real_t)(n + 1) * (real_t)eps[n];
+        out.x += a * dp.x + b * dm.x;
+        out.y += a * dp.y + b * dm.y;
+      }
     } else {
       const double *eps = g.eps + g.ebase[ml] - m;
       // vor: x=V (i m term), y=U ; div: x=U, y=V with opposite sign on the n-terms
       const bool isvor = (s.kind == SPO_VOR || s.kind == SPO_VOR_AD);
-      int fx = isvor ? s.src1 : s.src0;
-      int fy = isvor ? s.src0 : s.src1;
+      int fx = isvor ? s.src1 : s.src0, fxe = isvor ? s.src3 : s.src2;
+      int fy = isvor ? s.src0 : s.src1, fye = isvor ? s.src2 : s.src3;
       real_t sg = isvor ? 1.0 : -1.0;
-      real2 x0 = *(const real2 *)(W + row * ldw + 2 * fx);
-      real2 yp = *(const real2 *)(W + (row + 1) * ldw + 2 * fy);                        // n+1 (<= N+1 stored)
-      real2 ym = (n - 1 >= m) ? *(const real2 *)(W + (row - 1) * ldw + 2 * fy) : mk2(0, 0);  // n-1
-      real_t zkm = (real_t)m, c1 = (real_t)n * (real_t)eps[n + 1], c2 = (real_t)(n + 1) * (real_t)eps[n];
+      real2 x0 = wget(row, fx, fxe);
+      real2 yp = wget(row + 1, fy, fye);                                  // n+1 (<= N+1 stored)
+      real2 ym = (n - 1 >= m) ? wget(row - 1, fy, fye) : mk2(0, 0);       // n-1
+      real_t c1 = (real_t)n * (real_t)eps[n + 1], c2 = (real_t)(n + 1) * (real_t)eps[n];
       // vor_n = i m V_n - n e_{n+1} U_{n+1} + (n+1) e_n U_{n-1}
       // div_n = i m U_n + n e_{n+1} V_{n+1} - (n+1) e_n V_{n-1}
       out.x = -zkm * x0.y + sg * (-c1 * yp.x + c2 * ym.x);
@@ -162,6 +186,11 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
       if (m == 0 && n == 0) out = mk2(0, 0);  // updsp_mod.F90:113-126
       // adjoint of VDTUV (vdtuvad_mod.F90) = -RLAPIN(n) x the UVTVD stencil
       if (s.kind >= SPO_VOR_AD) out = cscale(out, -(real_t)g.lapin[n + 1]);
+      if (s.kind >= SPO_VOR_AD && s.src4 >= 0) {  // + the adjoint of the grid vorticity / divergence output (a plain copy)
+        const real2 c = *(const real2 *)(W + row * ldw + 2 * s.src4);
+        out.x += c.x;
+        out.y += c.y;
+      }
     }
     if (m == 0) out.y = 0.0;  // updspb_mod.F90:106,117
     long long isp = g.nasm0[ml] + 2LL * r;
@@ -1140,6 +1169,9 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_gm(EmiGeomDev g, FftTabDev T, FftLa
 // (ledir_mod.F90:118-124) and LDFOU2's 1/(a cos) (ldfou2_mod.F90:90-96) only depend on the
 // latitude and are folded into the same scale factor.
 // ==========================================================================================
+EMI_DEVFN real_t fft_dir_mode_scale(int mode, real_t racthe) {
+  return mode == GM_PLAIN ? (real_t)1.0 : (mode == GM_EWDER_UV ? racthe * racthe : racthe);
+}
 EMI_DEVFN void fft_dir_body(const EmiGeomDev &g, const FftTabDev &T, const FftLaunchDev &Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
                             int nproma, real2 *a) {
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
@@ -1193,7 +1225,9 @@ EMI_DEVFN void fft_dir_body(const EmiGeomDev &g, const FftTabDev &T, const FftLa
   for (int fl = 0; fl < nfl; fl++) {
     const GridFld gf = flds[f0 + fl];
     const real2 *af = a + (long long)fl * fs;
-    const real_t sc = base_scale * ((gf.mode == GM_ACOS) ? (real_t)g.racthe[lat] : (real_t)1.0);
+    // 1 / (a cos): the wind fields (LDFOU2) and, in INV_TRANSAD, the adjoints of the derivative outputs of FSC (once
+    // for the north-south and east-west derivatives of scalars, twice for the east-west derivatives of u, v)
+    const real_t sc = base_scale * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
     for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
       real2 x;
       if (!pl.cmode) {
@@ -1521,7 +1555,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
   for (int fl = 0; fl < nfl; fl++) {
   const GridFld gf = flds[f0 + fl];
   const real2 *a = (const real2 *)EMI_LDS_PTR + (long long)fl * fs;
-  const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * ((gf.mode == GM_ACOS) ? (real_t)g.racthe[lat] : (real_t)1.0);
+  const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
   for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
     const int kb = (k == 0) ? 0 : sz - k;
     real2 za = a[FPAD(k)], zb = a[FPAD(kb)];

@@ -52,11 +52,15 @@ struct SpecSrc {  // one Legendre-space input field of the inverse transform
   int sa, ia, sb, ib;
   int kind, pad_;
 };
-enum { SPO_COPY = 0, SPO_VOR = 1, SPO_DIV = 2, SPO_VOR_AD = 3, SPO_DIV_AD = 4 };  // *_AD: adjoint of VDTUV (INV_TRANSAD)
+enum { SPO_COPY = 0, SPO_VOR = 1, SPO_DIV = 2, SPO_VOR_AD = 3, SPO_DIV_AD = 4, SPO_SC_AD = 5 };  // *_AD: INV_TRANSAD
 struct SpecDst {  // one spectral output field of the direct transform
   void *dst;  // real_t array
   int stride, idx;
-  int kind, src0, src1, pad_;  // src*: field index in W (U and V for vor/div)
+  int kind, src0, src1;  // src*: field index in W (U and V for vor/div; the scalar for SPO_COPY / SPO_SC_AD)
+  // INV_TRANSAD with LDSCDERS / LDUVDER / LDVORGP / LDDIVGP (-1: absent).  SPO_VOR_AD / SPO_DIV_AD: src2, src3 = the
+  // adjoint inputs of the east-west derivatives of U and V, src4 = the grid vorticity / divergence input.
+  // SPO_SC_AD: src1 = the north-south derivative input (adjoint of SPNSDE, spnsdead_mod.F90), src2 = the east-west one.
+  int src2, src3, src4;
 };
 struct FuseDst {  // k_leg_dir epilogue: where the coefficients of one W field go (dst == NULL: to W, for k_postpack_dir)
   void *dst;      // real_t array; element (ispec) of the field = dst[ispec * stride + idx]

@@ -394,3 +394,92 @@ def adjoint_matrix_case(et, Oracle, xp, nsmax=10, seed=3, precision=8):
         return e_inv, e_dir
     finally:
         et.trans_release(r)
+
+
+def adjoint_options_case(et, Oracle, xp, nsmax=6, flags=None, seed=5, nproma=None, precision=8):
+    """INV_TRANSAD with LDSCDERS / LDVORGP / LDDIVGP / LDUVDER against the ORACLE: the dense matrix A of the oracle's
+    forward INV_TRANS with the same options -- columns (vor | div | scalar) basis vectors, rows every grid field the
+    options produce, in INV_TRANS's order (inv_trans.h:66-76) -- and A* = W^+ A^T (weights: spec_weights).  Returns the
+    error relative to the largest element."""
+    flags = flags or {}
+    to0, back0 = xp
+    dt = np.float32 if precision == 4 else np.float64
+    to = lambda a: to0(np.ascontiguousarray(a, dtype=dt))
+    back = lambda a: np.asarray(back0(a), dtype=np.float64)
+    nloen = octahedral(nsmax)
+    o = Oracle(nsmax, nloen)
+    ns2, ng = o.nspec2, o.ngptot
+    w = spec_weights(o.nasm0, nsmax, ns2)
+    winv = np.where(w > 0, 1.0 / np.maximum(w, 1e-300), 0.0)
+    eye, z = np.eye(ns2), np.zeros((ns2, ns2))
+    # forward on the basis: nuv = 2 ns2 wind "fields" (vor basis | div basis), nsc = ns2 scalar fields
+    g = o.inv_trans(spvor=np.concatenate([eye, z], axis=1), spdiv=np.concatenate([z, eye], axis=1), spsc=eye, **flags)
+    nuv, nsc = 2 * ns2, ns2
+    lv = flags.get("vorgp", False)
+    ld = flags.get("divgp", False) or lv
+    # grid field groups in INV_TRANS's order with their widths (in basis fields)
+    groups = ([("vor", nuv)] if lv else []) + ([("div", nuv)] if ld else []) + [("u", nuv), ("v", nuv), ("sc", nsc)] + \
+        ([("ns", nsc)] if flags.get("scders") else []) + ([("uew", nuv), ("vew", nuv)] if flags.get("uvder") else []) + \
+        ([("scew", nsc)] if flags.get("scders") else [])
+    assert g.shape[0] == sum(n for _, n in groups)
+    # one test field of each kind: A maps (vor, div, scalar) coefficients to the stacked grid fields
+    blocks, off = [], 0
+    for name, n in groups:
+        blk = np.zeros((ng, 3 * ns2))
+        if n == nuv:
+            blk[:, :2 * ns2] = g[off:off + n].T
+        else:
+            blk[:, 2 * ns2:] = g[off:off + n].T
+        blocks.append(blk)
+        off += n
+    A = np.concatenate(blocks)  # (ngroups * ng, 3 ns2)
+    rng = np.random.default_rng(seed)
+    y = rng.uniform(-1, 1, (len(groups), ng))
+    want = np.tile(winv, 3)[:, None] * (A.T @ y.reshape(-1, 1))
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
+    try:
+        npr = nproma or ng
+        v, d, s = (to(np.zeros((ns2, 1))) for _ in range(3))
+        et.inv_transad(r, pspvor=v, pspdiv=d, pspscalar=s, pgp=to(block(y, npr)), kproma=npr,
+                       ldscders=flags.get("scders", False), ldvorgp=lv, lddivgp=ld, lduvder=flags.get("uvder", False))
+        got = np.concatenate([back(v), back(d), back(s)])
+        return float(np.abs(got - want).max() / np.abs(want).max())
+    finally:
+        et.trans_release(r)
+
+
+def adjoint_options_call_mode2_case(et, xp, nsmax=8, seed=9, nproma=53):
+    """INV_TRANSAD with all options through the call-mode-2 arrays (PGPUV, PGP3A, PGP2 in INV_TRANS's layouts:
+    variables [vor][div] u v [u_EW v_EW]; value / N-S / E-W blocks of the scalar arrays, trltog_mod.F90:632-690) must
+    give what the same inputs give through one PGP array.  Returns the largest difference."""
+    to, back = xp
+    nloen = octahedral(nsmax)
+    r = et.setup_trans(nsmax, len(nloen), nloen)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        nlev, nvar = 2, 2
+        nsc = 1 + nvar * nlev  # sc2 (1 field) + sc3a
+        nb = (ng - 1) // nproma + 1
+        rng = np.random.default_rng(seed)
+        gpuv = rng.uniform(-1, 1, (nb, 6, nlev, nproma))       # vor div u v uew vew
+        gp3a = rng.uniform(-1, 1, (nb, 3 * nvar, nlev, nproma))  # [value vars][N-S vars][E-W vars]
+        gp2 = rng.uniform(-1, 1, (nb, 3, nproma))             # value, N-S, E-W of the one surface field
+        # the same fields in PGP order: vor div u v | scalars (sc2, then sc3a var-major) | N-S | uew vew | E-W
+        sc = lambda k: [gp2[:, k:k + 1]] + [gp3a[:, k * nvar + v] for v in range(nvar)]
+        parts = [gpuv[:, 0], gpuv[:, 1], gpuv[:, 2], gpuv[:, 3]] + sc(0) + sc(1) + [gpuv[:, 4], gpuv[:, 5]] + sc(2)
+        pgp = np.concatenate(parts, axis=1)
+        outs = []
+        for mode in (1, 2):
+            v, d = to(np.zeros((ns2, nlev))), to(np.zeros((ns2, nlev)))
+            kw = dict(ldscders=True, ldvorgp=True, lddivgp=True, lduvder=True, kproma=nproma)
+            if mode == 1:
+                s = to(np.zeros((ns2, nsc)))
+                et.inv_transad(r, pspvor=v, pspdiv=d, pspscalar=s, pgp=to(pgp), **kw)
+                outs.append(np.concatenate([back(v), back(d), back(s)], axis=1))
+            else:
+                s2, s3 = to(np.zeros((ns2, 1))), to(np.zeros((nvar, ns2, nlev)))
+                et.inv_transad(r, pspvor=v, pspdiv=d, pspsc2=s2, pspsc3a=s3, pgpuv=to(gpuv), pgp3a=to(gp3a), pgp2=to(gp2), **kw)
+                outs.append(np.concatenate([back(v), back(d), back(s2)] + [back(s3)[k] for k in range(nvar)], axis=1))
+        return float(np.abs(outs[0] - outs[1]).max() / np.abs(outs[0]).max())
+    finally:
+        et.trans_release(r)

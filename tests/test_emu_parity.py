@@ -124,15 +124,14 @@ def test_adjoint_transforms_dot_product(et, nuv, nsc, nproma):
     assert e_inv < 1e-13 and e_dir < 1e-13, (e_inv, e_dir)
 
 
-def test_adjoint_refuses_derivative_options(et):
-    nloen = octahedral(7)
-    r = et.setup_trans(7, len(nloen), nloen)
-    try:
-        a = et._Inv()
-        a.ldscders = 1
-        assert et.lib().emi_inv_transad(r, a) != 0 and b"not supported by the adjoint" in et.lib().emi_last_error()
-    finally:
-        et.trans_release(r)
+def test_adjoint_with_derivative_options_matches_transposed_oracle(et):
+    """INV_TRANSAD with LDSCDERS / LDVORGP / LDDIVGP / LDUVDER (ltinvad_mod.F90:149-225: the adjoints of SPNSDE and of FSC's
+    derivative outputs, spnsdead_mod.F90, fscad_mod.F90): against the weighted transpose of the oracle's forward INV_TRANS
+    with the same options, formed column by column at T6/O7 (tests/common.py::adjoint_options_case)."""
+    from tests.common import adjoint_options_case
+    for flags in (dict(scders=True), dict(uvder=True), dict(vorgp=True), dict(divgp=True), dict(scders=True, vorgp=True, uvder=True)):
+        e = adjoint_options_case(et, Oracle, XP, nsmax=6, flags=flags)
+        assert e < 1e-12, (flags, e)
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -404,3 +403,8 @@ def test_belousov_generator_lduserpnm(et):
         et.trans_release(r)
     e_inv, e_dir = run_case(et, lambda *a, **k: Oracle(*a, belusov=True, **k), XP, N, nloen, 1, 1, setup_kw=dict(lduserpnm=True))
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
+
+
+def test_adjoint_options_through_call_mode2_arrays(et):
+    from tests.common import adjoint_options_call_mode2_case
+    assert adjoint_options_call_mode2_case(et, XP) < 1e-14

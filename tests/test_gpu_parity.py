@@ -559,3 +559,17 @@ def test_belousov_generator_lduserpnm(et, dev, golden_dir):
         assert np.abs(back(s2)[:, 0] - sp).max() < 1e-10
     finally:
         et.trans_release(r)
+
+
+@pytest.mark.parametrize("flags", [dict(scders=True), dict(uvder=True), dict(vorgp=True), dict(scders=True, vorgp=True, uvder=True)])
+def test_adjoint_with_derivative_options_matches_transposed_oracle(et, dev, flags):
+    """INV_TRANSAD with LDSCDERS / LDVORGP / LDDIVGP / LDUVDER (ltinvad_mod.F90:149-225, spnsdead_mod.F90, fscad_mod.F90)
+    against the weighted transpose of the ORACLE's forward INV_TRANS with the same options (T8/O9, NPROMA blocks)."""
+    from tests.common import adjoint_options_case
+    e = adjoint_options_case(et, Oracle, dev, nsmax=8, flags=flags, nproma=61)
+    assert e < 1e-12, (flags, e)
+
+
+def test_adjoint_options_through_call_mode2_arrays(et, dev):
+    from tests.common import adjoint_options_call_mode2_case
+    assert adjoint_options_call_mode2_case(et, dev, nsmax=21) < 1e-14
