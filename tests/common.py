@@ -337,6 +337,7 @@ def full_size_call_mode2(et, Oracle, nsmax, nlev, nfld, precision=8, tol=1e-11, 
         return res
     finally:
         et.trans_release(r)
+        torch.cuda.empty_cache()
 
 
 def adjoint_matrix_case(et, Oracle, xp, nsmax=10, seed=3, precision=8):

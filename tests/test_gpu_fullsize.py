@@ -85,7 +85,10 @@ def test_per_latitude_row_relative_error_tco399(et):
 def test_tco2559_fp64_sets_up_and_matches_oracle(et):
     """TCo2559 in fp64 (round 1: EMI_ERR_UNSUPPORTED, its four longest rows need 196 KiB work arrays): set-up (2 x 51 GiB of
     Legendre panels) and 3 dense fields through both directions against the lazy-panel oracle."""
+    import gc
     import torch
+    gc.collect()
+    torch.cuda.empty_cache()  # the arrays of the previous tests sit in torch's caching allocator; the panels need the room
     N = 2559
     nloen = octahedral(N)
     r = et.setup_trans(N, len(nloen), nloen)
