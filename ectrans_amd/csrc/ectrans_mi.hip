@@ -41,7 +41,11 @@ extern "C" const char *emi_last_error(void) { return g_err; }
   } while (0)
 
 #ifndef EMI_CPU_EMU
+static void (*g_oom_hook)() = nullptr;  // frees what the library holds only as a cache (emi_stage.h: idle staging buffers)
 int emi_dev_malloc(void **p, size_t bytes) {
+  if (hipMalloc(p, bytes ? bytes : 16) == hipSuccess) return 0;
+  (void)hipGetLastError();
+  if (g_oom_hook) g_oom_hook();
   EMI_CHECK(hipMalloc(p, bytes ? bytes : 16));
   return 0;
 }
@@ -104,6 +108,11 @@ int emi_mem_info(size_t *f, size_t *t) {
   *t = (size_t)8 << 30;
   return 0;
 }
+#endif
+
+#include "emi_stage.h"
+#ifndef EMI_CPU_EMU
+static const bool g_oom_hook_set = (g_oom_hook = emi_stage::trim, true);
 #endif
 
 template <class T>
@@ -1208,6 +1217,7 @@ extern "C" int emi_finalize(void) {
   for (int i = 0; i < (int)G.plans.size(); i++)
     if (G.plans[i] && G.plans[i]->active) emi_release(i + 1);
   G.plans.clear();
+  emi_stage::trim();
   G.init = false;
   return EMI_SUCCESS;
 }
@@ -1395,19 +1405,19 @@ static int legpol_write(int kresol, const char *fname) {
 // ------------------------------------------------------------------------------------------
 // transforms
 // ------------------------------------------------------------------------------------------
-struct HostStage {  // staging of host arrays through device memory (mem_space == HOST)
+struct HostStage {  // staging of host arrays through device memory (mem_space == HOST): emi_stage.h
   size_t esz;
   explicit HostStage(int e) : esz((size_t)e) {}
   std::vector<void *> dev;
   bool failed = false;  // a staging buffer could not be allocated or filled: the call must not launch anything
   std::vector<std::pair<void *, std::pair<void *, size_t>>> outs;  // dev -> (host, bytes)
   ~HostStage() {
-    for (void *p : dev) emi_dev_free(p);
+    for (void *p : dev) emi_stage::release(p);
   }
   const void *in(const void *h, size_t elems, bool host, emi_stream_t s) {
     if (!h || !host) return h;
-    void *d = nullptr;
-    if (emi_dev_malloc(&d, elems * esz)) {
+    void *d = emi_stage::acquire(elems * esz);
+    if (!d) {
       failed = true;
       return nullptr;
     }
@@ -1420,8 +1430,8 @@ struct HostStage {  // staging of host arrays through device memory (mem_space =
   // leaves those elements as they were, as the reference does
   void *out(void *h, size_t elems, bool host, bool preload = false, emi_stream_t s = 0) {
     if (!h || !host) return h;
-    void *d = nullptr;
-    if (emi_dev_malloc(&d, elems * esz)) {
+    void *d = emi_stage::acquire(elems * esz);
+    if (!d) {
       failed = true;
       return nullptr;
     }
@@ -1595,7 +1605,7 @@ static int pick_batch(Plan &P, int nfields, int depth) {
   // pipelined) and EMI_MAX_BATCH; multiples of 64 fields so the 128-column tiles are full
   size_t fr = 0, tot = 0;
   emi_mem_info(&fr, &tot);
-  size_t have = fr + P.cap_W + P.cap_FBL + (P.nproc > 1 ? P.cap_FBF : 0);
+  size_t have = fr + P.cap_W + P.cap_FBL + (P.nproc > 1 ? P.cap_FBF : 0) + emi_stage::idle_bytes();
   const int nfb = depth > 1 ? 2 : 1;
   double per_field = (double)(P.wrows_total + nfb * P.frows + (P.nproc > 1 ? nfb * P.lrows : 0)) * 2.0 * P.esz;
   long long cap = (long long)((double)have * 0.85 / per_field);

@@ -484,3 +484,30 @@ def adjoint_options_call_mode2_case(et, xp, nsmax=8, seed=9, nproma=53):
         return float(np.abs(outs[0] - outs[1]).max() / np.abs(outs[0]).max())
     finally:
         et.trans_release(r)
+
+
+def staging_pool_case(et, Oracle, tol):
+    """The device-side staging buffers of host arrays are kept between calls (csrc/emi_stage.h): calls with more,
+    fewer and again more fields, with and without NPROMA padding, must each see only their own data -- a reused, larger
+    buffer holds the previous call's values behind the part this call fills."""
+    N = 8
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    o = Oracle(N, nloen)
+    ns2, ng = o.nspec2, o.ngptot
+    rng = np.random.default_rng(5)
+    try:
+        for nf, npr in ((3, ng), (1, 37), (5, ng), (2, 100), (5, 37)):
+            sp = random_spectrum(rng, o.nasm0, N, ns2, nf, False)
+            nb = (ng - 1) // npr + 1
+            gp = np.full((nb, nf, npr), -7.25)
+            et.inv_trans(r, pspscalar=sp, pgp=gp, kproma=npr)
+            got = np.concatenate([gp[b] for b in range(nb)], axis=1)[:, :ng]
+            assert rel_err(got, o.inv_trans(spsc=sp), axis=1) < tol
+            if nb * npr > ng:
+                assert np.all(gp[-1, :, ng - (nb - 1) * npr:] == -7.25)
+            back = np.full((ns2, nf), np.nan)
+            et.dir_trans(r, pspscalar=back, pgp=gp, kproma=npr)
+            assert np.abs(back - sp).max() < 1e3 * tol
+    finally:
+        et.trans_release(r)

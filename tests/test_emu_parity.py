@@ -260,6 +260,11 @@ def test_host_output_arrays_keep_unwritten_elements(et):
     et.trans_release(r)
 
 
+def test_host_staging_buffers_are_reused_between_calls(et):
+    from tests.common import staging_pool_case
+    staging_pool_case(et, Oracle, TOL)
+
+
 def test_argument_errors_mirror_abort_trans(et):
     N = 8
     nloen = octahedral(N)

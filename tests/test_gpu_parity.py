@@ -253,6 +253,13 @@ def test_host_output_arrays_keep_unwritten_elements(et):
         et.trans_release(r)
 
 
+def test_host_staging_buffers_are_reused_between_calls(et):
+    """The staging pool of csrc/emi_stage.h: calls of different sizes reuse device buffers and see only their own data."""
+    from oracle.oracle import Oracle as O
+    from tests.common import staging_pool_case
+    staging_pool_case(et, O, TOL)
+
+
 def test_field_batching_is_invisible(et, dev):
     """NPROMATR-like field packets (dir_trans_ctl_mod.F90:128-175): results must not depend on
     the batch size."""
