@@ -511,3 +511,45 @@ def staging_pool_case(et, Oracle, tol):
             assert np.abs(back - sp).max() < 1e3 * tol
     finally:
         et.trans_release(r)
+
+
+def direct_spectral_tiles_case(et, Oracle, xp, tol, nsmax=39, precision=8, nf=200, nlev=65, nvar=3, mbs=(0, 128)):
+    """Many plain-copy fields: PSPSCALAR with 200 fields (several 64-field column tiles of the Legendre kernels), then
+    call-mode-2 arrays with an odd level count (65 levels x 3 variables + winds: tiles that straddle variables, field
+    pairs that do not start on a 16-byte boundary, a tile mixing winds and scalars), in one batch and in batches.  The
+    imaginary parts of zonal wavenumber 0 are poisoned: they must not be read (prfi1b_mod.F90).  (Written for the
+    experiment in which k_leg_inv read such tiles in the caller's arrays; kept as a parity case.)"""
+    to, back = xp
+    nloen = octahedral(nsmax)
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
+    o = Oracle(nsmax, nloen)
+    ns2, ng = o.nspec2, o.ngptot
+    rng = np.random.default_rng(77)
+    dt = np.float64 if precision == 8 else np.float32
+    try:
+        sp = random_spectrum(rng, o.nasm0, nsmax, ns2, nf, False).astype(dt)
+        ref = o.inv_trans(spsc=sp.astype(np.float64))
+        bad = sp.copy()
+        bad[1:2 * (nsmax + 1):2] = 1e30  # imag(m = 0): defined to be zero, never read (prfi1b_mod.F90)
+        gp = to(np.zeros((1, nf, ng), dtype=dt))
+        et.inv_trans(r, pspscalar=to(bad), pgp=gp)
+        assert rel_err(np.asarray(back(gp), dtype=np.float64)[0], ref, axis=1) < tol
+        vor, div = (random_spectrum(rng, o.nasm0, nsmax, ns2, nlev, True).astype(dt) for _ in range(2))
+        s3 = random_spectrum(rng, o.nasm0, nsmax, ns2, nlev * nvar, False).astype(dt)
+        s2 = random_spectrum(rng, o.nasm0, nsmax, ns2, 1, False).astype(dt)
+        sc3a = np.ascontiguousarray(s3.reshape(ns2, nvar, nlev).transpose(1, 0, 2))  # C view of PSPSC3A(nlev, nspec2, nvar)
+        ref = o.inv_trans(spvor=vor.astype(np.float64), spdiv=div.astype(np.float64),
+                          spsc=np.concatenate([s3, s2], axis=1).astype(np.float64))
+        for mb in mbs:
+            et.set_max_batch(mb)
+            gpuv = to(np.zeros((1, 2, nlev, ng), dtype=dt))
+            gp3a = to(np.zeros((1, nvar, nlev, ng), dtype=dt))
+            gp2 = to(np.zeros((1, 1, ng), dtype=dt))
+            et.inv_trans(r, pspvor=to(vor), pspdiv=to(div), pspsc3a=to(sc3a), pspsc2=to(s2), pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+            got = np.concatenate([np.asarray(back(gpuv), dtype=np.float64)[0].reshape(2 * nlev, ng),
+                                  np.asarray(back(gp3a), dtype=np.float64)[0].reshape(nvar * nlev, ng),
+                                  np.asarray(back(gp2), dtype=np.float64)[0]], axis=0)
+            assert rel_err(got, ref, axis=1) < tol, mb
+    finally:
+        et.set_max_batch(0)
+        et.trans_release(r)

@@ -260,6 +260,15 @@ def test_host_staging_buffers_are_reused_between_calls(et):
     staging_pool_case(et, O, TOL)
 
 
+@pytest.mark.parametrize("precision", [8, 4])
+def test_many_plain_copy_fields_and_odd_level_counts(et, dev, precision):
+    """200 scalar fields of PSPSCALAR (imaginary parts of zonal wavenumber 0 poisoned: they are never read), then call-mode-2
+    arrays with 65 levels x 3 variables + winds, in one batch and in batches of 128 fields."""
+    from oracle.oracle import Oracle as O
+    from tests.common import direct_spectral_tiles_case
+    direct_spectral_tiles_case(et, O, dev, TOL if precision == 8 else 3e-5, nsmax=63, precision=precision)
+
+
 def test_field_batching_is_invisible(et, dev):
     """NPROMATR-like field packets (dir_trans_ctl_mod.F90:128-175): results must not depend on
     the batch size."""
