@@ -486,7 +486,7 @@ def adjoint_options_call_mode2_case(et, xp, nsmax=8, seed=9, nproma=53):
         et.trans_release(r)
 
 
-def staging_pool_case(et, Oracle, tol):
+def staging_pool_case(et, Oracle, tol, combos=((3, None), (1, 37), (5, None), (2, 100), (5, 37))):
     """The device-side staging buffers of host arrays are kept between calls (csrc/emi_stage.h): calls with more,
     fewer and again more fields, with and without NPROMA padding, must each see only their own data -- a reused, larger
     buffer holds the previous call's values behind the part this call fills."""
@@ -497,7 +497,8 @@ def staging_pool_case(et, Oracle, tol):
     ns2, ng = o.nspec2, o.ngptot
     rng = np.random.default_rng(5)
     try:
-        for nf, npr in ((3, ng), (1, 37), (5, ng), (2, 100), (5, 37)):
+        for nf, npr in combos:
+            npr = npr or ng
             sp = random_spectrum(rng, o.nasm0, N, ns2, nf, False)
             nb = (ng - 1) // npr + 1
             gp = np.full((nb, nf, npr), -7.25)

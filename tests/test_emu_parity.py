@@ -262,7 +262,7 @@ def test_host_output_arrays_keep_unwritten_elements(et):
 
 def test_host_staging_buffers_are_reused_between_calls(et):
     from tests.common import staging_pool_case
-    staging_pool_case(et, Oracle, TOL)
+    staging_pool_case(et, Oracle, TOL, combos=((3, None), (1, 37), (5, None)))
 
 
 def test_argument_errors_mirror_abort_trans(et):
@@ -406,7 +406,8 @@ def test_belousov_generator_lduserpnm(et):
         assert e_b <= 1e-14 and 1e-14 < e_f < 1e-11, (e_b, e_f)
     finally:
         et.trans_release(r)
-    e_inv, e_dir = run_case(et, lambda *a, **k: Oracle(*a, belusov=True, **k), XP, N, nloen, 1, 1, setup_kw=dict(lduserpnm=True))
+    N = 15  # the transform through Belousov panels on a smaller grid: the emulator is slow
+    e_inv, e_dir = run_case(et, lambda *a, **k: Oracle(*a, belusov=True, **k), XP, N, octahedral(N), 1, 1, setup_kw=dict(lduserpnm=True))
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
