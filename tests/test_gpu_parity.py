@@ -313,6 +313,72 @@ def test_call_mode_2(et, dev):
     et.trans_release(r)
 
 
+@pytest.mark.parametrize("nfld", [0, 10])
+@pytest.mark.parametrize("opts", ["", "scders uvders", "vordiv", "scders uvders vordiv"])
+@pytest.mark.parametrize("nproma", [0, 16])
+@pytest.mark.parametrize("callmode", [1, 2])
+def test_benchmark_option_matrix(et, dev, nfld, opts, nproma, callmode):
+    """The reference's CTest matrix of ectrans-benchmark at T47/O48 (tests/CMakeLists.txt:219-326): nfld 0 / 10 x 20 levels,
+    --scders --uvders, --vordiv, --nproma 16, call modes 1 and 2; harmonic Re(4,19) = 1 in every field, two iterations of
+    INV_TRANS + DIR_TRANS, spectral-norm drift <= 100 eps (ectrans-benchmark.F90:743-756, 847-871)."""
+    to, back = dev
+    N, nlev = 47, 20
+    scders, uvders, vordiv = "scders" in opts, "uvders" in opts, "vordiv" in opts
+    nloen = octahedral(N)
+    r = et.setup_trans(N, len(nloen), nloen)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        npr = nproma or ng
+        nb = (ng - 1) // npr + 1
+        i419 = int(et.trans_inq(r, "nasm0")[4] - 1 + 2 * 15)
+        nsc3 = nfld * nlev
+        vor, div, sc2 = to(np.zeros((ns2, nlev))), to(np.zeros((ns2, nlev))), to(np.zeros((ns2, 1)))
+        sc3 = to(np.zeros((max(nfld, 1), ns2, nlev)))  # PSPSC3A(nlev, nspec2, nfld), C order
+        for a in (vor, div, sc2):
+            a[i419] = 1.0
+        sc3[:, i419] = 1.0
+        nuvvar = 2 + (2 if vordiv else 0) + (2 if uvders else 0)
+        dmul = 3 if scders else 1
+        flags = dict(ldscders=scders, ldvorgp=vordiv, lddivgp=vordiv, lduvder=uvders, kproma=npr)
+        if callmode == 2:
+            gpuv = to(np.zeros((nb, nuvvar, nlev, npr)))
+            gp3a = to(np.zeros((nb, max(nfld, 1) * dmul, nlev, npr)))
+            gp2 = to(np.zeros((nb, dmul, npr)))
+            kw3 = dict(pspsc3a=sc3, pgp3a=gp3a) if nfld else {}
+            u0 = 2 if vordiv else 0  # PGPUV variables: [vor, div,] u, v [, u_EW, v_EW]
+        else:
+            nsc = nsc3 + 1
+            spsc = to(np.zeros((ns2, nsc)))
+            spsc[i419] = 1.0
+            gp = to(np.zeros((nb, nuvvar * nlev + nsc * dmul, npr)))
+            gd = to(np.zeros((nb, 2 * nlev + nsc, npr)))
+            u0 = 2 * nlev if vordiv else 0
+        n0 = [et.specnorm(r, vor), et.specnorm(r, div), et.specnorm(r, sc2)]
+        for _ in range(2):
+            if callmode == 2:
+                et.inv_trans(r, pspvor=vor, pspdiv=div, pspsc2=sc2, pgpuv=gpuv, pgp2=gp2, **kw3, **flags)
+                kd = dict(pspsc3a=sc3, pgp3a=gp3a[:, :nfld].contiguous()) if nfld else {}
+                et.dir_trans(r, pspvor=vor, pspdiv=div, pspsc2=sc2, pgpuv=gpuv[:, u0:u0 + 2].contiguous(), pgp2=gp2[:, :1].contiguous(),
+                             kproma=npr, **kd)
+            else:
+                et.inv_trans(r, pspvor=vor, pspdiv=div, pspscalar=spsc, pgp=gp, **flags)
+                gd[:, :2 * nlev] = gp[:, u0:u0 + 2 * nlev]  # u, v
+                s0 = u0 + 2 * nlev
+                gd[:, 2 * nlev:] = gp[:, s0:s0 + nsc]
+                et.dir_trans(r, pspvor=vor, pspdiv=div, pspscalar=spsc, pgp=gd, kproma=npr)
+        n1 = [et.specnorm(r, vor), et.specnorm(r, div), et.specnorm(r, sc2)]
+        if callmode == 1:
+            n0.append(np.full(nsc, n0[2][0]))
+            n1.append(et.specnorm(r, spsc))
+        elif nfld:
+            n0.append(np.full(nlev, n0[2][0]))
+            n1.append(et.specnorm(r, sc3[nfld - 1]))
+        for a, b in zip(n0, n1):
+            assert np.abs(np.asarray(a) / np.asarray(b) - 1.0).max() <= 100 * np.finfo(np.float64).eps
+    finally:
+        et.trans_release(r)
+
+
 @pytest.mark.parametrize("precision", [8, 4])
 def test_benchmark_harmonic_round_trips(et, dev, precision):
     """ectrans-benchmark semantics at T47/O48 (tests/CMakeLists.txt:219-326): Re(4,19)=1 in every
