@@ -91,7 +91,7 @@ def test_decomposition_invariance_and_checksum_dumps(tmp_path):
     check_invariance(res)
 
 
-@pytest.mark.parametrize("ngpus", [2, 4])
+@pytest.mark.parametrize("ngpus", [2, 4, 8])
 def test_bench_multi_rank_launch(ngpus):
     """`bench.py --gpus N` in its test configuration (EMI_BENCH_BACKEND=gloo, EMI_BENCH_ONE_GPU=1: N ranks share the one
     GPU, the exchange is staged through the host) at TCo399: the launcher, the sharded set-up, the timed loop and the
