@@ -175,8 +175,9 @@ int emi_dir_trans(int kresol, const emi_dirtrans_t *args);
  * blocks as the transforms they are the adjoints of, with the intents swapped: emi_inv_transad READS
  * the gp* arrays and WRITES the sp* arrays (it overwrites them; the reference adds to them, callers
  * zero them first -- test_invtrans_adjoint.F90:192-198), emi_dir_transad reads sp*, writes gp*.
- * The derivative / vorticity / divergence outputs of INV_TRANS have no adjoint here: those flags
- * must be 0 (EMI_ERR_UNSUPPORTED otherwise).                                                       */
+ * emi_inv_transad takes ldscders / ldvorgp / lddivgp / lduvder like INV_TRANSAD (inv_transad.h): the extra grid fields
+ * (same places as in INV_TRANS's output) are further inputs whose contributions are added to the spectral fields they
+ * derive from (spnsdead_mod.F90, fscad_mod.F90, vdtuvad_mod.F90).                                                    */
 int emi_inv_transad(int kresol, const emi_invtrans_t *args);
 int emi_dir_transad(int kresol, const emi_dirtrans_t *args);
 
