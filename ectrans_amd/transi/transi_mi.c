@@ -26,7 +26,23 @@ const char *trans_error_msg(int errcode) {
   }
 }
 
-int trans_use_mpi(_bool b) { return b ? TRANS_NOTIMPL : TRANS_SUCCESS; }
+/* Several tasks: the host attaches a transport first (emi_mpi_attach of ectrans_amd/mpi, emi_rccl_attach of
+ * ectrans_amd/rccl: they call emi_init with the task count and number and register the exchange and the host
+ * collectives); trans_init then adopts what it finds, as the Fortran shim's SETUP_TRANS0 does.  trans_use_mpi(true) is
+ * therefore only accepted once such a transport is attached (the reference: transi.h:177, MPL_INIT inside trans_init). */
+int trans_use_mpi(_bool b) {
+  int np = 0, me = 0;
+  if (!b) return TRANS_SUCCESS;
+  return emi_inq_tasks(&np, &me) == 0 ? TRANS_SUCCESS : TRANS_NOTIMPL;
+}
+/* NPRTRV / NPRGPEW (transi.h:144,156): the decomposition of this library is NPRTRW x 1; LEQ_REGIONS (transi.h:167)
+ * has no effect on it (the grid-point distribution equals the latitude bands). */
+int trans_set_nprtrv(int n) { return n == 1 ? TRANS_SUCCESS : TRANS_NOTIMPL; }
+int trans_set_nprgpew(int n) { return n == 1 ? TRANS_SUCCESS : TRANS_NOTIMPL; }
+int trans_set_leq_regions(_bool b) {
+  (void)b;
+  return TRANS_SUCCESS;
+}
 int trans_set_handles_limit(int n) {
   if (g_init) return TRANS_ERROR;
   g_limit = n;
@@ -40,6 +56,11 @@ int trans_set_radius(double r) {
 
 int trans_init(void) {
   if (g_init) return TRANS_SUCCESS;
+  int np = 0, me = 0;
+  if (emi_inq_tasks(&np, &me) == 0) { /* a transport (or the host) has initialised the library: adopt its tasks */
+    g_init = 1;
+    return TRANS_SUCCESS;
+  }
   emi_init_t cfg;
   memset(&cfg, 0, sizeof(cfg));
   cfg.kmax_resol = g_limit;
@@ -126,12 +147,15 @@ int trans_setup(struct Trans_t *t) {
   }
   if (emi_setup_legpol(&cfg, io.io ? &io : NULL, &t->handle) != 0) return TRANS_ERROR;
   t->myproc = t->nproc = 1;
+  emi_inq_tasks(&t->nproc, &t->myproc);
   emi_inq_int(t->handle, "nspec2", &t->nspec2);
   t->nspec = t->nspec2 / 2;
-  t->nspec2g = t->nspec2mx = t->nspec2;
+  emi_inq_int(t->handle, "nspec2g", &t->nspec2g);
+  emi_inq_int(t->handle, "nspec2mx", &t->nspec2mx);
   emi_inq_int(t->handle, "nump", &t->nump);
   emi_inq_int(t->handle, "ngptot", &t->ngptot);
-  t->ngptotg = t->ngptotmx = t->ngptot;
+  emi_inq_int(t->handle, "ngptotg", &t->ngptotg);
+  emi_inq_int(t->handle, "ngptotmx", &t->ngptotmx);
   return TRANS_SUCCESS;
 }
 
@@ -179,6 +203,15 @@ int trans_inquire(struct Trans_t *t, const char *varlist) {
   return TRANS_SUCCESS;
 }
 
+/* lglobal: rgp is the global field [nfld][ngptotg]; valid with one task only (transi_module.F90:1514-1527) */
+static int check_global(const struct Trans_t *t, int lglobal) {
+  if (lglobal && t->nproc != 1) {
+    fprintf(stderr, "assert_global: ERROR: Configuration only valid for nproc == 1\n");
+    return TRANS_ERROR;
+  }
+  return TRANS_SUCCESS;
+}
+
 struct DirTrans_t new_dirtrans(struct Trans_t *t) {
   struct DirTrans_t d;
   memset(&d, 0, sizeof(d));
@@ -204,8 +237,9 @@ int trans_dirtrans(struct DirTrans_t *d) {
     a.spscalar = d->rspscalar;
     a.nf_scalar = d->nscalar;
   }
-  /* lglobal: rgp is the global field [nfld][ngptotg] (transi_module.F90:1721-1728); this layer drives
-   * one task, so global == local and the call is the unblocked one */
+  /* lglobal: rgp is the global field [nfld][ngptotg] (transi_module.F90:1721-1728): one task, so global == local and
+   * the call is the unblocked one */
+  if (check_global(d->trans, d->lglobal)) return TRANS_ERROR;
   a.kproma = (d->nproma > 0 && !d->lglobal) ? d->nproma : d->trans->ngptot;
   a.gp = d->rgp;
   a.gp_nfld = 2 * d->nvordiv + d->nscalar;
@@ -240,6 +274,7 @@ int trans_invtrans(struct InvTrans_t *v) {
   a.ldscders = v->lscalarders;
   a.lduvder = v->luvder_EW;
   a.ldvorgp = a.lddivgp = v->lvordivgp;
+  if (check_global(v->trans, v->lglobal)) return TRANS_ERROR;
   a.kproma = (v->nproma > 0 && !v->lglobal) ? v->nproma : v->trans->ngptot; /* lglobal: as trans_dirtrans */
   a.gp = v->rgp;
   a.gp_nfld = 2 * v->nvordiv + v->nscalar + (v->lscalarders ? 2 * v->nscalar : 0) + (v->lvordivgp ? 2 * v->nvordiv : 0) +
@@ -265,6 +300,7 @@ int trans_dirtrans_adj(struct DirTransAdj_t *d) {
   a.mem_space = EMI_MEM_HOST;
   if (d->nvordiv > 0) a.spvor = d->rspvor, a.spdiv = d->rspdiv, a.nf_uv = d->nvordiv;
   if (d->nscalar > 0) a.spscalar = d->rspscalar, a.nf_scalar = d->nscalar;
+  if (check_global(d->trans, d->lglobal)) return TRANS_ERROR;
   a.kproma = (d->nproma > 0 && !d->lglobal) ? d->nproma : d->trans->ngptot;
   a.gp = d->rgp; /* written */
   a.gp_nfld = 2 * d->nvordiv + d->nscalar;
@@ -281,24 +317,25 @@ int trans_invtrans_adj(struct InvTransAdj_t *v) {
   if (!v->trans || !v->rgp) return TRANS_MISSING_ARG;
   if (v->nscalar > 0 && !v->rspscalar) return TRANS_MISSING_ARG;
   if (v->nvordiv > 0 && (!v->rspvor || !v->rspdiv)) return TRANS_MISSING_ARG;
-  if (v->rmeanu || v->rmeanv || v->lscalarders || v->luvder_EW || v->lvordivgp) return TRANS_NOTIMPL;
+  if (v->rmeanu || v->rmeanv) return TRANS_NOTIMPL;
+  if (check_global(v->trans, v->lglobal)) return TRANS_ERROR;
   emi_invtrans_t a;
   memset(&a, 0, sizeof(a));
   a.mem_space = EMI_MEM_HOST;
   if (v->nvordiv > 0) a.spvor = v->rspvor, a.spdiv = v->rspdiv, a.nf_uv = v->nvordiv; /* written */
   if (v->nscalar > 0) a.spscalar = v->rspscalar, a.nf_scalar = v->nscalar;
+  a.ldscders = v->lscalarders; /* the extra grid fields are further inputs (inv_transad.h) */
+  a.lduvder = v->luvder_EW;
+  a.ldvorgp = a.lddivgp = v->lvordivgp;
   a.kproma = (v->nproma > 0 && !v->lglobal) ? v->nproma : v->trans->ngptot;
   a.gp = v->rgp;
-  a.gp_nfld = 2 * v->nvordiv + v->nscalar;
+  a.gp_nfld = 2 * v->nvordiv + v->nscalar + (v->lscalarders ? 2 * v->nscalar : 0) + (v->lvordivgp ? 2 * v->nvordiv : 0) +
+              (v->luvder_EW ? 2 * v->nvordiv : 0);
   return emi_inv_transad(v->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
 }
 
-/* ---- global <-> distributed arrays (one task: re-layouts) ---- */
-static int only_task_one(const int *v, int n) {
-  for (int i = 0; v && i < n; i++)
-    if (v[i] != 1) return 0;
-  return 1;
-}
+/* ---- global <-> distributed arrays: DIST_GRID / GATH_GRID / DIST_SPEC / GATH_SPEC of the C-ABI, any task count
+ * (transi.h:499-616; nfrom / nto: the task of every field, 1-based; rgpg / rspecg hold the fields of THIS task) ---- */
 struct DistGrid_t new_distgrid(struct Trans_t *t) {
   struct DistGrid_t a;
   memset(&a, 0, sizeof(a));
@@ -329,40 +366,56 @@ struct GathSpec_t new_gathspec(struct Trans_t *t) {
 }
 int trans_distgrid(struct DistGrid_t *a) {
   if (a->count++ > 0) return TRANS_STALE_ARG;
-  if (!a->trans || !a->rgpg || !a->rgp || a->nfld <= 0 || a->nproma <= 0) return TRANS_MISSING_ARG;
-  if (!only_task_one(a->nfrom, a->nfld)) return TRANS_ERROR;
+  if (!a->trans || !a->rgp || !a->nfrom || a->nfld <= 0 || a->nproma <= 0) return TRANS_MISSING_ARG;
   const long ng = a->trans->ngptot, np = a->nproma, nb = (ng - 1) / np + 1;
   if (a->ngpblks < nb) return TRANS_ERROR;
-  for (long b = 0; b < nb; b++)
-    for (long f = 0; f < a->nfld; f++)
-      for (long i = 0; i < np; i++) {
-        long p = b * np + i;
-        a->rgp[(b * a->nfld + f) * np + i] = p < ng ? a->rgpg[f * ng + p] : 0.0;
-      }
-  return TRANS_SUCCESS;
+  return emi_dist_grid(a->trans->handle, a->rgpg, a->nfld, a->nfrom, NULL, a->nproma, a->rgp) ? TRANS_ERROR : TRANS_SUCCESS;
 }
 int trans_gathgrid(struct GathGrid_t *a) {
   if (a->count++ > 0) return TRANS_STALE_ARG;
-  if (!a->trans || !a->rgpg || !a->rgp || a->nfld <= 0 || a->nproma <= 0) return TRANS_MISSING_ARG;
-  if (!only_task_one(a->nto, a->nfld)) return TRANS_ERROR;
-  const long ng = a->trans->ngptot, np = a->nproma;
-  for (long f = 0; f < a->nfld; f++)
-    for (long p = 0; p < ng; p++) a->rgpg[f * ng + p] = a->rgp[((p / np) * a->nfld + f) * np + p % np];
-  return TRANS_SUCCESS;
+  if (!a->trans || !a->rgp || !a->nto || a->nfld <= 0 || a->nproma <= 0) return TRANS_MISSING_ARG;
+  return emi_gath_grid(a->trans->handle, a->rgpg, a->nfld, a->nto, a->nproma, a->rgp) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+/* rspecg is [nspec2g][nfldg] here (Fortran PSPECG(nfldg, nspec2g), transi.h:1140-1186), [nfldg][nspec2g] in the C-ABI */
+static int count_mine(const struct Trans_t *t, const int *task, int nfld) {
+  int n = 0;
+  for (int f = 0; f < nfld; f++) n += task[f] == t->myproc;
+  return n;
 }
 int trans_distspec(struct DistSpec_t *a) {
   if (a->count++ > 0) return TRANS_STALE_ARG;
-  if (!a->trans || !a->rspecg || !a->rspec || a->nfld <= 0) return TRANS_MISSING_ARG;
-  if (!only_task_one(a->nfrom, a->nfld)) return TRANS_ERROR;
-  memcpy(a->rspec, a->rspecg, sizeof(double) * (size_t)a->trans->nspec2 * (size_t)a->nfld); /* local order == global order */
-  return TRANS_SUCCESS;
+  if (!a->trans || !a->rspec || !a->nfrom || a->nfld <= 0) return TRANS_MISSING_ARG;
+  const int nm = count_mine(a->trans, a->nfrom, a->nfld);
+  const size_t ng = (size_t)a->trans->nspec2g;
+  double *tmp = NULL;
+  if (nm > 0) {
+    if (!a->rspecg) return TRANS_MISSING_ARG;
+    tmp = (double *)malloc(sizeof(double) * ng * (size_t)nm);
+    if (!tmp) return TRANS_ERROR;
+    for (size_t i = 0; i < ng; i++)
+      for (int f = 0; f < nm; f++) tmp[(size_t)f * ng + i] = a->rspecg[i * (size_t)nm + f];
+  }
+  const int rc = emi_dist_spec(a->trans->handle, tmp, a->nfld, a->nfrom, NULL, a->rspec);
+  free(tmp);
+  return rc ? TRANS_ERROR : TRANS_SUCCESS;
 }
 int trans_gathspec(struct GathSpec_t *a) {
   if (a->count++ > 0) return TRANS_STALE_ARG;
-  if (!a->trans || !a->rspecg || !a->rspec || a->nfld <= 0) return TRANS_MISSING_ARG;
-  if (!only_task_one(a->nto, a->nfld)) return TRANS_ERROR;
-  memcpy(a->rspecg, a->rspec, sizeof(double) * (size_t)a->trans->nspec2 * (size_t)a->nfld);
-  return TRANS_SUCCESS;
+  if (!a->trans || !a->rspec || !a->nto || a->nfld <= 0) return TRANS_MISSING_ARG;
+  const int nm = count_mine(a->trans, a->nto, a->nfld);
+  const size_t ng = (size_t)a->trans->nspec2g;
+  double *tmp = NULL;
+  if (nm > 0) {
+    if (!a->rspecg) return TRANS_MISSING_ARG;
+    tmp = (double *)malloc(sizeof(double) * ng * (size_t)nm);
+    if (!tmp) return TRANS_ERROR;
+  }
+  const int rc = emi_gath_spec(a->trans->handle, tmp, a->nfld, a->nto, a->rspec);
+  if (!rc)
+    for (size_t i = 0; i < ng; i++)
+      for (int f = 0; f < nm; f++) a->rspecg[i * (size_t)nm + f] = tmp[(size_t)f * ng + i];
+  free(tmp);
+  return rc ? TRANS_ERROR : TRANS_SUCCESS;
 }
 
 struct SpecNorm_t new_specnorm(struct Trans_t *t) {

@@ -116,7 +116,10 @@ struct SpecNorm_t {
 };
 
 const char *trans_error_msg(int errcode);
-int trans_use_mpi(_bool);          /* only false is meaningful: one task per GPU */
+int trans_use_mpi(_bool);          /* true: only once a transport is attached (ectrans_amd/mpi, ectrans_amd/rccl) */
+int trans_set_nprtrv(int);         /* 1 (transi.h:144) */
+int trans_set_nprgpew(int);        /* 1 (transi.h:156) */
+int trans_set_leq_regions(_bool);  /* accepted, no effect on this decomposition (transi.h:167) */
 int trans_set_handles_limit(int);  /* default 100 (transi_module.F90:129-136) */
 int trans_set_radius(double);      /* default 6371.22e3 (transi's own default) */
 int trans_init(void);
@@ -133,8 +136,8 @@ int trans_dirtrans(struct DirTrans_t *);
 struct InvTrans_t new_invtrans(struct Trans_t *);
 int trans_invtrans(struct InvTrans_t *);
 /* trans_distgrid / trans_gathgrid / trans_distspec / trans_gathspec (transi.h:1082-1186): global <->
- * distributed arrays.  This layer drives one task, so they are re-layouts; a task number other than 1
- * in nfrom / nto is an error. */
+ * distributed arrays over DIST_GRID / GATH_GRID / DIST_SPEC / GATH_SPEC of the C-ABI, any task count: nfrom / nto name
+ * the task (1-based) of every field; rgpg / rspecg hold the fields of THIS task, in field order. */
 struct DistGrid_t {
   const double *rgpg; /* [nfld][ngptotg] */
   double *rgp;        /* [ngpblks][nfld][nproma] */

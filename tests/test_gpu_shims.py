@@ -148,3 +148,20 @@ def test_fortran_shim_several_tasks(ntasks):
     env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     p = subprocess.run([mpiexec, "-n", str(ntasks), os.path.join(d, "test_shim_mpi")], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and p.stdout.count("FORTRAN SHIM MPI OK") == ntasks, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("ntasks", [1, 2, 3])
+def test_transi_c_api_several_tasks(ntasks):
+    """The transi-style C layer with several tasks (tests/transi/transi_test_mpi.c under mpiexec; the reference: transi
+    with TRANS_USE_MPI): trans_init adopts the attached MPI transport; trans_distspec -> trans_invtrans ->
+    trans_gathgrid -> trans_distgrid -> trans_dirtrans -> trans_gathspec between different source / target tasks
+    returns the global fields (1e-10: the octahedral grid's own truncation), trans_specnorm the global norms on every task.  Skipped without MPI."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec) or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI installation")
+    d = os.path.join(ROOT, "ectrans_amd", "transi")
+    subprocess.check_call(["make", "-s", "-C", d, "transi_test_mpi"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([mpiexec, "-n", str(ntasks), os.path.join(d, "transi_test_mpi")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and p.stdout.count("TRANSI MPI OK") == ntasks, p.stdout + p.stderr
