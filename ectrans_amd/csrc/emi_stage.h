@@ -50,14 +50,14 @@ inline void trim() {
 inline void *acquire(size_t bytes) {
   auto &v = pool();
   const size_t need = std::max(bytes, (size_t)256);
+  const size_t cap = (need + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);  // capacities are multiples of 2 MiB
   int best = -1;
   for (int i = 0; i < (int)v.size(); i++)
     if (!v[i].busy && v[i].cap >= need && (best < 0 || v[i].cap < v[best].cap)) best = i;
-  if (best >= 0 && v[best].cap <= 2 * need + ((size_t)1 << 20)) {
+  if (best >= 0 && v[best].cap <= 2 * cap) {  // not a buffer of a much larger call
     v[best].busy = true;
     return v[best].p;
   }
-  const size_t cap = (need + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
   void *p = nullptr;
   if (emi_dev_malloc(&p, cap)) return nullptr;  // (emi_dev_malloc itself retries once after trim())
   v.push_back(Buf{p, cap, true});

@@ -462,6 +462,37 @@ def test_two_resolutions_coexist(et, dev):
     et.trans_release(r2)
 
 
+def test_no_device_memory_leak_over_setup_release_cycles(et, dev):
+    """Device memory after N cycles of SETUP_TRANS / transforms (device and host arrays, two field counts) / TRANS_RELEASE
+    equals the level after the first cycle (the reference's tests/transi/transi_test_memory.c does this for the heap): panels,
+    tables, work buffers, tile maps and descriptors all go back; the staging pool of host arrays is bounded by the largest call."""
+    import torch
+    to, back = dev
+    N = 63
+    nloen = octahedral(N)
+    rng = np.random.default_rng(0)
+
+    def cycle(nf):
+        r = et.setup_trans(N, len(nloen), nloen)
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        sp = rng.uniform(-1, 1, (ns2, nf))
+        gp = np.zeros((1, nf, ng))
+        et.inv_trans(r, pspscalar=sp, pgp=gp)  # host arrays
+        et.dir_trans(r, pspscalar=sp, pgp=gp)
+        tsp, tgp = to(sp), to(gp)
+        et.inv_trans(r, pspscalar=tsp, pgp=tgp)  # device arrays
+        et.dir_trans(r, pspscalar=tsp, pgp=tgp)
+        torch.cuda.synchronize()
+        et.trans_release(r)
+        del tsp, tgp
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    levels = [cycle(70 if i % 2 else 7) for i in range(16)]
+    # a leak shrinks the free memory cycle after cycle; the HIP runtime's own pools may still grow once or twice early on
+    assert max(levels[8:]) - min(levels[8:]) == 0 and levels[0] - levels[-1] <= 64 << 20, levels
+
+
 def test_errors_on_gpu(et, dev):
     to, _ = dev
     r = et.setup_trans(21, 44, octahedral(21))
