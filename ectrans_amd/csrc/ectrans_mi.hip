@@ -2084,7 +2084,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     memcpy(hdesc.data() + bt.off_l, lt.data() + b0, (size_t)nb * sizeof(SpecSrc));
     bt.off_g = hdesc.size();
     hdesc.resize(bt.off_g + (bg.size() * sizeof(GridFld) + 255) / 256 * 256);
-    memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
+    if (!bg.empty()) memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
     bats.push_back(bt);
     b0 += nb;
   }
@@ -2351,13 +2351,13 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
     bt.no = (int)bo.size();
     bt.off_g = hdesc.size();
     hdesc.resize(bt.off_g + (bg.size() * sizeof(GridFld) + 255) / 256 * 256);
-    memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
+    if (!bg.empty()) memcpy(hdesc.data() + bt.off_g, bg.data(), bg.size() * sizeof(GridFld));
     bt.off_o = hdesc.size();
     hdesc.resize(bt.off_o + (bo.size() * sizeof(SpecDst) + 255) / 256 * 256);
-    memcpy(hdesc.data() + bt.off_o, bo.data(), bo.size() * sizeof(SpecDst));
+    if (!bo.empty()) memcpy(hdesc.data() + bt.off_o, bo.data(), bo.size() * sizeof(SpecDst));
     bt.off_f = hdesc.size();
     hdesc.resize(bt.off_f + (bf.size() * sizeof(FuseDst) + 255) / 256 * 256);
-    memcpy(hdesc.data() + bt.off_f, bf.data(), bf.size() * sizeof(FuseDst));
+    if (!bf.empty()) memcpy(hdesc.data() + bt.off_f, bf.data(), bf.size() * sizeof(FuseDst));
     bats.push_back(bt);
   }
   std::vector<LegMaps *> bmaps(nbat, nullptr);  // per batch: only the column tiles that hold fields (as INV_TRANS)
