@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence on the GPU box:  bash tools/collect_profiles.sh TAG
 # (run through gpurun; writes gpurun_out/TAG_*; copy what should be judged into profiles/)
-TAG=${1:-r2c}
+TAG=${1:-r2d}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
