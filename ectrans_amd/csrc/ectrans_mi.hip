@@ -143,6 +143,7 @@ static int upload(const std::vector<T> &h, T **d) {
 struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a workgroup size, fields per workgroup and kernel
   int nthr = 0, fbk = 0;
   int hot = 0;  // > 0: specialised kernel k_fft_*_hot<hot> (EMI_HOT_PLAN_LIST)
+  int r16 = 0;  // > 0: register-resident kernel k_fft_*_r16<r16> (EMI_R16_LIST)
   int gmem = 0;  // 1: the work array does not fit the LDS; k_fft_*_gm on a global scratch buffer (elems: complex numbers per workgroup)
   long long gm_elems = 0;
   std::vector<int> lats;
@@ -298,6 +299,7 @@ static int build_fft_plans(Plan &P) {
   struct Shared {
     int S, tw_off, perm_off, ptw_off[14];
     std::vector<int> fac;
+    int r16 = 0;
   };
   std::map<int, int> idx;            // row length -> plan
   std::map<int, int> sidx;           // work size -> shared tables
@@ -318,7 +320,24 @@ static int build_fft_plans(Plan &P) {
     std::vector<int> fac;
     pl.blue = !emi::factorize_smooth(pl.sz, fac);
     pl.S = pl.sz;
-    if (pl.blue) {
+    // Register-resident kernels (k_fft_*_r16<R1>, round 3): Bluestein rows of even length whose work length fits 256 R1,
+    // R1 from EMI_R16_LIST -- at TCo1279 every row longer than 1538 points.  EMI_FFT_R16=0 keeps the in-place LDS kernels.
+    if (pl.blue && !pl.cmode && !(getenv("EMI_FFT_R16") && atoi(getenv("EMI_FFT_R16")) == 0)) {
+      static const int r1s[] = {
+#define EMI_R16_ROW(r_) r_,
+          EMI_R16_LIST(EMI_R16_ROW)
+#undef EMI_R16_ROW
+      };
+      const char *rmin = getenv("EMI_FFT_R16_MIN");  // experiments: shortest work length that takes these kernels, in units of 256
+      for (int r : r1s)
+        if (!pl.r16 && 256 * r >= 2 * pl.sz - 1 && 256 * r >= 1024 + 512 + 1 && r >= (rmin ? atoi(rmin) : 0)) pl.r16 = r;
+      // a row short enough for a smaller work length of the in-place kernels than 256 * 8 keeps them (several fields per workgroup)
+      if (pl.r16 && 2 * pl.sz - 1 <= 1536) pl.r16 = 0;
+    }
+    if (pl.r16) {
+      pl.S = 256 * pl.r16;
+      fac.assign(1, pl.r16);  // bookkeeping only: the factor list of these kernels is R1, 16, 16 at compile time
+    } else if (pl.blue) {
       pl.S = emi::next_235(2 * pl.sz - 1);
       emi::factorize_smooth(pl.S, fac);
       // Specialised kernels (EMI_HOT_PLAN_LIST): the work length and factor list of the cheapest one that is long
@@ -363,21 +382,28 @@ static int build_fft_plans(Plan &P) {
     if (pl.S > 65535 || fac.size() > 14) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d not supported (work size %d)", n, pl.S);
     pl.nfac = (int)fac.size();
     for (int i = 0; i < pl.nfac; i++) pl.fac[i] = fac[i];
-    const int skey = pl.S * 16 + pl.nfac;  // the tables depend on the factor list: merged and plain lists differ in length
+    const int skey = pl.S * 16 + (pl.r16 ? 15 : pl.nfac);  // the tables depend on the factor list: merged and plain lists differ in length
     auto si = sidx.find(skey);
     if (si == sidx.end()) {
       Shared sh{};
       sh.S = pl.S;
       sh.fac = fac;
+      sh.r16 = pl.r16;
       sh.tw_off = (int)n_tw;
-      n_tw += pl.S;
       sh.perm_off = (int)n_perm;
+      if (pl.r16) {
+        // the digit twiddles of A1 / B1: rows 0..2 = w^(t qa), qa = 1..3; rows 3..6 = w^(4 t qb), qb = 1..4; w = exp(-2 pi i / S), t < 256
+        sh.ptw_off[0] = (int)n_ptw;
+        n_ptw += 7 * 256;
+      } else {
+      n_tw += pl.S;
       n_perm += pl.S;
       long long lenp = 1;
       for (int ip = 0; ip < pl.nfac; ip++) {
         sh.ptw_off[ip] = (int)n_ptw;
         if (lenp > 1) n_ptw += (size_t)(fac[ip] - 1) * lenp;
         lenp *= fac[ip];
+      }
       }
       si = sidx.emplace(skey, (int)shared.size()).first;
       shared.push_back(sh);
@@ -438,17 +464,24 @@ static int build_fft_plans(Plan &P) {
       }
       if (hot) nthr = nthr_rule;  // the specialised kernels are compiled for this size: EMI_FFT_THREADS only reaches the generic ones
     }
+    if (pl.r16) {  // one field per workgroup, 256 or 320 threads, one plane + the 240 small twiddles of LDS
+      hot = 0;
+      fbk = 1;
+      pl.fbk = 1;
+      nthr = 16 * pl.r16 > 256 ? roundup(16 * pl.r16, 64) : 256;
+    }
     for (int i = 0; i < pl.nfac; i++)
-      if (!hot && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
+      if (!hot && !pl.r16 && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
     int cls = -1;
     for (size_t c = 0; c < P.fclass.size(); c++)
-      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot && P.fclass[c].gmem == (gmem ? 1 : 0)) cls = (int)c;
+      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot && P.fclass[c].r16 == pl.r16 && P.fclass[c].gmem == (gmem ? 1 : 0)) cls = (int)c;
     if (cls < 0) {
       cls = (int)P.fclass.size();
       P.fclass.emplace_back();
       P.fclass[cls].nthr = nthr;
       P.fclass[cls].fbk = fbk;
       P.fclass[cls].hot = hot;
+      P.fclass[cls].r16 = pl.r16;
       P.fclass[cls].gmem = gmem ? 1 : 0;
     }
     pl.lds_class = cls;
@@ -463,6 +496,17 @@ static int build_fft_plans(Plan &P) {
   emi::parallel_for((int)shared.size(), [&](int is) {
     const Shared &sh = shared[is];
     const int S = sh.S;
+    if (sh.r16) {
+      d2 *dst = ptw.data() + sh.ptw_off[0];
+      for (int row = 0; row < 7; row++) {
+        const int mult = row < 3 ? row + 1 : 4 * (row - 2);
+        for (int t = 0; t < 256; t++) {
+          long double a = 2.0L * (long double)M_PIl * (long double)(((long long)t * mult) % S) / (long double)S;
+          *dst++ = d2{(double)cosl(a), (double)-sinl(a)};
+        }
+      }
+      return;
+    }
     for (int k = 0; k < S; k++) {
       long double a = 2.0L * (long double)M_PIl * (long double)k / (long double)S;
       tw[sh.tw_off + k] = d2{(double)cosl(a), (double)-sinl(a)};
@@ -506,7 +550,7 @@ static int build_fft_plans(Plan &P) {
     // filter b_j = conj(c_|j|) wrapped to length L; Bhat = DFT_L(b) (direct O(L*sz) sum in
     // long double: setup only, keeps the table accurate to ~1e-17), stored at the DIT positions
     const int L = pl.S, r0 = pl.fac[0];
-    const uint16_t *pm = perm.data() + pl.perm_off;
+    const uint16_t *pm = pl.r16 ? nullptr : perm.data() + pl.perm_off;
     std::vector<long double> cr(L);
     for (int k = 0; k < L; k++) cr[k] = cosl(2.0L * (long double)M_PIl * (long double)k / (long double)L);
     d2 *bh = bhat.data() + pl.bhat_off;
@@ -523,6 +567,12 @@ static int build_fft_plans(Plan &P) {
       }
       // position p = pm[k] of the DIT-ordered spectrum belongs to the middle butterfly q = p / R0 as its
       // element t = p % R0; stored [t][q] so that a wave reads its filter values coalesced
+      if (pl.r16) {
+        // k = k0 + R1 (k1 + 16 k2) sits in register k2 of thread 16 k0 + k1 of the fused middle pass: table [k2][16 k0 + k1]
+        const int k0 = k % pl.r16, kk = k / pl.r16, k1 = kk % 16, k2 = kk / 16;
+        bh[(size_t)k2 * (16 * pl.r16) + 16 * k0 + k1] = d2{(double)sr, (double)si};
+        continue;
+      }
       const int p = pm[k];
       bh[(size_t)(p % r0) * (L / r0) + p / r0] = d2{(double)sr, (double)si};
     }
@@ -533,10 +583,23 @@ static int build_fft_plans(Plan &P) {
     fc.lats.push_back(j);
     if (fc.gmem)
       fc.gm_elems = std::max(fc.gm_elems, (long long)pl.fbk * FFT_LDS_ELEMS(pl.S));
+    else if (fc.r16)
+      fc.lds = (size_t)fc.r16 * 272 * 8 + 240 * 2 * P.esz;
     else
       fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 2 * P.esz);
   }
-  void *d_tw, *d_rtw, *d_chirp, *d_bhat, *d_ptw;
+  if (getenv("EMI_DEBUG_FFT"))
+    for (const FftClass &fc : P.fclass)
+      fprintf(stderr, "emi: FFT launch group: %zu latitudes, %d threads, %d fields per workgroup, hot %d, r16 %d, gmem %d, LDS %zu bytes\n", fc.lats.size(), fc.nthr,
+              fc.fbk, fc.hot, fc.r16, fc.gmem, fc.lds);
+  // exp(-2 pi i c k1 / 256), [k1 - 1][c]: the small twiddles of k_fft_*_r16
+  std::vector<d2> tw256(15 * 16);
+  for (int k1 = 1; k1 < 16; k1++)
+    for (int c = 0; c < 16; c++) {
+      long double a = 2.0L * (long double)M_PIl * (long double)(c * k1) / 256.0L;
+      tw256[(k1 - 1) * 16 + c] = d2{(double)cosl(a), (double)-sinl(a)};
+    }
+  void *d_tw, *d_rtw, *d_chirp, *d_bhat, *d_ptw, *d_tw256;
   uint16_t *d_perm;
   FftPlanDev *d_plans;
   int *d_planid;
@@ -547,16 +610,17 @@ static int build_fft_plans(Plan &P) {
     for (size_t i = 0; i < v.size(); i++) w[i] = f2{(float)v[i].x, (float)v[i].y};
     return upload(w, (f2 **)d);
   };
-  if (upload_c(tw, &d_tw) || upload_c(ptw, &d_ptw) || upload_c(rtw, &d_rtw) || upload_c(chirp, &d_chirp) || upload_c(bhat, &d_bhat) || upload(perm, &d_perm) ||
+  if (upload_c(tw, &d_tw) || upload_c(ptw, &d_ptw) || upload_c(rtw, &d_rtw) || upload_c(chirp, &d_chirp) || upload_c(bhat, &d_bhat) || upload_c(tw256, &d_tw256) || upload(perm, &d_perm) ||
       upload(P.fplans, &d_plans) || upload(P.planid, &d_planid))
     return EMI_ERR_RUNTIME;
-  for (void *p : {d_tw, d_ptw, d_rtw, d_chirp, d_bhat, (void *)d_perm, (void *)d_plans, (void *)d_planid})
+  for (void *p : {d_tw, d_ptw, d_rtw, d_chirp, d_bhat, d_tw256, (void *)d_perm, (void *)d_plans, (void *)d_planid})
     P.dev_allocs.push_back(p);
   P.ftab.tw = d_tw;
   P.ftab.ptw = d_ptw;
   P.ftab.rtw = d_rtw;
   P.ftab.chirp = d_chirp;
   P.ftab.bhat = d_bhat;
+  P.ftab.tw256 = d_tw256;
   P.ftab.perm = d_perm;
   P.ftab.plans = d_plans;
   P.ftab.planid = d_planid;
@@ -1699,6 +1763,21 @@ static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, in
           EMI_LAUNCH(emi_f64::k_fft_dir_gm, nblocks, nthr, 0, st, P.g, P.ftab, lc, d_flds, nfld, (double *)FB, ldf, nproma, (d2 *)P.d_fftscr, fc.gm_elems);
         else
           EMI_LAUNCH(emi_f32::k_fft_dir_gm, nblocks, nthr, 0, st, P.g, P.ftab, lc, d_flds, nfld, (float *)FB, ldf, nproma, (f2 *)P.d_fftscr, fc.gm_elems);
+      }
+      continue;
+    }
+    if (fc.r16) {
+      switch (fc.r16) {
+#define EMI_R16_LAUNCH(r_)                                                                                                                  \
+  case r_:                                                                                                                                  \
+    if (inverse)                                                                                                                            \
+      EMI_LAUNCH_P(P.esz, k_fft_inv_r16<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);       \
+    else                                                                                                                                    \
+      EMI_LAUNCH_P(P.esz, k_fft_dir_r16<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);             \
+    break;
+        EMI_R16_LIST(EMI_R16_LAUNCH)
+#undef EMI_R16_LAUNCH
+        default: EMI_FAIL(EMI_ERR_RUNTIME, "internal: no k_fft_*_r16 kernel for R1 = %d", fc.r16);
       }
       continue;
     }

@@ -1570,6 +1570,527 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
 }
 
 // ==========================================================================================
+// Register-resident Bluestein kernels k_fft_dir_r16<R1> / k_fft_inv_r16<R1> (round 3): the rows whose Bluestein work
+// length is S = 256 R1, R1 in {8, 10, 12, 16, 18, 20} (TCo1279: every row longer than 1538 points), one field per
+// workgroup.  Same transform as k_fft_*_hot (FTDIR / FTINV of ftdir_mod.F90:67-84, ftinv_mod.F90:65-84 through a chirp-z
+// convolution), different machine mapping:
+//   * S = R1 * 16 * 16.  A thread keeps its points in registers through the whole chain
+//         A1 (radix R1, stride 256, 256 threads)  X  A2 (radix 16, stride 16)  L  A3 (radix 16) * filter * B3  L  B2  X  B1
+//     (A = forward DIF passes, B = inverse DIT passes; A2 .. B2 run on 16 R1 threads holding 16 points each).  The zero half of
+//     the padded row never enters A1 and the unread half of the result never leaves B1 (r16_first / r16_last).
+//   * LDS is only the exchange medium: 4 round trips per row instead of the 7 of the in-place LDS kernels, and in fp64 one REAL
+//     plane at a time (real parts, then imaginary parts), so a row needs R1 * 2176 bytes instead of R1 * 4096 and four
+//     independent 4-wave workgroups share a CU instead of two 8-wave ones.  X exchanges cross waves (workgroup barriers);
+//     L exchanges stay inside one 16-lane row of a wave (plane row `hi`), so they need no barrier at all.
+//     Plane layout: block k0 (256 points) at k0 * 272; inside an L exchange point (k1, c) of the block at 17 k1 + c: every
+//     ds_read_b64 / ds_write_b64 of the four exchanges is bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   * twiddles: w_256^(c k1) of A2 / B2 from a 240-entry LDS copy; w_S^(t k0) of A1 / B1 as w^(t qa) w^(4 t qb), k0 = qa + 4 qb,
+//     from at most 7 coalesced loads (15 table loads per pass cost more than the 9 extra complex products: tools/fft_r16_probe);
+//     tables and grid rows through buffer descriptors (one lane offset, no 64-bit vector address arithmetic, free masking of
+//     the row tail).
+// Measured in tools/fft_r16_probe.hip (S = 4096, synthetic rows): 18.7 ns per row against 28.3 ns for k_fft_dir_hot<4>.
+// ==========================================================================================
+#define R16_ROWP 272
+EMI_DEVFN constexpr int r16_threads(int R1) { return 16 * R1 > 256 ? ((16 * R1 + 63) / 64) * 64 : 256; }
+EMI_DEVFN constexpr int r16_lds_bytes(int R1) { return R1 * R16_ROWP * 8 + 240 * 2 * (int)sizeof(real_t); }
+
+// v *= exp(sgn 2 pi i J / N), J and N compile-time constants
+template <int N, int J>
+EMI_DEVFN real2 r16_cmul_w(real2 a, int sgn) {
+  constexpr real_t c8[4] = {1.0, 0.707106781186547524401, 0.0, -0.707106781186547524401};
+  constexpr real_t s8[4] = {0.0, 0.707106781186547524401, 1.0, 0.707106781186547524401};
+  constexpr real_t c10[5] = {1.0, 0.809016994374947424102, 0.309016994374947424102, -0.309016994374947424102, -0.809016994374947424102};
+  constexpr real_t s10[5] = {0.0, 0.587785252292473129169, 0.951056516295153572116, 0.951056516295153572116, 0.587785252292473129169};
+  constexpr real_t c12[6] = {1.0, 0.866025403784438646764, 0.5, 0.0, -0.5, -0.866025403784438646764};
+  constexpr real_t s12[6] = {0.0, 0.5, 0.866025403784438646764, 1.0, 0.866025403784438646764, 0.5};
+  constexpr real_t c16[8] = {1.0, 0.923879532511286756128, 0.707106781186547524401, 0.382683432365089771728, 0.0, -0.382683432365089771728,
+                             -0.707106781186547524401, -0.923879532511286756128};
+  constexpr real_t s16[8] = {0.0, 0.382683432365089771728, 0.707106781186547524401, 0.923879532511286756128, 1.0, 0.923879532511286756128,
+                             0.707106781186547524401, 0.382683432365089771728};
+  constexpr real_t c18[9] = {1.0, 0.939692620785908384054, 0.766044443118978035202, 0.5, 0.173648177666930348852, -0.173648177666930348852,
+                             -0.5, -0.766044443118978035202, -0.939692620785908384054};
+  constexpr real_t s18[9] = {0.0, 0.342020143325668733044, 0.642787609686539326323, 0.866025403784438646764, 0.984807753012208059367,
+                             0.984807753012208059367, 0.866025403784438646764, 0.642787609686539326323, 0.342020143325668733044};
+  constexpr real_t c20[10] = {1.0, 0.951056516295153572116, 0.809016994374947424102, 0.587785252292473129169, 0.309016994374947424102, 0.0,
+                              -0.309016994374947424102, -0.587785252292473129169, -0.809016994374947424102, -0.951056516295153572116};
+  constexpr real_t s20[10] = {0.0, 0.309016994374947424102, 0.587785252292473129169, 0.809016994374947424102, 0.951056516295153572116, 1.0,
+                              0.951056516295153572116, 0.809016994374947424102, 0.587785252292473129169, 0.309016994374947424102};
+  static_assert(J >= 0 && 2 * J < N, "r16_cmul_w: first half of the circle only");
+  if constexpr (J == 0) {
+    return a;
+  } else if constexpr (4 * J == N) {
+    return cmuli(mk2(a.x * (real_t)sgn, a.y * (real_t)sgn));  // sgn i a; sgn = +-1 is a compile-time constant at every call
+  } else {
+    constexpr real_t c = (N == 8) ? c8[J % 4] : (N == 10) ? c10[J % 5] : (N == 12) ? c12[J % 6] : (N == 16) ? c16[J % 8] : (N == 18) ? c18[J % 9] : c20[J % 10];
+    constexpr real_t s = (N == 8) ? s8[J % 4] : (N == 10) ? s10[J % 5] : (N == 12) ? s12[J % 6] : (N == 16) ? s16[J % 8] : (N == 18) ? s18[J % 9] : s20[J % 10];
+    const real_t sn = s * (real_t)sgn;
+    return mk2(a.x * c - a.y * sn, a.x * sn + a.y * c);
+  }
+}
+
+// dst[J] = (ADD ? add[J] : 0) + src[J] W_N^(sgn J) for J = J0 .. H-1 (compile-time recursion: the twiddles are template constants)
+template <int N, int J, int H, int ADD>
+EMI_DEVFN void r16_tw_each(real2 *dst, const real2 *src, const real2 *add, int sgn) {
+  if constexpr (J < H) {
+    const real2 m = r16_cmul_w<N, J>(src[J], sgn);
+    dst[J] = ADD ? cadd(add[J], m) : m;
+    r16_tw_each<N, J + 1, H, ADD>(dst, src, add, sgn);
+  }
+}
+// radix 16, natural order in and out: Y[k] = sum_a x[a] W16^(a k), a = 4 a1 + a0, k = k1 + 4 k0
+EMI_DEVFN void r16_bf16(real2 *v, int sgn) {
+#pragma unroll
+  for (int a0 = 0; a0 < 4; a0++) bf4(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12], sgn);  // -> u[a0][k1] at a0 + 4 k1
+  v[5] = r16_cmul_w<16, 1>(v[5], sgn);
+  v[6] = r16_cmul_w<16, 2>(v[6], sgn);
+  v[7] = r16_cmul_w<16, 3>(v[7], sgn);
+  v[9] = r16_cmul_w<16, 2>(v[9], sgn);
+  v[10] = r16_cmul_w<16, 4>(v[10], sgn);
+  v[11] = r16_cmul_w<16, 6>(v[11], sgn);
+  v[13] = r16_cmul_w<16, 3>(v[13], sgn);
+  v[14] = r16_cmul_w<16, 6>(v[14], sgn);
+  {  // W16^9 = -W16^1
+    const real2 m = r16_cmul_w<16, 1>(v[15], sgn);
+    v[15] = mk2(-m.x, -m.y);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) bf4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3], sgn);  // -> Y[k1 + 4 k0] at 4 k1 + k0
+  real2 y[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) y[(j >> 2) + 4 * (j & 3)] = v[j];
+#pragma unroll
+  for (int j = 0; j < 16; j++) v[j] = y[j];
+}
+// first pass of the zero-padded convolution: radix R1 of (v[0 .. R1/2-1], 0, ..., 0) -> v[0 .. R1-1].
+// a = (R1/2) a1 + a0 with a1 = 1 zero: Y[k1 + 2 k'] = DFT_{R1/2}( x[a0] W_R1^(a0 k1) )[k']
+template <int R1>
+EMI_DEVFN void r16_first(real2 *v, int sgn) {
+  constexpr int H = R1 / 2;
+  real2 e[H], o[H];
+#pragma unroll
+  for (int a0 = 0; a0 < H; a0++) e[a0] = v[a0];
+  r16_tw_each<R1, 0, H, 0>(o, v, nullptr, sgn);
+  butterfly<H>(e, nullptr, 0, sgn);
+  butterfly<H>(o, nullptr, 0, sgn);
+#pragma unroll
+  for (int k = 0; k < H; k++) v[2 * k] = e[k], v[2 * k + 1] = o[k];
+}
+// last pass, of which only the outputs k < R1/2 are read: a = 2 a' + a1, Y[k] = E[k] + W_R1^k O[k]
+template <int R1>
+EMI_DEVFN void r16_last(real2 *v, int sgn) {
+  constexpr int H = R1 / 2;
+  real2 e[H], o[H];
+#pragma unroll
+  for (int a = 0; a < H; a++) e[a] = v[2 * a], o[a] = v[2 * a + 1];
+  butterfly<H>(e, nullptr, 0, sgn);
+  butterfly<H>(o, nullptr, 0, sgn);
+  r16_tw_each<R1, 0, H, 1>(v, o, e, sgn);
+}
+
+// The convolution chain of one row.  In: v[a] = u[t + 256 a], a < R1/2 (threads t < 256), the chirped row.  Out: v[a] = (u * b)[t + 256 a],
+// unscaled (S times the circular convolution with the filter whose spectrum is behind b_bh; CONJB: with its conjugate).
+// `lds`: the plane (R1 * 272 * 8 bytes; no other use between entry and exit), tw2s: the LDS copy of w_256^(c k1).
+template <int R1, int CONJB>
+EMI_DEVFN void r16_conv(real2 *vio, const unsigned t, const EmiBuf &b_tw, const EmiBuf &b_bh, char *lds, const real2 *tw2s) {
+  constexpr int H = R1 / 2, NMID = 16 * R1, NT = r16_threads(R1);
+  constexpr bool PL = sizeof(real_t) == 8;  // fp64: one real plane at a time; fp32: a complex number is 8 bytes, one phase
+  constexpr unsigned SZ2 = sizeof(real2);
+  const unsigned hi = t >> 4, lo = t & 15;
+  const bool edge = (NT == 256) ? true : (t < 256u), mid = (NMID == NT) ? true : (t < (unsigned)NMID);
+  real_t *pr = (real_t *)lds;
+  real2 *pc = (real2 *)lds;
+  // Between the phases the points live in separate real / imaginary scalars: a real2 that crosses a branch is a 4-register
+  // tuple even when only one half is alive (the other half already written to the plane), which at R1 = 18, 20 spilled
+  real_t vx[R1], vy[R1], wx[16], wy[16];
+#define R16_PACK(dst_, x_, y_, n_) \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n_); i_++) dst_[i_] = mk2(x_[i_], y_[i_])
+#define R16_UNPACK(x_, y_, src_, n_) \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n_); i_++) x_[i_] = src_[i_].x, y_[i_] = src_[i_].y
+  // ---- A1: radix R1 over a, then w_S^(t k0) = w^(t qa) w^(4 t qb), k0 = qa + 4 qb: two loads (w^t, w^4t), the other digits by
+  // products (one or two more rounding errors of 1e-16 each) -- fewer registers held across the butterfly than a table row per digit
+  if (edge) {
+    real2 v[R1];
+#pragma unroll
+    for (int a = 0; a < H; a++) v[a] = vio[a];
+    r16_first<R1>(v, -1);
+    EMI_SCHED_FENCE();  // the twiddle loads stay behind the butterfly: with R1 = 18, 20 its 4 R1 data registers leave no room for them
+    const real2 w1 = emi_buf_ld<real2>(b_tw, t * SZ2, 0), w4 = emi_buf_ld<real2>(b_tw, t * SZ2, 3u * 256u * SZ2);
+    const real2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+    real2 wq = w4;  // w^(4 t qb)
+#pragma unroll
+    for (int k0 = 1; k0 < R1; k0++) {
+      const int qa = k0 & 3, qb = k0 >> 2;
+      if (qa == 0 && qb > 1) wq = cmul(wq, w4);
+      const real2 wa = (qa == 1) ? w1 : (qa == 2) ? w2 : w3;
+      v[k0] = cmul(v[k0], qb == 0 ? wa : (qa == 0 ? wq : cmul(wa, wq)));
+    }
+    R16_UNPACK(vx, vy, v, R1);
+  }
+  // ---- X1: thread t, block k0 -> thread (hi = k0, lo = c), slot b = t >> 4
+  if constexpr (PL) {
+    if (edge) {
+#pragma unroll
+      for (int k0 = 0; k0 < R1; k0++) pr[k0 * R16_ROWP + t] = vx[k0];
+    }
+    EMI_LDS_SYNC();
+    if (mid) {
+#pragma unroll
+      for (int b = 0; b < 16; b++) wx[b] = pr[hi * R16_ROWP + 16 * b + lo];
+    }
+    EMI_LDS_SYNC();
+    if (edge) {
+#pragma unroll
+      for (int k0 = 0; k0 < R1; k0++) pr[k0 * R16_ROWP + t] = vy[k0];
+    }
+    EMI_LDS_SYNC();
+    if (mid) {
+#pragma unroll
+      for (int b = 0; b < 16; b++) wy[b] = pr[hi * R16_ROWP + 16 * b + lo];
+    }
+  } else {
+    if (edge) {
+#pragma unroll
+      for (int k0 = 0; k0 < R1; k0++) pc[k0 * R16_ROWP + t] = mk2(vx[k0], vy[k0]);
+    }
+    EMI_LDS_SYNC();
+    if (mid) {
+#pragma unroll
+      for (int b = 0; b < 16; b++) {
+        const real2 q = pc[hi * R16_ROWP + 16 * b + lo];
+        wx[b] = q.x, wy[b] = q.y;
+      }
+    }
+  }
+  // ---- A2 in thread (k0 = hi, c = lo): radix 16 over b, then w_256^(c k1)
+  if (mid) {
+    real2 w[16];
+    R16_PACK(w, wx, wy, 16);
+    r16_bf16(w, -1);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++) w[k1] = cmul(w[k1], tw2s[(k1 - 1) * 16 + lo]);
+    R16_UNPACK(wx, wy, w, 16);
+  }
+  // ---- L1: thread (k0, c), value k1 -> thread (k0, k1), slot c.  Row hi of the plane belongs to this 16-lane row alone.
+  if constexpr (PL) {
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) pr[hi * R16_ROWP + 17 * k1 + lo] = wx[k1];
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) wx[c] = pr[hi * R16_ROWP + 17 * lo + c];
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) pr[hi * R16_ROWP + 17 * k1 + lo] = wy[k1];
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) wy[c] = pr[hi * R16_ROWP + 17 * lo + c];
+    }
+  } else {
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) pc[hi * R16_ROWP + 17 * k1 + lo] = mk2(wx[k1], wy[k1]);
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const real2 q = pc[hi * R16_ROWP + 17 * lo + c];
+        wx[c] = q.x, wy[c] = q.y;
+      }
+    }
+  }
+  // ---- A3 (over c), filter, B3 (over k2) in thread (k0, k1) = t, then conj w_256^(c k1) for B2
+  if (mid) {
+    real2 w[16];
+    R16_PACK(w, wx, wy, 16);
+    r16_bf16(w, -1);  // w[k2]: spectrum at k0 + R1 (k1 + 16 k2)
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+      const real2 b = emi_buf_ld<real2>(b_bh, t * SZ2, (unsigned)k2 * (unsigned)NMID * SZ2);  // table [k2][t]
+      w[k2] = CONJB ? cmulc(w[k2], b) : cmul(w[k2], b);
+    }
+    r16_bf16(w, +1);  // w[c]
+#pragma unroll
+    for (int c = 1; c < 16; c++) w[c] = cmulc(w[c], tw2s[(c - 1) * 16 + lo]);
+    R16_UNPACK(wx, wy, w, 16);
+  }
+  // ---- L2: thread (k0, k1), value c -> thread (k0, c), slot k1
+  if constexpr (PL) {
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) pr[hi * R16_ROWP + 17 * lo + c] = wx[c];
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) wx[k1] = pr[hi * R16_ROWP + 17 * k1 + lo];
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) pr[hi * R16_ROWP + 17 * lo + c] = wy[c];
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) wy[k1] = pr[hi * R16_ROWP + 17 * k1 + lo];
+    }
+  } else {
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) pc[hi * R16_ROWP + 17 * lo + c] = mk2(wx[c], wy[c]);
+    }
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) {
+        const real2 q = pc[hi * R16_ROWP + 17 * k1 + lo];
+        wx[k1] = q.x, wy[k1] = q.y;
+      }
+    }
+  }
+  // ---- B2 in thread (k0, c): radix 16 over k1 -> b
+  if (mid) {
+    real2 w[16];
+    R16_PACK(w, wx, wy, 16);
+    r16_bf16(w, +1);
+    R16_UNPACK(wx, wy, w, 16);
+  }
+  // ---- X2: thread (k0, c), value b -> thread t = 16 b + c, slot k0
+  if constexpr (PL) {
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int b = 0; b < 16; b++) pr[hi * R16_ROWP + 16 * b + lo] = wx[b];
+    }
+    EMI_LDS_SYNC();
+    if (edge) {
+#pragma unroll
+      for (int k0 = 0; k0 < R1; k0++) vx[k0] = pr[k0 * R16_ROWP + t];
+    }
+    EMI_LDS_SYNC();
+    if (mid) {
+#pragma unroll
+      for (int b = 0; b < 16; b++) pr[hi * R16_ROWP + 16 * b + lo] = wy[b];
+    }
+    EMI_LDS_SYNC();
+    if (edge) {
+#pragma unroll
+      for (int k0 = 0; k0 < R1; k0++) vy[k0] = pr[k0 * R16_ROWP + t];
+    }
+  } else {
+    EMI_WAVE_FENCE();
+    if (mid) {
+#pragma unroll
+      for (int b = 0; b < 16; b++) pc[hi * R16_ROWP + 16 * b + lo] = mk2(wx[b], wy[b]);
+    }
+    EMI_LDS_SYNC();
+    if (edge) {
+#pragma unroll
+      for (int k0 = 0; k0 < R1; k0++) {
+        const real2 q = pc[k0 * R16_ROWP + t];
+        vx[k0] = q.x, vy[k0] = q.y;
+      }
+    }
+  }
+  // ---- B1 in thread t: conj w_S^(t k0), radix R1 over k0 -> a < R1/2
+  if (edge) {
+    real2 v[R1];
+    R16_PACK(v, vx, vy, R1);
+    const real2 w1 = emi_buf_ld<real2>(b_tw, t * SZ2, 0), w4 = emi_buf_ld<real2>(b_tw, t * SZ2, 3u * 256u * SZ2);
+    const real2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+    real2 wq = w4;
+#pragma unroll
+    for (int k0 = 1; k0 < R1; k0++) {
+      const int qa = k0 & 3, qb = k0 >> 2;
+      if (qa == 0 && qb > 1) wq = cmul(wq, w4);
+      const real2 wa = (qa == 1) ? w1 : (qa == 2) ? w2 : w3;
+      v[k0] = cmulc(v[k0], qb == 0 ? wa : (qa == 0 ? wq : cmul(wa, wq)));
+    }
+    EMI_SCHED_FENCE();
+    r16_last<R1>(v, +1);
+#pragma unroll
+    for (int a = 0; a < H; a++) vio[a] = v[a];
+  }
+#undef R16_PACK
+#undef R16_UNPACK
+}
+
+template <int R1>
+EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+                                                   int nproma) {
+  constexpr int H = R1 / 2, NT = r16_threads(R1), S = 256 * R1;
+  constexpr unsigned SZ2 = sizeof(real2);
+  EMI_LDS_DECL;
+  char *lds = EMI_LDS_PTR;
+  real2 *tw2s = (real2 *)(lds + R1 * R16_ROWP * 8), *zbuf = (real2 *)lds;
+  const unsigned t = (unsigned)EMI_TID;
+  const bool edge = (NT == 256) ? true : (t < 256u);
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = bid / Lc.nchunk;
+  const int lat = Lc.lats[li];
+  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const int f0 = bid - li * Lc.nchunk;  // one field per workgroup
+  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
+  const int fb0 = g.fbase[lat];
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
+  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
+  const EmiBuf b_ch = emi_buf((const real2 *)T.chirp + pl.chirp_off, (unsigned)sz * SZ2);
+  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + pl.ptw_off[0], 7u * 256u * SZ2);
+  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + pl.bhat_off, (unsigned)S * SZ2);
+  if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
+  const GridFld gf = flds[f0];
+  // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp; l = t + 256 a
+  real2 v[H];
+  if (edge) {
+    const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
+    const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
+    if (flat) {  // whole row inside one NPROMA block and 2-element aligned (uniform): the row is one buffer, its tail reads as zero
+      const EmiBuf b_in = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned off = (t + 256u * a) * SZ2;
+        v[a] = cmul(emi_buf_ld<real2>(b_in, off, 0), emi_buf_ld<real2>(b_ch, off, 0));
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned lz = t + 256u * a;
+        real2 z = mk2(0, 0);
+        if (lz < (unsigned)sz) {
+          if (grid_pair_ok(gr, 2u * lz)) {
+            z = *(const real2 *)grid_ptr(gr, 2u * lz);
+          } else {
+            z.x = *grid_ptr(gr, 2u * lz);
+            z.y = *grid_ptr(gr, 2u * lz + 1);
+          }
+        }
+        v[a] = cmul(z, emi_buf_ld<real2>(b_ch, lz * SZ2, 0));
+      }
+    }
+  }
+  r16_conv<R1, 0>(v, t, b_tw, b_bh, lds, tw2s);
+  // Z_i = conv_i chirp_i / S, i < sz, to LDS (complex, natural order: sz <= S/2 of them fit the plane)
+  EMI_LDS_SYNC();  // every thread has read its last plane values
+  if (edge) {
+    const real_t invL = (real_t)(1.0 / (double)S);
+#pragma unroll
+    for (int a = 0; a < H; a++) {
+      const unsigned i = t + 256u * a;
+      zbuf[i] = cscale(cmul(v[a], emi_buf_ld<real2>(b_ch, i * SZ2, 0)), invL);  // i >= sz: zero chirp, never read
+    }
+  }
+  EMI_LDS_SYNC();
+  // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
+  const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
+  for (int k = (int)t; k <= nmen; k += NT) {
+    const int kb = (k == 0) ? 0 : sz - k;
+    const real2 za = zbuf[k], zb = zbuf[kb];
+    const real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
+    const real2 tt = cmuli(cmul(rtw[k], d1));
+    const real2 x = mk2((real_t)0.5 * (s1.x - tt.x), (real_t)0.5 * (s1.y - tt.y));
+    *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * f0) = cscale(x, sc);
+  }
+}
+
+template <int R1>
+EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+                                                   int ldf, int nproma) {
+  constexpr int H = R1 / 2, NT = r16_threads(R1), S = 256 * R1;
+  constexpr unsigned SZ2 = sizeof(real2);
+  EMI_LDS_DECL;
+  char *lds = EMI_LDS_PTR;
+  real2 *tw2s = (real2 *)(lds + R1 * R16_ROWP * 8), *zbuf = (real2 *)lds;
+  const unsigned t = (unsigned)EMI_TID;
+  const bool edge = (NT == 256) ? true : (t < 256u);
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = bid / Lc.nchunk;
+  const int lat = Lc.lats[li];
+  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const int f0 = bid - li * Lc.nchunk;
+  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
+  const real_t racthe = (real_t)g.racthe[lat];
+  const real_t adjw = (real_t)(g.rw[lat] / (double)pl.n);  // DIR_TRANSAD only (Lc.adj)
+  const int fb0 = g.fbase[lat];
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
+  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
+  const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
+  const EmiBuf b_ch = emi_buf(chirp, (unsigned)sz * SZ2);
+  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + pl.ptw_off[0], 7u * 256u * SZ2);
+  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + pl.bhat_off, (unsigned)S * SZ2);
+  if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
+  const GridFld gf = flds[f0];
+  // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times conj(chirp), to LDS
+  {
+    const int npair = sz / 2 + 1;
+    for (int k = (int)t; k < npair; k += NT) {
+      const int k2 = sz - k;
+      real2 xa = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
+      real2 xb = (k2 <= nmen) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
+      if (Lc.adj) xa = cscale(xa, adjw), xb = cscale(xb, adjw);
+      const real2 wk = cconj(rtw[k]);
+      const real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
+      const real2 zk = cadd(s1, cmuli(cmul(wk, d1)));
+      zbuf[k] = cmulc(zk, chirp[k]);
+      if (k2 != k && k2 < sz) {
+        const real2 s2 = cadd(xb, cconj(xa)), d2_ = csub(xb, cconj(xa));
+        const real2 zk2 = cadd(s2, cmuli(cmul(mk2(-wk.x, wk.y), d2_)));
+        zbuf[k2] = cmulc(zk2, chirp[k2]);
+      }
+    }
+  }
+  EMI_LDS_SYNC();
+  real2 v[H];
+  if (edge) {
+#pragma unroll
+    for (int a = 0; a < H; a++) {
+      const unsigned l = t + 256u * a;
+      v[a] = (l < (unsigned)sz) ? zbuf[l] : mk2(0, 0);
+    }
+  }
+  EMI_LDS_SYNC();  // the plane is free for the exchanges
+  r16_conv<R1, 1>(v, t, b_tw, b_bh, lds, tw2s);
+  // stage 3 (TRLTOG local copy): z_i = conv_i conj(chirp_i) / S; x_{2i} = Re z_i, x_{2i+1} = Im z_i, straight from the registers
+  if (edge) {
+    const real_t invL = (real_t)(1.0 / (double)S);
+    const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
+    const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
+    if (flat) {
+      const EmiBuf b_out = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned off = (t + 256u * a) * SZ2;
+        emi_buf_st<real2>(b_out, off, 0, cscale(cmulc(v[a], emi_buf_ld<real2>(b_ch, off, 0)), invL));  // i >= sz: dropped
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned i = t + 256u * a;
+        if (i < (unsigned)sz) {
+          const real2 z = cscale(cmulc(v[a], chirp[i]), invL);
+          if (grid_pair_ok(gr, 2u * i)) {
+            *(real2 *)grid_ptr(gr, 2u * i) = z;
+          } else {
+            *grid_ptr(gr, 2u * i) = z.x;
+            *grid_ptr(gr, 2u * i + 1) = z.y;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ==========================================================================================
 // k_legpol: SUPOLF (supolf_mod.F90:13-251) for m >= 2 on the device -- the normalised associated
 // Legendre functions P_n^m(mu), n = m+par, m+par+2, ..., of one (wavenumber, parity, latitude) per
 // thread, by the reference's 4-term recurrence in n with its 1e+-100 rescaling, written straight into

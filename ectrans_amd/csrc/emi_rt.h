@@ -39,6 +39,43 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 #define EMI_LDS_DECL extern __shared__ __attribute__((aligned(16))) char emi_lds_raw[]
+// workgroup barrier that orders LDS accesses only: unlike __syncthreads() it does not wait for the wave's outstanding
+// global loads (vmcnt), so table loads issued ahead of an LDS exchange stay in flight across it
+#define EMI_LDS_SYNC() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// compiler-only fence between LDS accesses of ONE wave (its LDS instructions execute in order)
+#define EMI_WAVE_FENCE() __asm__ volatile("" ::: "memory")
+// the instruction scheduler moves nothing across this point
+#define EMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Buffer-descriptor access to tables and rows (k_fft_*_r16): one 32-bit lane offset, row / leg offsets in scalar registers,
+// no 64-bit vector address arithmetic; a read whose lane offset + immediate is past `bytes` returns zero and such a write is
+// dropped (raw buffer, stride 0: the range check of the hardware).  The scalar offset `soff` is NOT part of the check.
+struct EmiBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+typedef int emi_v4i __attribute__((ext_vector_type(4)));
+typedef int emi_v2i __attribute__((ext_vector_type(2)));
+EMI_DEVFN EmiBuf emi_buf(const void *p, unsigned bytes) {
+  EmiBuf b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
+  return b;
+}
+template <class V>
+EMI_DEVFN V emi_buf_ld(const EmiBuf &b, unsigned voff, unsigned soff) {
+  static_assert(sizeof(V) == 16 || sizeof(V) == 8, "emi_buf_ld: 8- or 16-byte values");
+  if constexpr (sizeof(V) == 16)
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0));
+  else
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0));
+}
+template <class V>
+EMI_DEVFN void emi_buf_st(const EmiBuf &b, unsigned voff, unsigned soff, V v) {
+  static_assert(sizeof(V) == 16 || sizeof(V) == 8, "emi_buf_st: 8- or 16-byte values");
+  if constexpr (sizeof(V) == 16)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(emi_v4i, v), b.r, voff, soff, 0);
+  else
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(emi_v2i, v), b.r, voff, soff, 0);
+}
 // Wave priority around the MFMA block of the Legendre stage loops: the two waves of a SIMD are in
 // different phases (one issues MFMAs, the other address arithmetic, LDS writes and loads for its next
 // stage); with the MFMA wave at the higher priority its next MFMA never queues behind the other wave's
@@ -102,6 +139,25 @@ static inline void emu_barrier() {
 }
 #define EMI_SYNC() emu_barrier()
 #define EMI_WAVE_SYNC() emu_barrier()  // lanes are threads here: a real barrier
+#define EMI_LDS_SYNC() emu_barrier()
+#define EMI_WAVE_FENCE() emu_barrier()  // lanes are threads here: a real barrier (every thread of the workgroup reaches it)
+#define EMI_SCHED_FENCE() ((void)0)
+struct EmiBuf {
+  const char *p;
+  unsigned bytes;
+};
+inline EmiBuf emi_buf(const void *p, unsigned bytes) { return EmiBuf{(const char *)p, bytes}; }
+template <class V>
+inline V emi_buf_ld(const EmiBuf &b, unsigned voff, unsigned soff) {
+  V v;
+  memset(&v, 0, sizeof(V));
+  if ((size_t)voff + sizeof(V) <= b.bytes) memcpy(&v, b.p + voff + soff, sizeof(V));
+  return v;
+}
+template <class V>
+inline void emi_buf_st(const EmiBuf &b, unsigned voff, unsigned soff, V v) {
+  if ((size_t)voff + sizeof(V) <= b.bytes) memcpy((char *)b.p + voff + soff, &v, sizeof(V));
+}
 #define EMI_LDS_DECL
 #define EMI_OPAQUE(x) ((void)0)
 #define EMI_PRIO_HI() ((void)0)

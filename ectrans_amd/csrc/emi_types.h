@@ -84,7 +84,8 @@ struct FftPlanDev {
   int tw_off, perm_off, rtw_off, chirp_off, bhat_off;
   int ptw_off[14];  // per pass (DIT order): table [(t-1)*lenp + j] = exp(-2 pi i j t/(lenp*R))
   int fbk;  // fields per workgroup
-  int lds_class, pad_;
+  int lds_class;
+  int r16;  // > 0: register-resident kernels k_fft_*_r16<r16>, S = 256 r16; ptw_off[0]: the 7 x 256 digit twiddles, bhat in [k2][16 k0 + k1] order
 };
 struct FftTabDev {
   const void *tw;              // real2 tables of the library precision: e^{-2 pi i k/S}
@@ -93,6 +94,7 @@ struct FftTabDev {
   const void *rtw;             // e^{-2 pi i k/n}, k=0..sz
   const void *chirp;           // e^{-i pi k^2/sz}
   const void *bhat;            // DFT_L of the chirp filter in DIT order, laid out [t][q] for the fused middle pass (q = butterfly, t = element)
+  const void *tw256;           // [15][16]: exp(-2 pi i c k1 / 256), k1 = 1..15 (k_fft_*_r16)
   const FftPlanDev *plans;
   const int *planid;           // [ndgl]
 };
@@ -117,6 +119,11 @@ struct FftLaunchDev {
 #define LG_LDS_BYTES_DIR (2 * LG_LDS_BYTES)                  // k_leg_dir, 16-row stages (+ its row-number tables)
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
+// First radices R1 of the register-resident kernels (work length 256 R1).  R1 = 18 and 20 (work lengths 4608, 5120) were built and
+// measured in round 3 and lost to the in-place LDS kernels (k_fft_inv_r16<18>, 20 bytes of spills: 18.0 ms against 15.0 ms for the
+// rows of TCo1279; R1 = 20: 21.2 against 15.8): their first / last butterflies hold 72 / 80 data registers of the 128 a wave
+// may use at four waves per SIMD, and 16 R1 threads make five-wave workgroups of which only three fit a CU.
+#define EMI_R16_LIST(X) X(8) X(10) X(12) X(16)
 
 // Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors[5], fields per
 // workgroup).  The factor lists are what emi::factorize_smooth yields for S and the field count what the

@@ -75,6 +75,24 @@ def test_specialised_fft_kernels_match_oracle(et, half, precision):
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
+R16_ROWS = [1540, 2044, 2052, 2556, 2564, 3068, 3076, 4092]  # first and last row length of the work lengths 256 R1, R1 = 8, 10, 12, 16
+
+
+@pytest.mark.parametrize("precision", [8, 4])
+def test_register_resident_fft_kernels_blocked_rows(et, precision):
+    """k_fft_dir_r16 / k_fft_inv_r16 with NPROMA blocks that cut the rows (the element-wise grid path; the unblocked
+    specialised-kernel cases above take the row-as-one-buffer path), winds and derivatives."""
+    e_inv, e_dir = run_case(et, Oracle, XP, 15, R16_ROWS + R16_ROWS[::-1], 1, 1, dict(scders=True, uvder=True), 1000, precision=precision)
+    tol = TOL if precision == 8 else 2e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+def test_register_resident_fft_kernels_adjoints(et):
+    """the `adj` scalings of the register-resident kernels: dot-product identity of INV_TRANSAD / DIR_TRANSAD"""
+    e_inv, e_dir = adjoint_case(et, XP, 15, R16_ROWS + R16_ROWS[::-1], 1, 1, nproma=3000)
+    assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
+
+
 def test_unmerged_radix_fft_kernels_match_oracle(et, monkeypatch):
     """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists 8*8*8*2*3 ... (the default merges the last two
     factors into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""

@@ -152,6 +152,53 @@ def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
     assert not np.array_equal(outs[0][0], np.zeros_like(outs[0][0]))
 
 
+R16_ROWS = [1540, 2044, 2052, 2556, 2564, 3068, 3076, 4092]  # first and last row length of the work lengths 256 R1, R1 = 8, 10, 12, 16
+
+
+@pytest.mark.parametrize("precision,nproma", [(8, 1000), (4, 1000), (8, 4094)])
+def test_register_resident_fft_kernels_blocked_rows(et, dev, precision, nproma):
+    """k_fft_dir_r16 / k_fft_inv_r16 (round 3: rows whose Bluestein work length is 256 R1, points in registers, LDS as the
+    exchange medium) with NPROMA blocks that cut the rows: the element-wise grid path instead of the row-as-one-buffer
+    path the unblocked cases take; winds, derivatives and both precisions."""
+    from oracle.oracle import Oracle as O
+    e_inv, e_dir = run_case(et, O, dev, 15, R16_ROWS + R16_ROWS[::-1], 2, 3, dict(scders=True, uvder=True, vorgp=True, divgp=True), nproma, precision=precision)
+    tol = TOL if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+def test_register_resident_and_lds_fft_kernels_agree(et, dev, monkeypatch):
+    """EMI_FFT_R16=0 sends the same rows through the in-place LDS kernels (other work lengths for some of them, another
+    factorisation for all): both are the same transform to rounding."""
+    to, back = dev
+    nloen = np.array(R16_ROWS + R16_ROWS[::-1], dtype=np.int32)
+    rng = np.random.default_rng(5)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("EMI_FFT_R16", "0")
+        r = et.setup_trans(15, len(nloen), nloen)
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        if not outs:
+            sp = random_spectrum(rng, et.trans_inq(r, "nasm0"), 15, ns2, 3, False)
+        gp = to(np.zeros((1, 3, ng)))
+        et.inv_trans(r, pspscalar=to(sp), pgp=gp)
+        s2 = to(np.zeros((ns2, 3)))
+        et.dir_trans(r, pspscalar=s2, pgp=gp)
+        outs.append((back(gp).copy(), back(s2).copy()))
+        et.trans_release(r)
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-13 and rel_err(outs[0][1], outs[1][1]) < 1e-13
+    assert not np.array_equal(outs[0][0], outs[1][0])  # really two different kernels
+
+
+@pytest.mark.parametrize("precision", [8, 4])
+def test_register_resident_fft_kernels_adjoints(et, dev, precision):
+    """INV_TRANSAD / DIR_TRANSAD on rows that take the register-resident kernels (their `adj` scalings): the reference's
+    dot-product identity (tests/trans/test_invtrans_adjoint.F90: 2000 epsilon)."""
+    e_inv, e_dir = adjoint_case(et, dev, 15, R16_ROWS + R16_ROWS[::-1], 1, 2, nproma=3000, precision=precision)
+    tol = 1e-12 if precision == 8 else 2e-4
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
 def test_unmerged_radix_fft_kernels_match_oracle(et, dev, monkeypatch):
     """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists (the default merges the last two factors
     into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""
