@@ -320,19 +320,24 @@ static int build_fft_plans(Plan &P) {
     std::vector<int> fac;
     pl.blue = !emi::factorize_smooth(pl.sz, fac);
     pl.S = pl.sz;
-    // Register-resident kernels (k_fft_*_r16<R1>, round 3): Bluestein rows of even length whose work length fits 256 R1,
-    // R1 from EMI_R16_LIST -- at TCo1279 every row longer than 1538 points.  EMI_FFT_R16=0 keeps the in-place LDS kernels.
-    if (pl.blue && !pl.cmode && !(getenv("EMI_FFT_R16") && atoi(getenv("EMI_FFT_R16")) == 0)) {
+    // Register-resident kernels (k_fft_*_r16<R1>, round 3): rows of even length whose Bluestein work length fits 256 R1, R1 from
+    // EMI_R16_LIST and at least 8 -- at TCo1279 every row of 1540 to 4098 points.  EMI_FFT_R16=0 keeps the in-place LDS kernels.
+    // Rows of that range with a 7-smooth half-length take them too (EMI_FFT_R16_SMOOTH=0: the generic mixed-radix kernels): per
+    // point the generic kernels cost 8.7 ps and row, the convolution 5.5 - 6 ps per work point (profiles/r3c_pmc_fft.txt), although it
+    // does four times the arithmetic -- every one of those 100-odd row lengths has its own factor list, which the generic kernels
+    // walk at run time.
+    if (!pl.cmode && !(getenv("EMI_FFT_R16") && atoi(getenv("EMI_FFT_R16")) == 0)) {
       static const int r1s[] = {
 #define EMI_R16_ROW(r_) r_,
           EMI_R16_LIST(EMI_R16_ROW)
 #undef EMI_R16_ROW
       };
-      const char *rmin = getenv("EMI_FFT_R16_MIN");  // experiments: shortest work length that takes these kernels, in units of 256
-      for (int r : r1s)
-        if (!pl.r16 && 256 * r >= 2 * pl.sz - 1 && 256 * r >= 1024 + 512 + 1 && r >= (rmin ? atoi(rmin) : 0)) pl.r16 = r;
-      // a row short enough for a smaller work length of the in-place kernels than 256 * 8 keeps them (several fields per workgroup)
-      if (pl.r16 && 2 * pl.sz - 1 <= 1536) pl.r16 = 0;
+      const bool smooth_too = !(getenv("EMI_FFT_R16_SMOOTH") && atoi(getenv("EMI_FFT_R16_SMOOTH")) == 0);
+      const int need = 2 * pl.sz - 1;
+      if ((pl.blue || smooth_too) && need > 1536)  // shorter rows: in-place kernels with several fields per workgroup
+        for (int r : r1s)
+          if (!pl.r16 && 256 * r >= need) pl.r16 = r;
+      if (pl.r16) pl.blue = 1;
     }
     if (pl.r16) {
       pl.S = 256 * pl.r16;
@@ -570,7 +575,7 @@ static int build_fft_plans(Plan &P) {
       if (pl.r16) {
         // k = k0 + R1 (k1 + 16 k2) sits in register k2 of thread 16 k0 + k1 of the fused middle pass: table [k2][16 k0 + k1]
         const int k0 = k % pl.r16, kk = k / pl.r16, k1 = kk % 16, k2 = kk / 16;
-        bh[(size_t)k2 * (16 * pl.r16) + 16 * k0 + k1] = d2{(double)sr, (double)si};
+        bh[(size_t)k2 * (16 * pl.r16) + 16 * k0 + k1] = d2{(double)(sr / (long double)L), (double)(si / (long double)L)};  // the 1/S of the convolution folded in
         continue;
       }
       const int p = pm[k];

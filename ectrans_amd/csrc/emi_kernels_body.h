@@ -1983,23 +1983,21 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
   // Z_i = conv_i chirp_i / S, i < sz, to LDS (complex, natural order: sz <= S/2 of them fit the plane)
   EMI_LDS_SYNC();  // every thread has read its last plane values
   if (edge) {
-    const real_t invL = (real_t)(1.0 / (double)S);
 #pragma unroll
     for (int a = 0; a < H; a++) {
       const unsigned i = t + 256u * a;
-      zbuf[i] = cscale(cmul(v[a], emi_buf_ld<real2>(b_ch, i * SZ2, 0)), invL);  // i >= sz: zero chirp, never read
+      zbuf[i] = cmul(v[a], emi_buf_ld<real2>(b_ch, i * SZ2, 0));  // i >= sz: zero chirp, never read (1 / S: in the filter table)
     }
   }
   EMI_LDS_SYNC();
   // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
-  const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
+  const real_t sc = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
   for (int k = (int)t; k <= nmen; k += NT) {
     const int kb = (k == 0) ? 0 : sz - k;
     const real2 za = zbuf[k], zb = zbuf[kb];
     const real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
     const real2 tt = cmuli(cmul(rtw[k], d1));
-    const real2 x = mk2((real_t)0.5 * (s1.x - tt.x), (real_t)0.5 * (s1.y - tt.y));
-    *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * f0) = cscale(x, sc);
+    *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * f0) = mk2((s1.x - tt.x) * sc, (s1.y - tt.y) * sc);
   }
 }
 
@@ -2031,6 +2029,8 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
   // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times conj(chirp), to LDS
+  // (issuing all Fourier-row loads of a thread before the first use -- the loop unrolled over its at most five trips -- was
+  // measured 3 ms per pair SLOWER over the four work lengths: the other workgroups of the CU already cover that latency)
   {
     const int npair = sz / 2 + 1;
     for (int k = (int)t; k < npair; k += NT) {
@@ -2062,7 +2062,6 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   r16_conv<R1, 1>(v, t, b_tw, b_bh, lds, tw2s);
   // stage 3 (TRLTOG local copy): z_i = conv_i conj(chirp_i) / S; x_{2i} = Re z_i, x_{2i+1} = Im z_i, straight from the registers
   if (edge) {
-    const real_t invL = (real_t)(1.0 / (double)S);
     const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
     if (flat) {
@@ -2070,14 +2069,14 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
 #pragma unroll
       for (int a = 0; a < H; a++) {
         const unsigned off = (t + 256u * a) * SZ2;
-        emi_buf_st<real2>(b_out, off, 0, cscale(cmulc(v[a], emi_buf_ld<real2>(b_ch, off, 0)), invL));  // i >= sz: dropped
+        emi_buf_st<real2>(b_out, off, 0, cmulc(v[a], emi_buf_ld<real2>(b_ch, off, 0)));  // i >= sz: dropped (1 / S: in the filter table)
       }
     } else {
 #pragma unroll
       for (int a = 0; a < H; a++) {
         const unsigned i = t + 256u * a;
         if (i < (unsigned)sz) {
-          const real2 z = cscale(cmulc(v[a], chirp[i]), invL);
+          const real2 z = cmulc(v[a], chirp[i]);
           if (grid_pair_ok(gr, 2u * i)) {
             *(real2 *)grid_ptr(gr, 2u * i) = z;
           } else {

@@ -1,3 +1,32 @@
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/hot1 -- python3 tools/gpu_perf.py 1279 137 10 1 8 > gpurun_out/hot1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/hot2 -- python3 tools/gpu_perf.py 1279 137 10 1 8 > gpurun_out/hot2.log 2>&1
+# SQ counters of the FFT kernels of one TCo1279 pair:  bash tools/pmc_fft.sh TAG   (through gpurun; two counter passes, kernel trace only)
+TAG=${1:-hot}
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${TAG}_pmc1 -- python3 tools/gpu_perf.py 1279 137 10 1 8 > gpurun_out/${TAG}_pmc1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/${TAG}_pmc2 -- python3 tools/gpu_perf.py 1279 137 10 1 8 > gpurun_out/${TAG}_pmc2.log 2>&1
+python3 - <<PY
+import csv,glob,collections,re
+acc=collections.defaultdict(lambda: collections.defaultdict(float))
+dur=collections.defaultdict(float)
+for d in ("gpurun_out/${TAG}_pmc1","gpurun_out/${TAG}_pmc2"):
+    for f in glob.glob(d+"/**/*counter_collection.csv",recursive=True):
+        for r in csv.DictReader(open(f)):
+            m=re.search(r'(k_fft_\w+(<\d+>)?)',r["Kernel_Name"])
+            if m: acc[m.group(1)][r["Counter_Name"]]+=float(r["Counter_Value"])
+for f in glob.glob("gpurun_out/${TAG}_pmc1/**/*kernel_trace.csv",recursive=True):
+    for r in csv.DictReader(open(f)):
+        m=re.search(r'(k_fft_\w+(<\d+>)?)',r["Kernel_Name"])
+        if m: dur[m.group(1)]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
+with open("gpurun_out/${TAG}_pmc_fft.txt","w") as fh:
+    fh.write("kernel ms clkGHz valu/wave lds/wave vmem/wave | share of SIMD time: valu lds any | wave life: wait_any wait_inst | lds conflict\n")
+    for k in sorted(acc, key=lambda k:-dur[k]):
+        a=acc[k]
+        if not a.get("SQ_WAVES"): continue
+        w=a["SQ_WAVES"]; cyc=a["SQ_BUSY_CYCLES"]/32.0
+        simd=cyc*1024.0/4.0   # quad-cycles of all SIMDs
+        fh.write("%-20s %6.2f %5.2f %6.0f %5.0f %5.0f | %4.2f %4.2f %4.2f | %4.2f %4.2f | %5.3f\n"%(k,dur[k],cyc/dur[k]/1e6 if dur[k] else 0,
+            a["SQ_INSTS_VALU"]/w,a["SQ_INSTS_LDS"]/w,(a["SQ_INSTS_VMEM_RD"]+a["SQ_INSTS_VMEM_WR"])/w,
+            a["SQ_ACTIVE_INST_VALU"]/simd,a["SQ_ACTIVE_INST_LDS"]/simd,a["SQ_ACTIVE_INST_ANY"]/simd,
+            a["SQ_WAIT_ANY"]/a["SQ_WAVE_CYCLES"],a["SQ_WAIT_INST_ANY"]/a["SQ_WAVE_CYCLES"],
+            a["SQ_LDS_BANK_CONFLICT"]/max(1.0,a["SQ_LDS_IDX_ACTIVE"])))
+print(open("gpurun_out/${TAG}_pmc_fft.txt").read())
+PY
