@@ -617,6 +617,30 @@ static void supolf_panels(const orc_trans *t, const pol_t *pol, int im, double *
   *pps = ps;
 }
 
+/* The Legendre functions of ONE latitude and wavenumber exactly as the panels hold them (same SUPOLF calls as
+ * supolf_panels: suleg_mod.F90:609-662, 891-944): out[n - km] = P_n^km(mu(jgl)), n = km .. nsmax; jgl 1-based, any hemisphere
+ * (P_n^m(-mu) = (-1)^(n-m) P_n^m(mu) is NOT applied: the value at the latitude's own mu is returned).  For test yardsticks
+ * that evaluate sampled rows of a transform independently (tests/common.py::fp32_yardstick).                          */
+void orc_legpol(const orc_trans *t, int km, int jgl, double *out) {
+  const int nsmax = t->nsmax, imaxn = t->ntmax + 1;
+  pol_t tmp, *pol = (pol_t *)t->pol;
+  if (!pol) {
+    tmp = ini_pol(t->ntmax + 3);
+    pol = &tmp;
+  }
+  double *zlpol = xcalloc((size_t)imaxn + 3, 8);
+  int *icorr = xcalloc((size_t)imaxn + 3, sizeof(int));
+  const int inmaxa = ((imaxn - km) % 2 == 0) ? imaxn + 1 : imaxn, inmaxs = ((imaxn - km) % 2 == 0) ? imaxn : imaxn + 1;
+  const double mu = t->rmu[jgl - 1];
+  supolf(pol, km, inmaxa, mu, zlpol, 3, icorr);
+  for (int n = km + 1; n <= nsmax; n += 2) out[n - km] = zlpol[n];
+  supolf(pol, km, inmaxs, mu, zlpol, 2, icorr);
+  for (int n = km; n <= nsmax; n += 2) out[n - km] = zlpol[n];
+  free(zlpol);
+  free(icorr);
+  if (pol == &tmp) end_pol(&tmp);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* SETUP_TRANS (cpu/external/setup_trans.F90:169-428) -> SETUP_DIMS, SUMP_TRANS_PRELEG,  */
 /* PRE_SULEG, SULEG, SETUP_GEOM for NPROC=1                                              */

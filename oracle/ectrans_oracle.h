@@ -56,6 +56,9 @@ const int *orc_nasm0(const orc_trans *t);    /* nsmax+1, 1-based offsets as in F
 const double *orc_rpnma(const orc_trans *t, int m, int *rows, int *cols);
 const double *orc_rpnms(const orc_trans *t, int m, int *rows, int *cols);
 
+/* P_n^km(mu(jgl)), n = km .. nsmax, as the panels hold them (one SUPOLF column): out[n - km]; jgl 1-based. */
+void orc_legpol(const orc_trans *t, int km, int jgl, double *out);
+
 /* INV_TRANS (inv_trans.F90:182-611).  Grid field order (inv_trans.h:66-76):
  * [vor][div] u v scalars [NS-ders] [u_EW v_EW] [sc_EW].  Returns number of grid fields. */
 int orc_inv_trans(const orc_trans *t, int nuv, int nsc, const double *spvor,

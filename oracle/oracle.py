@@ -49,6 +49,7 @@ def lib():
                                     C.c_int, dp]
         L.orc_dir_trans.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp, dp]
         L.orc_specnorm.argtypes = [C.c_void_p, C.c_int, dp, dp]
+        L.orc_legpol.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.orc_fft_r2c.argtypes = [C.c_int, dp, dp]
         L.orc_fft_c2r.argtypes = [C.c_int, dp, dp]
         _LIB = L
@@ -141,6 +142,12 @@ class Oracle:
         sc = np.zeros((self.nspec2, nsc)) if nsc else None
         self.L.orc_dir_trans(self.h, nuv, nsc, _dp(gp), _dp(vor), _dp(div), _dp(sc))
         return vor, div, sc
+
+    def legpol(self, m, jgl):
+        """P_n^m(mu(jgl)), n = m .. nsmax (jgl 1-based): the values the Legendre panels hold"""
+        out = np.zeros(self.nsmax - m + 1)
+        self.L.orc_legpol(self.h, int(m), int(jgl), _dp(out))
+        return out
 
     def set_sp_mode(self, on=True):
         """dir_trans computes LEDIR as libtrans_sp does: float operands, SGEMM, m = 0 in double (ledir_mod.F90:133-171)"""

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
-from tests.common import adjoint_case, legpol_io_case, octahedral, run_case
+from tests.common import adjoint_case, closed_form_errors, legpol_io_case, octahedral, run_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-12  # fp64: observed ~1e-15
@@ -432,3 +432,27 @@ def test_belousov_generator_lduserpnm(et):
 def test_adjoint_options_through_call_mode2_arrays(et):
     from tests.common import adjoint_options_call_mode2_case
     assert adjoint_options_call_mode2_case(et, XP) < 1e-14
+
+
+def test_closed_form_winds_and_derivatives(et):
+    """the kernels against analytic fields (tests/common.py::closed_form_case)"""
+    to, back = XP
+    nloen = octahedral(21)
+    r = et.setup_trans(21, len(nloen), nloen)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+
+        def inv(v, d, s):
+            gp = to(np.zeros((1, 9, ng)))
+            et.inv_trans(r, pspvor=to(v), pspdiv=to(d), pspscalar=to(s), pgp=gp, ldscders=True, ldvorgp=True, lddivgp=True, lduvder=True)
+            return back(gp)[0]
+
+        def dirt(g):
+            v2, d2, s2 = (to(np.zeros((ns2, 1))) for _ in range(3))
+            et.dir_trans(r, pspvor=v2, pspdiv=d2, pspscalar=s2, pgp=to(np.ascontiguousarray(g[None])))
+            return back(v2), back(d2), back(s2)
+
+        e_inv, e_dir = closed_form_errors(inv, dirt, 21, nloen, et.trans_inq(r, "rmu"), et.trans_inq(r, "nasm0"), ns2)
+    finally:
+        et.trans_release(r)
+    assert max(e_inv) < 1e-12 and max(e_dir) < 1e-12, (e_inv, e_dir)

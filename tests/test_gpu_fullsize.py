@@ -34,14 +34,15 @@ def Oracle(*a, **k):
 
 def test_tco399_137lev_x4_kf823_matches_oracle(et):
     """BASELINE configs[1]: TCo399, 137 levels x 4 fields (KF = 823), fp64, one field batch."""
-    res = full_size_call_mode2(et, Oracle, 399, 137, 4, precision=8, tol=1e-11, tol_norm=1e-10)
+    res = full_size_call_mode2(et, Oracle, 399, 137, 4, precision=8, tol=1e-11, tol_norm=1e-10, tol_group=1e-10)
     print("TCo399 KF=823:", res)
 
 
 def test_tco1279_137lev_x10_kf1645_matches_oracle(et):
     """BASELINE configs[2] -- the headline metric's workload, exactly bench.py's arrays: TCo1279, 137 levels x 10
-    fields (KF = 1645), fp64, call mode 2, one batch, 26 column tiles x 1280 wavenumbers."""
-    res = full_size_call_mode2(et, Oracle, 1279, 137, 10, precision=8, tol=1e-11, tol_norm=1e-10)
+    fields (KF = 1645), fp64, call mode 2, one batch, 26 column tiles x 1280 wavenumbers.  Every field also per latitude
+    row (inverse) and per total wavenumber (direct) relative to that row's / wavenumber's own maximum: 1e-10."""
+    res = full_size_call_mode2(et, Oracle, 1279, 137, 10, precision=8, tol=1e-11, tol_norm=1e-10, tol_group=1e-10)
     print("TCo1279 KF=1645:", res)
 
 
@@ -51,9 +52,22 @@ def test_tco2559_137lev_x10_fp32_matches_oracle(et):
     this size float rounding is visible in the tails: a Legendre sum has up to 2560 terms and the largest error is
     taken over 4e10 elements (observed 6e-5 / 1e-4 of the field maximum, inverse / direct), so the bound on the
     largest element is 3e-4 (5000 float epsilons) while the per-field RMS error is held to 2e-5 and the spectral
-    norms to 1e-5 -- an indexing or batching error would break all three."""
-    res = full_size_call_mode2(et, Oracle, 2559, 137, 10, precision=4, tol=3e-4, tol_norm=1e-5, chunk=2, tol_rms=2e-5)
+    norms to 1e-5 -- an indexing or batching error would break all three.
+    The yardstick for "is 1e-4 good or bad in float" (round 3): seven latitude rows of the inverse and seven zonal wavenumbers
+    of the direct transform are also evaluated by a plain float32 CPU chain (float32 Legendre functions, BLAS SDOT / SGEMV,
+    scipy single-precision FFT: the arithmetic class of libtrans_sp) and the HIP error on those rows / columns, both measured
+    against the fp64 oracle, must not exceed 3 x the CPU float32 error."""
+    ys = dict(lats=[1, 2, 40, 640, 1280, 2000, 2560], ms=[0, 1, 2, 100, 1280, 2500, 2559], factor=3.0)
+    res = full_size_call_mode2(et, Oracle, 2559, 137, 10, precision=4, tol=3e-4, tol_norm=1e-5, chunk=2, tol_rms=2e-5, yardstick=ys)
     print("TCo2559 fp32 KF=1645:", res)
+
+
+def test_tco399_fp32_against_float32_cpu_yardstick(et):
+    """The fp32 library at TCo399 (137 levels x 4 fields) with the same yardstick: HIP error <= 3 x the error of a plain float32
+    CPU evaluation on sampled rows / wavenumbers (and the absolute bounds of the fp32 parity tests)."""
+    ys = dict(lats=[1, 3, 50, 200, 400], ms=[0, 1, 5, 200, 399], factor=3.0)
+    res = full_size_call_mode2(et, Oracle, 399, 137, 4, precision=4, tol=3e-5, tol_norm=1e-5, tol_rms=5e-6, yardstick=ys)
+    print("TCo399 fp32 KF=823:", res)
 
 
 def test_per_latitude_row_relative_error_tco399(et):

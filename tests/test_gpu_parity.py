@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.common import adjoint_case, block, legpol_io_case, octahedral, random_spectrum, rel_err, run_case, unblock
+from tests.common import adjoint_case, block, closed_form_errors, legpol_io_case, octahedral, random_spectrum, rel_err, run_case, unblock
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -733,3 +733,32 @@ def test_adjoint_with_derivative_options_matches_transposed_oracle(et, dev, flag
 def test_adjoint_options_through_call_mode2_arrays(et, dev):
     from tests.common import adjoint_options_call_mode2_case
     assert adjoint_options_call_mode2_case(et, dev, nsmax=21) < 1e-14
+
+
+@pytest.mark.parametrize("grid,precision", [("octahedral", 8), ("regular", 8), ("octahedral", 4)])
+def test_closed_form_winds_and_derivatives(et, dev, grid, precision):
+    """HIP path against analytic fields (solid-body rotation, single harmonics of vorticity, divergence and a scalar with
+    all derivative outputs): numbers neither the oracle nor the reference's tests hold -- see tests/common.py::closed_form_case."""
+    to0, back0 = dev
+    dt = np.float32 if precision == 4 else np.float64
+    to, back = (lambda a: to0(np.ascontiguousarray(a, dtype=dt))), (lambda a: np.asarray(back0(a), dtype=np.float64))
+    nloen = octahedral(21) if grid == "octahedral" else np.full(44, 96, dtype=np.int32)
+    r = et.setup_trans(21, len(nloen), nloen, precision=precision)
+    try:
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+
+        def inv(v, d, s):
+            gp = to(np.zeros((1, 9, ng)))
+            et.inv_trans(r, pspvor=to(v), pspdiv=to(d), pspscalar=to(s), pgp=gp, ldscders=True, ldvorgp=True, lddivgp=True, lduvder=True)
+            return back(gp)[0]
+
+        def dirt(g):
+            v2, d2, s2 = (to(np.zeros((ns2, 1))) for _ in range(3))
+            et.dir_trans(r, pspvor=v2, pspdiv=d2, pspscalar=s2, pgp=to(g[None]))
+            return back(v2), back(d2), back(s2)
+
+        e_inv, e_dir = closed_form_errors(inv, dirt, 21, nloen, et.trans_inq(r, "rmu"), et.trans_inq(r, "nasm0"), ns2)
+    finally:
+        et.trans_release(r)
+    tol = 1e-12 if precision == 8 else 2e-5
+    assert max(e_inv) < tol and max(e_dir) < tol, (e_inv, e_dir)

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle, fft_c2r, fft_r2c
+from tests.common import closed_form_errors, octahedral
 
 EPSILON = 1e-10  # test_ectrans4py.py:16
 
@@ -119,3 +120,18 @@ def test_dense_roundtrip_with_winds(grid):
     assert np.abs(s2 - sc).max() < tol_sc
     assert np.abs(v2 - vor).max() < tol_vd
     assert np.abs(d2 - div).max() < tol_vd
+
+
+@pytest.mark.parametrize("grid", ["octahedral", "regular"])
+def test_closed_form_winds_and_derivatives(grid):
+    """The reference holds no golden vector for the wind / derivative operators (its own checks are norm round trips,
+    tests/CMakeLists.txt:274-290).  Closed forms pin them to numbers no restatement shares: solid-body rotation
+    (zeta = 2U/(a sqrt 3) P_1^0 => u = U cos(theta), v = 0), single harmonics of vorticity, divergence and a scalar with
+    their analytic u, v, d/dlambda, d/dtheta fields -- vdtuv_mod.F90:97-143, spnsde_mod.F90:95-114, fsc_mod.F90:138-187 in
+    INV_TRANS and uvtvd_mod.F90:91-139 in DIR_TRANS (observed 3e-14; 1e-12 asserted)."""
+    nloen = octahedral(21) if grid == "octahedral" else np.full(44, 96, dtype=np.int32)
+    o = Oracle(21, nloen)
+    inv = lambda v, d, s: o.inv_trans(spvor=v, spdiv=d, spsc=s, scders=True, vorgp=True, divgp=True, uvder=True)
+    dirt = lambda g: o.dir_trans(g, nuv=1, nsc=1)
+    e_inv, e_dir = closed_form_errors(inv, dirt, 21, nloen, o.rmu, o.nasm0, o.nspec2)
+    assert max(e_inv) < 1e-12 and max(e_dir) < 1e-12, (e_inv, e_dir)
