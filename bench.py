@@ -220,7 +220,35 @@ def main():
     import ectrans_amd as et
     N, nlev, nfld = args.nsmax, args.nlev, args.nfld
     kf = 2 * nlev + nfld * nlev + 1
-    et.setup_trans0(kmax_resol=2, device=local, kprtrw=world, myproc=rank + 1)
+    # N > 1: the exchange runs on the native RCCL transport (ectrans_amd/rccl: one group of ncclSend / ncclRecv per field batch
+    # on the library's exchange stream -- the path a Fortran host uses); EMI_BENCH_TRANSPORT=torch keeps the Python
+    # all_to_all_single callback, which is also the fallback when the native attach fails (and the gloo test configuration)
+    transport = "torch"
+    if world > 1 and backend == "nccl" and os.environ.get("EMI_BENCH_TRANSPORT", "rccl") == "rccl":
+        transport = "rccl"
+    transport_note = None
+    ok = 1
+    try:
+        et.setup_trans0(kmax_resol=2, device=local, kprtrw=world, myproc=rank + 1, transport=transport)
+    except OSError as e:
+        if transport != "rccl":
+            raise
+        ok, transport_note = 0, str(e)
+    if transport == "rccl":
+        if world > 1:  # every rank must take the same path: fall back together if the native attach failed anywhere
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            all_ok = int(flag.item())
+        else:
+            all_ok = ok
+        if not all_ok:
+            if ok:
+                et.trans_end()
+                from ectrans_amd import dist as _ed
+                _ed.rccl_native_lib().emi_rccl_detach()
+            transport_note = transport_note or "native attach failed on another rank"
+            transport = "torch"
+            et.setup_trans0(kmax_resol=2, device=local, kprtrw=world, myproc=rank + 1)
     if args.max_batch:
         et.set_max_batch(args.max_batch)
     t0 = time.time()
@@ -319,8 +347,11 @@ def main():
                                    "device-resident call-mode-2 arrays" % (N, N + 1, nlev, nfld, kf),
                        "parallelism": "1 GPU" if world == 1 else
                        "%d GPUs: zonal wavenumbers zig-zag + latitude bands, all-to-all-v per direction over %s" % (
-                           world, "RCCL (torch.distributed nccl)" if backend == "nccl" else backend + " (test configuration, host staged)"),
-                       "world_size": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+                           world, ("RCCL (native grouped ncclSend / ncclRecv, ectrans_amd/rccl)" if transport == "rccl" else "RCCL (torch.distributed nccl)")
+                           if backend == "nccl" else backend + " (test configuration, host staged)"),
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": None if world == 1 else ("rccl-native" if transport == "rccl" else backend),
+                       "transport_note": transport_note, "pipeline_batches": int(os.environ.get("EMI_PIPELINE_DIST", "4")) if world > 1 else 1,
                        "setup_s": round(t_setup, 2)},
             # the reference reports 1 / median step time (ectrans-benchmark.F90:906-943); `value` is steps / wall time
             "pairs_per_s_median": 1e3 / med_ms, "ms_per_step_median": med_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],

@@ -130,6 +130,7 @@ def _bind(L):
     L.emi_dist_grid.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, ip, C.c_int, C.c_void_p]
     L.emi_gath_grid.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, C.c_int, C.c_void_p]
     L.emi_inq_tasks.argtypes = [ip, ip]
+    L.emi_inq_init.argtypes = [ip, dp]
     return L
 
 
@@ -185,15 +186,24 @@ _DIST = {"nproc": 1, "group": None, "device": None}
 
 
 def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, myproc=1, group=None, alltoallv=None,
-                 **unsupported):
+                 transport="torch", **unsupported):
     """SETUP_TRANS0 (setup_trans0.h:12-89).
 
     kprtrw > 1: this process is task `myproc` (1-based) of a W-set of `kprtrw` tasks, one per GPU
     (NPRTRV = NPRGPEW = 1); the all-to-all-v between them defaults to torch.distributed on `group`
-    (RCCL for CUDA devices, gloo on the CPU test tier) -- see ectrans_amd.dist."""
+    (RCCL for CUDA devices, gloo on the CPU test tier) -- see ectrans_amd.dist.
+    transport="rccl": the native transport of ectrans_amd/rccl instead (what a Fortran host attaches: grouped
+    ncclSend / ncclRecv on the library's stream, no Python callback per field batch); `group` only carries the
+    128-byte unique id and the small reductions of SPECNORM."""
     for k, v in unsupported.items():
         if k.lower() in ("kprgpns", "kprgpew") and v not in (None, 1, kprtrw):
             raise TransError("SETUP_TRANS0: %s=%r: only the W-set decomposition (KPRTRW tasks) is supported" % (k, v))
+    if transport == "rccl":
+        from . import dist as _dist
+        _dist.rccl_native_attach(kprtrw, myproc, kmax_resol, kprintlev, prad, device, group)  # calls emi_init itself
+        _DIST.update(nproc=kprtrw, group=group if kprtrw > 1 else None,
+                     device=("cuda:%d" % device) if kprtrw > 1 and device is not None and device >= 0 else None)
+        return
     if kprtrw > 1:
         from . import dist as _dist
         dev = ("cuda:%d" % device) if device is not None and device >= 0 else "cpu"
@@ -206,6 +216,14 @@ def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, mypr
         _DIST.update(nproc=1, group=None, device=None)
     cfg = _Init(kmax_resol, kprintlev, prad if prad else 0.0, kprtrw, myproc, device if device is not None else -1)
     _chk(lib().emi_init(C.byref(cfg)))
+
+
+def inq_init():
+    """(KMAX_RESOL, PRAD) the library was initialised with (emi_inq_init): what a host that adopts an attached transport's
+    initialisation compares its own SETUP_TRANS0 arguments with."""
+    k, r = C.c_int(0), C.c_double(0.0)
+    _chk(lib().emi_inq_init(C.byref(k), C.byref(r)))
+    return k.value, r.value
 
 
 _PREC = {}  # kresol -> array dtype name of that resolution

@@ -17,6 +17,52 @@
 #include "../../include/ectrans_mi.h"
 #include "emi_kernels.h"
 #include "emi_setup.h"
+#include <dlfcn.h>
+
+// ---- roctx ranges named after the reference's GSTATS phases (gpu/internal/tpm_stats.F90:33-55 turns GSTATS into NVTX ranges;
+// labels of ectrans-benchmark.F90:1681-1697), so that a rocprofv3 --marker-trace of a Fortran or C host shows INV_TRANS /
+// LTINV_CTL / FTINV_CTL ... around the kernel launches.  librocprofiler-sdk-roctx is opened at run time (no link dependency:
+// absent library or EMI_ROCTX=0 = no ranges); a range covers the host-side enqueue of its phase.
+struct EmiRoctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+  void load() {
+    tried = true;
+#ifndef EMI_CPU_EMU
+    const char *e = getenv("EMI_ROCTX");
+    if (e && atoi(e) == 0) return;
+    void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+#endif
+  }
+};
+static EmiRoctx g_roctx;
+struct EmiRange {  // RAII: one nested range
+  bool on;
+  explicit EmiRange(const char *label) {
+    if (!g_roctx.tried) g_roctx.load();
+    on = g_roctx.push != nullptr;
+    if (on) g_roctx.push(label);
+  }
+  ~EmiRange() {
+    if (on) g_roctx.pop();
+  }
+};
+extern "C" int emi_roctx_active(void) {
+  if (!g_roctx.tried) g_roctx.load();
+  return g_roctx.push != nullptr;
+}
+static const char *const EMI_LBL_SETUP = "SETUP_TRANS    - Setup ecTrans handle", *const EMI_LBL_SULEG = "SULEG          - Comp. of Leg. poly.",
+                         *const EMI_LBL_INV = "INV_TRANS      - Inverse transform", *const EMI_LBL_DIR = "DIR_TRANS      - Direct transform",
+                         *const EMI_LBL_LTINV = "LTINV_CTL      - Inv. Legendre transform", *const EMI_LBL_LTDIR = "LTDIR_CTL      - Dir. Legendre transform",
+                         *const EMI_LBL_FTDIR = "FTDIR_CTL      - Dir. Fourier transform", *const EMI_LBL_FTINV = "FTINV_CTL      - Inv. Fourier transform",
+                         *const EMI_LBL_TRMTOL = "LTINV_CTL      - M to L transposition", *const EMI_LBL_TRLTOM = "LTDIR_CTL      - L to M transposition";
 
 #ifdef EMI_CPU_EMU
 thread_local EmuCtx *emu_ctx = nullptr;
@@ -718,6 +764,7 @@ static int legpol_index(LegpolSource &src, int nsmax, int ndgnh, const std::vect
 static int legpol_write(int kresol, const char *fname);
 
 extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *io, int *kresol) {
+  EmiRange rg_setup(EMI_LBL_SETUP);  // GSTATS 2
   if (!G.init) EMI_FAIL(EMI_ERR_STATE, "SETUP_TRANS: SETUP_TRANS0 HAS TO BE CALLED BEFORE SETUP_TRANS");
   if (!cfg) EMI_FAIL(EMI_ERR_ARG, "emi_setup: null config");
   if (cfg->kdgl <= 0 || cfg->kdgl % 2 != 0) EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: KDGL IS NOT A POSITIVE, EVEN NUMBER");
@@ -1221,6 +1268,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
         return EMI_ERR_RUNTIME;
       }
       LegPolDev la{d_mu, d_dcl, d_ddl, d_zf, d_blk, P.ndgnh, nmax};
+      EmiRange rg_suleg(EMI_LBL_SULEG);  // GSTATS 140
       EMI_LAUNCH_P(P.esz, k_legpol, blk.size() / 2, 64, 0, (emi_stream_t)0, P.g, la);
       emi_stream_sync(0);
       for (void *q : {(void *)d_dcl, (void *)d_ddl, (void *)d_zf, (void *)d_mu, (void *)d_blk}) emi_dev_free(q);
@@ -2202,21 +2250,26 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     // stream A: spectral pack + Legendre; FBl[ib&1] was last read by the FFT (one task) or by the
     // exchange (several tasks) of batch ib-2
     if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + (dist ? 2 : 1), sA);
-    int iv = g_pt.start(0, sA);
+    int iv;
     {
-      long long nblk = (long long)P.wrows_total * ((bfpad_b + 255) / 256);
-      EMI_LAUNCH_P(P.esz, k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad_b, (RT *)P.d_W, ldw, (long long)P.wrows_total);
+      EmiRange rg(EMI_LBL_LTINV);  // GSTATS 102: PRFI1B / VDTUV / SPNSDE + LEINV + ASRE1B
+      iv = g_pt.start(0, sA);
+      {
+        long long nblk = (long long)P.wrows_total * ((bfpad_b + 255) / 256);
+        EMI_LAUNCH_P(P.esz, k_prepack_inv, nblk, 256, 0, sA, P.g, d_bl, bt.nl, bfpad_b, (RT *)P.d_W, ldw, (long long)P.wrows_total);
+      }
+      g_pt.stop(iv, sA);
+      iv = g_pt.start(1, sA);
+      LegMaps *lmaps = bmaps[ib];
+      EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
+      g_pt.stop(iv, sA);
     }
-    g_pt.stop(iv, sA);
-    iv = g_pt.start(1, sA);
-    LegMaps *lmaps = bmaps[ib];
-    EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
-    g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib, sA);
     if (dist) {
       // stream X: TRMTOL; FBf[ib&1] was last read by the FFT of batch ib-2
       if (piped) g_pipe.wait(3 * ib, sX);
       if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + 1, sX);
+      EmiRange rg(EMI_LBL_TRMTOL);  // GSTATS 152
       if (exchange(P, true, ldw, sX, FBl, FBf)) {
         if (piped) g_pipe.end(st);  // the three streams were forked from the caller's: join them before giving up
         plan_end(P, st);
@@ -2226,6 +2279,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
     }
     // stream B: FFTs
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sB);
+    EmiRange rgf(EMI_LBL_FTINV);  // GSTATS 107: FOURIER_IN + FSC + FTINV + TRLTOG
     iv = g_pt.start(2, sB);
     if (launch_fft(P, true, adj, d_bg, bt.ng, FBf, ldw, nproma, sB)) {
       if (piped) g_pipe.end(st);
@@ -2472,18 +2526,23 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
     // stream B: FFTs; FBf[ib&1] was last read by the Legendre transform (one task) or by the exchange
     // (several tasks) of batch ib-2
     if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + (dist ? 2 : 1), sB);
-    int iv = g_pt.start(2, sB);
-    if (launch_fft(P, false, adj, d_bg, bt.ng, FBf, ldw, nproma, sB)) {
-      if (piped) g_pipe.end(st);
-      plan_end(P, st);
-      return EMI_ERR_RUNTIME;
+    int iv;
+    {
+      EmiRange rg(EMI_LBL_FTDIR);  // GSTATS 106: TRGTOL + FTDIR + FOURIER_OUT
+      iv = g_pt.start(2, sB);
+      if (launch_fft(P, false, adj, d_bg, bt.ng, FBf, ldw, nproma, sB)) {
+        if (piped) g_pipe.end(st);
+        plan_end(P, st);
+        return EMI_ERR_RUNTIME;
+      }
+      g_pt.stop(iv, sB);
     }
-    g_pt.stop(iv, sB);
     if (piped) g_pipe.signal(3 * ib, sB);
     if (dist) {
       // stream X: TRLTOM; FBl[ib&1] was last read by the Legendre transform of batch ib-2
       if (piped) g_pipe.wait(3 * ib, sX);
       if (piped && ib >= 2) g_pipe.wait(3 * (ib - 2) + 1, sX);
+      EmiRange rg(EMI_LBL_TRLTOM);  // GSTATS 153
       if (exchange(P, false, ldw, sX, FBl, FBf)) {
         if (piped) g_pipe.end(st);
         plan_end(P, st);
@@ -2493,6 +2552,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
     }
     // stream A: Legendre + spectral unpack
     if (piped) g_pipe.wait(3 * ib + (dist ? 2 : 0), sA);
+    EmiRange rgl(EMI_LBL_LTDIR);  // GSTATS 103: PRFI2B + LEDIR + UVTVD + UPDSP
     iv = g_pt.start(1, sA);
     // the zero row of this batch: row `lrows_call` in the batch's own row width (the buffer held other data before)
     emi_dev_memset(FBl + (size_t)lrows_call * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
@@ -2614,6 +2674,12 @@ extern "C" int emi_set_host_collectives(emi_bcast_fn bcast, emi_allgatherv_fn al
   G.hc_bcast = bcast;
   G.hc_gather = allgatherv;
   G.hc_user = user;
+  return EMI_SUCCESS;
+}
+extern "C" int emi_inq_init(int *kmax_resol, double *prad) {
+  if (!G.init) EMI_FAIL(EMI_ERR_STATE, "emi_inq_init: SETUP_TRANS0 has not been called");
+  if (kmax_resol) *kmax_resol = G.max_resol;
+  if (prad) *prad = G.ra;
   return EMI_SUCCESS;
 }
 extern "C" int emi_inq_tasks(int *nproc, int *myproc) {
@@ -2817,8 +2883,14 @@ extern "C" int emi_crc64(const void *data, size_t bytes, unsigned long long *crc
   return EMI_SUCCESS;
 }
 
-extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *args) { return inv_trans_impl(kresol, args, false); }
-extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *args) { return dir_trans_impl(kresol, args, false); }
+extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *args) {
+  EmiRange rg(EMI_LBL_INV);  // GSTATS 4
+  return inv_trans_impl(kresol, args, false);
+}
+extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *args) {
+  EmiRange rg(EMI_LBL_DIR);  // GSTATS 5
+  return dir_trans_impl(kresol, args, false);
+}
 
 // INV_TRANSAD (include/ectrans/inv_transad.h): arguments of INV_TRANS with the intents swapped
 extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {

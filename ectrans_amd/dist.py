@@ -181,3 +181,49 @@ def all_gather_padded(a, nmax, group=None, device=None):
     out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, t, group=group)
     return [o.cpu().numpy() for o in out]
+
+
+_RCCL = [None]
+
+
+def rccl_native_lib():
+    """libectrans_mi_rccl.so (ectrans_amd/rccl): the transport a Fortran / C host attaches -- one group of ncclSend / ncclRecv
+    per exchange on the library's own stream, no Python in the data path."""
+    import os
+    if _RCCL[0] is None:
+        from . import lib
+        lib()  # libectrans_mi.so first: the hook library resolves its symbols against the instance already loaded
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl", "libectrans_mi_rccl.so")
+        if not os.path.exists(path):
+            raise OSError("%s is missing: make -C ectrans_amd/rccl" % path)
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        L.emi_rccl_get_unique_id.argtypes = [C.c_void_p]
+        L.emi_rccl_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        L.emi_rccl_last_error.restype = C.c_char_p
+        _RCCL[0] = L
+    return _RCCL[0]
+
+
+def rccl_native_attach(nproc, myproc, kmax_resol=1, kprintlev=0, prad=0.0, device=-1, group=None):
+    """SETUP_TRANS0 through the native RCCL transport (emi_rccl_attach): task 1 draws the 128-byte RCCL unique id and the
+    process group carries it to the other tasks (torch.distributed here; MPI_Bcast in a Fortran host); every
+    task then creates its rank of the communicator, registers the grouped ncclSend / ncclRecv exchange and the host collectives
+    of DIST_x / GATH_x, and initialises the library as task `myproc` of `nproc`.  Returns 0 or raises OSError with the
+    transport's message."""
+    import torch.distributed as dist
+    L = rccl_native_lib()
+    uid = C.create_string_buffer(128)
+    if myproc == 1:
+        if L.emi_rccl_get_unique_id(uid):
+            raise OSError("emi_rccl_get_unique_id: " + (L.emi_rccl_last_error() or b"").decode())
+    box = [uid.raw if myproc == 1 else None]
+    if nproc > 1:
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+    uid2 = C.create_string_buffer(box[0], 128)
+    rc = L.emi_rccl_attach(uid2, int(nproc), int(myproc), int(kmax_resol), int(kprintlev), float(prad or 0.0), int(device if device is not None else -1))
+    if rc:
+        from . import lib
+        msg = (L.emi_rccl_last_error() or b"").decode() or (lib().emi_last_error() or b"").decode()
+        raise OSError("emi_rccl_attach failed (%d): %s" % (rc, msg))
+    return 0

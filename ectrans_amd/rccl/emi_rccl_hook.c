@@ -51,12 +51,17 @@ int emi_rccl_alltoallv(void *user, const void *sendbuf, const long long *sc, con
   if (sc[g_me] > 0)
     HIP_TRY(hipMemcpyAsync((char *)recvbuf + rd[g_me], (const char *)sendbuf + sd[g_me], (size_t)sc[g_me], hipMemcpyDeviceToDevice, st));
   RCCL_TRY(ncclGroupStart());
-  for (int r = 0; r < nproc; r++) {
+  ncclResult_t bad = ncclSuccess;  /* a failed send / recv must not leave the group open: close it, then report */
+  for (int r = 0; r < nproc && bad == ncclSuccess; r++) {
     if (r == g_me) continue;
-    if (sc[r] > 0) RCCL_TRY(ncclSend((const char *)sendbuf + sd[r], (size_t)sc[r], ncclChar, r, g_comm, st));
-    if (rc[r] > 0) RCCL_TRY(ncclRecv((char *)recvbuf + rd[r], (size_t)rc[r], ncclChar, r, g_comm, st));
+    if (sc[r] > 0) bad = ncclSend((const char *)sendbuf + sd[r], (size_t)sc[r], ncclChar, r, g_comm, st);
+    if (bad == ncclSuccess && rc[r] > 0) bad = ncclRecv((char *)recvbuf + rd[r], (size_t)rc[r], ncclChar, r, g_comm, st);
   }
-  RCCL_TRY(ncclGroupEnd());
+  const ncclResult_t endr = ncclGroupEnd();
+  if (bad != ncclSuccess || endr != ncclSuccess) {
+    snprintf(g_err, sizeof(g_err), "grouped ncclSend / ncclRecv exchange failed: %s", ncclGetErrorString(bad != ncclSuccess ? bad : endr));
+    return EMI_ERR_RUNTIME;
+  }
   return 0;
 }
 
@@ -64,14 +69,26 @@ int emi_rccl_alltoallv(void *user, const void *sendbuf, const long long *sc, con
 static int hc_bcast(void *user, void *buf, long long bytes, int root) {
   (void)user;
   if (g_nproc == 1 || bytes == 0) return 0;
+  /* chunks of at most 256 MiB through one staging buffer, released on every path */
+  const size_t chunk = (size_t)bytes < ((size_t)256 << 20) ? (size_t)bytes : ((size_t)256 << 20);
   void *d = NULL;
-  HIP_TRY(hipMalloc(&d, (size_t)bytes));
-  if (root == g_me) HIP_TRY(hipMemcpy(d, buf, (size_t)bytes, hipMemcpyHostToDevice));
-  RCCL_TRY(ncclBroadcast(d, d, (size_t)bytes, ncclChar, root, g_comm, (hipStream_t)0));
-  HIP_TRY(hipStreamSynchronize((hipStream_t)0));
-  if (root != g_me) HIP_TRY(hipMemcpy(buf, d, (size_t)bytes, hipMemcpyDeviceToHost));
-  HIP_TRY(hipFree(d));
-  return 0;
+  HIP_TRY(hipMalloc(&d, chunk));
+  int rc = 0;
+  for (size_t off = 0; off < (size_t)bytes && !rc; off += chunk) {
+    const size_t nb = (size_t)bytes - off < chunk ? (size_t)bytes - off : chunk;
+    hipError_t e = hipSuccess;
+    ncclResult_t r = ncclSuccess;
+    if (root == g_me) e = hipMemcpy(d, (char *)buf + off, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) r = ncclBroadcast(d, d, nb, ncclChar, root, g_comm, (hipStream_t)0);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize((hipStream_t)0);
+    if (e == hipSuccess && r == ncclSuccess && root != g_me) e = hipMemcpy((char *)buf + off, d, nb, hipMemcpyDeviceToHost);
+    if (e != hipSuccess || r != ncclSuccess) {
+      snprintf(g_err, sizeof(g_err), "broadcast of %lld host bytes failed: %s", bytes, e != hipSuccess ? hipGetErrorString(e) : ncclGetErrorString(r));
+      rc = -1;
+    }
+  }
+  (void)hipFree(d);
+  return rc;
 }
 static int hc_allgatherv(void *user, const void *sendbuf, long long sendbytes, void *recvbuf, const long long *recvbytes, const long long *displs,
                          int nproc) {
@@ -136,7 +153,14 @@ int emi_rccl_attach(const void *id, int nproc, int myproc, int kmax_resol, int k
   memcpy(&u, id, sizeof(u));
   RCCL_TRY(ncclCommInitRank(&g_comm, nproc, u, myproc - 1));
   g_owned = 1;
-  return attach_common(nproc, myproc, kmax_resol, kprintlev, prad, dev);
+  const int rc = attach_common(nproc, myproc, kmax_resol, kprintlev, prad, dev);
+  if (rc) { /* emi_init refused: do not keep a communicator nobody will destroy */
+    (void)ncclCommDestroy(g_comm);
+    g_comm = NULL;
+    g_owned = 0;
+    (void)emi_set_alltoallv(NULL, NULL);
+  }
+  return rc;
 }
 
 int emi_rccl_attach_comm(void *nccl_comm, int nproc, int myproc, int kmax_resol, int kprintlev, double prad, int device) {
@@ -154,11 +178,16 @@ int emi_rccl_specnorm(int kresol, int mem_space, const void *spec, int nfld, dou
   if (g_nproc > 1) {
     double *d = NULL;
     HIP_TRY(hipMalloc((void **)&d, sizeof(double) * (size_t)nfld));
-    HIP_TRY(hipMemcpy(d, norms, sizeof(double) * (size_t)nfld, hipMemcpyHostToDevice));
-    RCCL_TRY(ncclAllReduce(d, d, (size_t)nfld, ncclDouble, ncclSum, g_comm, (hipStream_t)0));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)0));
-    HIP_TRY(hipMemcpy(norms, d, sizeof(double) * (size_t)nfld, hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d));
+    hipError_t e = hipMemcpy(d, norms, sizeof(double) * (size_t)nfld, hipMemcpyHostToDevice);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = ncclAllReduce(d, d, (size_t)nfld, ncclDouble, ncclSum, g_comm, (hipStream_t)0);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize((hipStream_t)0);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(norms, d, sizeof(double) * (size_t)nfld, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess || r != ncclSuccess) {
+      snprintf(g_err, sizeof(g_err), "SPECNORM all-reduce failed: %s", e != hipSuccess ? hipGetErrorString(e) : ncclGetErrorString(r));
+      return EMI_ERR_RUNTIME;
+    }
   }
   for (int f = 0; f < nfld; f++) norms[f] = sqrt(norms[f]);
   return EMI_SUCCESS;

@@ -7,8 +7,9 @@
 
 #include "../../include/ectrans_mi.h"
 
-static int g_limit = 100;
+static int g_limit = 100, g_limit_set = 0;
 static double g_radius = 6371.22e3;
+static int g_radius_set = 0;
 static int g_init = 0;
 static char g_msg[1200];
 
@@ -46,11 +47,13 @@ int trans_set_leq_regions(_bool b) {
 int trans_set_handles_limit(int n) {
   if (g_init) return TRANS_ERROR;
   g_limit = n;
+  g_limit_set = 1;
   return TRANS_SUCCESS;
 }
 int trans_set_radius(double r) {
   if (g_init) return TRANS_ERROR;
   g_radius = r;
+  g_radius_set = 1;
   return TRANS_SUCCESS;
 }
 
@@ -58,6 +61,16 @@ int trans_init(void) {
   if (g_init) return TRANS_SUCCESS;
   int np = 0, me = 0;
   if (emi_inq_tasks(&np, &me) == 0) { /* a transport (or the host) has initialised the library: adopt its tasks */
+    /* ... but not silently its handle limit and planet radius: trans_set_handles_limit / trans_set_radius of this host must
+     * agree with what the transport passed to emi_init (transi's own default radius is 6371.22e3, transi_module.F90:129-136) */
+    int lim = 0;
+    double rad = 0.0;
+    if (emi_inq_init(&lim, &rad) != 0) return TRANS_ERROR;
+    if ((g_limit_set && g_limit > lim) || (g_radius_set && g_radius != rad)) {
+      fprintf(stderr, "trans_init: the attached transport initialised the library with kmax_resol %d, radius %.17g; this host asks for %d, %.17g\n",
+              lim, rad, g_limit, g_radius);
+      return TRANS_ERROR;
+    }
     g_init = 1;
     return TRANS_SUCCESS;
   }

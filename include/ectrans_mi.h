@@ -219,6 +219,10 @@ int emi_gath_grid(int kresol, void *gpg, int nfld, const int *kto, int kproma, c
 /* What emi_init was given (EMI_ERR_STATE before it): a Fortran host whose transport attached first (emi_mpi_attach,
  * emi_rccl_attach) learns its task number from here in SETUP_TRANS0.                                                 */
 int emi_inq_tasks(int *nproc, int *myproc);
+/* KMAX_RESOL and PRAD the library was initialised with (setup_trans0.F90:113-129): SETUP_TRANS0 / trans_init of a host whose
+ * transport called emi_init first compare their own arguments with these and abort on a mismatch instead of silently
+ * computing with the transport's planet radius.                                                                      */
+int emi_inq_init(int *kmax_resol, double *prad);
 
 /* ---- TRANS_RELEASE / TRANS_END (trans/cpu/external/trans_release.F90, trans_end.F90) -- */
 int emi_release(int kresol);
@@ -240,6 +244,11 @@ int emi_last_phase_launches(int *l3);
  * 2 accumulated over all calls since this emi_set_profile(2) (nothing is resolved, hence nothing
  * synchronises, between the calls of a timed loop; up to 4096 intervals).                   */
 int emi_set_profile(int on);
+/* 1 when the roctx ranges are live: INV_TRANS / DIR_TRANS / LTINV_CTL / LTDIR_CTL / FTDIR_CTL / FTINV_CTL / the two
+ * transpositions / SETUP_TRANS / SULEG, with the GSTATS labels of the reference harness (gpu/internal/tpm_stats.F90:33-55 maps
+ * GSTATS to NVTX ranges; src/programs/ectrans-benchmark.F90:1681-1697), around the host-side enqueue of each phase.
+ * librocprofiler-sdk-roctx is opened at run time; EMI_ROCTX=0 switches the ranges off.       */
+int emi_roctx_active(void);
 /* Upper bound on Fourier-space fields per batch (0: from free HBM).                         */
 int emi_set_max_batch(int max_fields);
 

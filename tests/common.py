@@ -376,7 +376,13 @@ def full_size_call_mode2(et, Oracle, nsmax, nlev, nfld, precision=8, tol=1e-11, 
             # same rows -- both measured against the fp64 oracle, relative to the field maximum
             off = np.concatenate([[0], np.cumsum(nloen)])
             fmax = float(np.abs(gref[2]).max())
-            y32 = fp32_rows_inverse(o, nsmax, nloen, S[:, 0], yardstick["lats"])
+            # the sampled rows plus the three northern rows on which the HIP result of this field is worst
+            dsurf = (gp2[0, 0].double() / c2 - tg[2].double()).abs_()
+            per_lat = group_max(dsurf[None], rows)[0][:len(nloen) // 2]
+            worst_lats = [int(j) + 1 for j in torch.topk(per_lat, 3).indices.cpu().numpy()]
+            res["inv_fp32_worst_rows"] = worst_lats
+            del dsurf
+            y32 = fp32_rows_inverse(o, nsmax, nloen, S[:, 0], sorted(set(list(yardstick["lats"]) + worst_lats)))
             worst_ratio, e32s, ehs = 0.0, [], []
             for jgl, row32 in y32.items():
                 ref = gref[2][off[jgl - 1]:off[jgl]]
@@ -410,8 +416,16 @@ def full_size_call_mode2(et, Oracle, nsmax, nlev, nfld, precision=8, tol=1e-11, 
         res["dir"], res["dir_rms"], res["dir_n"] = e_dir, rms[0], gworst[0]
         if yardstick:
             smax = float(np.abs(sr[:, 0]).max())
-            y32 = fp32_columns_direct(o, nsmax, nloen, gin[2], yardstick["ms"])
             hip2 = spsc2[:, 0].double().cpu().numpy() / c2
+            # ... plus the three zonal wavenumbers on which the HIP result of this field is worst
+            m_of = np.zeros(ns2, dtype=np.int64)
+            for m in range(nsmax + 1):
+                m_of[o.nasm0[m] - 1:o.nasm0[m] - 1 + 2 * (nsmax - m + 1)] = m
+            per_m = np.zeros(nsmax + 1)
+            np.maximum.at(per_m, m_of, np.abs(hip2 - sr[:, 0]))
+            worst_ms = [int(m) for m in np.argsort(per_m)[-3:]]
+            res["dir_fp32_worst_ms"] = worst_ms
+            y32 = fp32_columns_direct(o, nsmax, nloen, gin[2], sorted(set(list(yardstick["ms"]) + worst_ms)))
             worst_ratio, e32s, ehs = 0.0, [], []
             for m, x32 in y32.items():
                 i0 = o.nasm0[m] - 1

@@ -456,3 +456,10 @@ def test_closed_form_winds_and_derivatives(et):
     finally:
         et.trans_release(r)
     assert max(e_inv) < 1e-12 and max(e_dir) < 1e-12, (e_inv, e_dir)
+
+
+def test_inquiry_of_the_initialisation(et):
+    """emi_inq_init: KMAX_RESOL and PRAD of SETUP_TRANS0 -- SETUP_TRANS0 / trans_init of a host whose transport initialised
+    the library first abort on a different radius instead of computing with the transport's."""
+    kmax, ra = et.inq_init()
+    assert kmax >= 1 and ra == 6371229.0  # setup_trans0.F90:129 default

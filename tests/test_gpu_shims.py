@@ -165,3 +165,37 @@ def test_transi_c_api_several_tasks(ntasks):
     env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     p = subprocess.run([mpiexec, "-n", str(ntasks), os.path.join(d, "transi_test_mpi")], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and p.stdout.count("TRANSI MPI OK") == ntasks, p.stdout + p.stderr
+
+
+def test_python_host_attaches_the_native_rccl_transport():
+    """setup_trans0(transport="rccl") -- what `bench.py --gpus N` uses for N > 1 (round 3): emi_rccl_get_unique_id,
+    emi_rccl_attach (communicator, exchange hook, host collectives, emi_init) from a Python host, then a transform pair
+    against the oracle.  One task on the one-GPU box (RCCL refuses two ranks on one device); own process: the
+    library is initialised once per process."""
+    import sys
+    code = """
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import ectrans_amd as et
+from oracle.oracle import Oracle
+from tests.common import octahedral, random_spectrum
+et.setup_trans0(kmax_resol=2, device=0, kprtrw=1, myproc=1, transport="rccl")
+assert et.inq_init()[0] == 2
+N = 21; nloen = octahedral(N)
+r = et.setup_trans(N, len(nloen), nloen)
+o = Oracle(N, nloen)
+sp = random_spectrum(np.random.default_rng(2), o.nasm0, N, o.nspec2, 3, False)
+gp = torch.zeros((1, 3, o.ngptot), dtype=torch.float64, device="cuda:0")
+et.inv_trans(r, pspscalar=torch.from_numpy(sp).to("cuda:0"), pgp=gp)
+g = o.inv_trans(spsc=sp)
+assert np.abs(gp[0].cpu().numpy() - g).max() / np.abs(g).max() < 1e-12
+s2 = torch.zeros((o.nspec2, 3), dtype=torch.float64, device="cuda:0")
+et.dir_trans(r, pspscalar=s2, pgp=gp)
+ref = o.dir_trans(g, nsc=3)[2]
+assert np.abs(s2.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-12
+assert abs(et.specnorm(r, s2)[0] / o.specnorm(ref)[0] - 1) < 1e-13
+et.trans_end()
+print("NATIVE RCCL ATTACH OK")
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "NATIVE RCCL ATTACH OK" in p.stdout, p.stdout + p.stderr
