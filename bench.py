@@ -86,6 +86,13 @@ def cpu_baseline(nsmax, kf_full, budget_s=20.0, gpu=None):
     nf = int(max(1, min(64, budget_s / max(t1, 1e-3))))
     t = pair(nf) if nf > 1 else t1
     kf = 3 * nf
+    blas = None
+    if os.environ.get("EMI_BENCH_BLAS", "1") != "0":
+        try:
+            nf_ = keep["nf"]
+            blas = cpu_baseline_blas(o, nsmax, kf_full, keep["sc"], keep["g"][2 * nf_:3 * nf_], keep["out"][2], cores)
+        except Exception as e:  # the port stays the reported baseline if the library leg cannot run on this host
+            blas = {"error": repr(e)}
     base = {"value": (1.0 / t) * kf / kf_full, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": "same grid+truncation, dense spectrum, %d of %d Fourier fields (vor/div/scalar x %d), scaled linearly in KF; "
                       "oracle setup %.1fs not included" % (kf, kf_full, nf, t_setup)}
@@ -108,7 +115,103 @@ def cpu_baseline(nsmax, kf_full, budget_s=20.0, gpu=None):
         drift = float(np.abs(et.specnorm(r, to(keep["sc"])) / et.specnorm(r, s2) - 1.0).max())
         dense = {"fields": kf, "checker": "oracle (CPU restatement), same inputs", "inv_max_rel_err": e_inv, "dir_max_rel_err": e_dir,
                  "spectral_norm_rel_err_vs_oracle": e_norm, "spectral_norm_rel_error_round_trip": drift}
-    return base, dense
+    return base, dense, blas
+
+
+def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=64):
+    """A second CPU baseline on LIBRARY BLAS + FFT -- the closest stand-in for the reference's FFTW + BLAS path that may travel
+    (north_star; ledir_mod.F90:130,204 / leinv_mod.F90:133,166 call DGEMM, tpm_fftw.F90:294-316 FFTW): the Legendre transforms as
+    torch.matmul (MKL) on the ORACLE's panels, the Fourier transforms as scipy.fft (pocketfft) per latitude on a thread pool,
+    scalar fields only (the wind stencils are not where the time goes).  The first columns are the oracle's own sample and
+    must reproduce its results; pairs/s scaled linearly in the field count, as cpu_baseline."""
+    import scipy.fft
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    torch.set_num_threads(cores)
+    nloen = octahedral(nsmax)
+    ndgl, H = len(nloen), len(nloen) // 2
+    nasm0, nmen, ndglu, rw = o.nasm0, o.nmen, o.ndglu, o.rw
+    off = np.concatenate([[0], np.cumsum(nloen)])
+    nref = sc_ref.shape[1]
+    rng = np.random.default_rng(7)
+    nf = max(nf_total, nref)
+    sc = np.concatenate([sc_ref, random_spectrum(rng, nasm0, nsmax, o.nspec2, nf - nref, False)], axis=1) if nf > nref else sc_ref
+    # the panels as the BLAS operands (set-up, not timed: the reference keeps RPNMA / RPNMS in memory too)
+    Ps, Pa = [], []
+    for m in range(nsmax + 1):
+        ps, pa = o.rpnm(m, True), o.rpnm(m, False)  # [column: n descending][latitude]
+        # [k][lat], n = m + 2 k (+ 1); the panels also hold the row n = N + 1 the wind stencils use: dropped here (scalars only)
+        Ps.append(torch.from_numpy(ps[::-1][:(nsmax - m) // 2 + 1].copy()))
+        Pa.append(torch.from_numpy(pa[::-1][:(nsmax - m + 1) // 2].copy()))
+    pool = ThreadPoolExecutor(max_workers=min(cores, 64))
+
+    def coeffs(spec, m):
+        i0 = nasm0[m] - 1
+        z = spec[i0:i0 + 2 * (nsmax - m + 1)].reshape(nsmax - m + 1, 2, -1)  # [n - m][re | im][field]
+        return torch.from_numpy(np.ascontiguousarray(z[0::2].reshape(-1, 2 * z.shape[2]))), torch.from_numpy(np.ascontiguousarray(z[1::2].reshape(-1, 2 * z.shape[2])))
+
+    def inverse(spec):
+        nfl = spec.shape[1]
+        FN, FS = np.zeros((H, nsmax + 1, 2 * nfl)), np.zeros((H, nsmax + 1, 2 * nfl))
+        for m in range(nsmax + 1):
+            K = int(min(H, ndglu[m]))
+            if K <= 0:
+                continue
+            xs, xa = coeffs(spec, m)
+            S = (Ps[m].T @ xs).numpy()  # LEINV: (K x ILS) (ILS x 2 KF)
+            A = (Pa[m].T @ xa).numpy() if xa.shape[0] else 0.0
+            FN[H - K:, m], FS[H - K:, m] = S + A, S - A  # ASRE1B
+        grid = np.zeros((nfl, int(off[-1])))
+
+        def row(j):
+            n, jn = int(nloen[j]), (j if j < H else ndgl - 1 - j)
+            M = int(min(nmen[j], n // 2))
+            X = np.zeros((nfl, n // 2 + 1), dtype=np.complex128)
+            F = (FN if j < H else FS)[jn, :M + 1]  # [m][re | im][field]
+            F = F.reshape(M + 1, 2, nfl)
+            X[:, :M + 1] = (F[:, 0] + 1j * F[:, 1]).T
+            grid[:, off[j]:off[j + 1]] = scipy.fft.irfft(X, n, axis=1) * n  # FTINV: c2r, unscaled
+
+        list(pool.map(row, range(ndgl)))
+        return grid
+
+    def direct(grid):
+        nfl = grid.shape[0]
+        FN, FS = np.zeros((H, nsmax + 1, 2 * nfl)), np.zeros((H, nsmax + 1, 2 * nfl))
+
+        def row(j):
+            n, jn = int(nloen[j]), (j if j < H else ndgl - 1 - j)
+            M = int(min(nmen[j], n // 2))
+            X = scipy.fft.rfft(grid[:, off[j]:off[j + 1]], axis=1)[:, :M + 1] * (rw[j] / n)  # FTDIR scaled 1 / NLOEN, times the Gaussian weight
+            (FN if j < H else FS)[jn, :M + 1] = np.stack([X.real.T, X.imag.T], axis=1).reshape(M + 1, 2 * nfl)
+
+        list(pool.map(row, range(ndgl)))
+        spec = np.zeros((o.nspec2, nfl))
+        for m in range(nsmax + 1):
+            K = int(min(H, ndglu[m]))
+            if K <= 0:
+                continue
+            fn, fs = torch.from_numpy(FN[H - K:, m]), torch.from_numpy(FS[H - K:, m])
+            xs = (Ps[m] @ (fn + fs)).numpy().reshape(-1, 2, nfl)  # LEDIR: (ILS x K) (K x 2 KF)
+            xa = (Pa[m] @ (fn - fs)).numpy().reshape(-1, 2, nfl)
+            i0 = nasm0[m] - 1
+            z = spec[i0:i0 + 2 * (nsmax - m + 1)].reshape(nsmax - m + 1, 2, nfl)
+            z[0::2], z[1::2] = xs, xa
+            if m == 0:
+                z[:, 1] = 0.0
+        return spec
+
+    t = time.time()
+    g = inverse(sc)
+    s2 = direct(g)
+    dt = time.time() - t
+    rel = lambda a, b: float((np.abs(a - b).max(axis=-1) / np.abs(b).max(axis=-1)).max())
+    e_inv, e_dir = rel(g[:nref], g_ref), rel(s2[:, :nref].T, s_ref.T)
+    pool.shutdown()
+    return {"value": (1.0 / dt) * nf / kf_full, "unit": "pairs/s", "cores": cores, "kind": "library BLAS + FFT on the oracle's panels",
+            "libraries": "torch.matmul (MKL, %d threads) for LEINV / LEDIR, scipy.fft (pocketfft) per latitude on a thread pool" % cores,
+            "sample": "same grid+truncation, dense spectrum, %d scalar fields of %d Fourier fields, scaled linearly in KF; panels and thread pool set up outside the timed pair" % (nf, kf_full),
+            "inv_max_rel_err_vs_oracle": e_inv, "dir_max_rel_err_vs_oracle": e_dir}
 
 
 def api_level(et, r, N, kf_full, esz, nf=128, pairs=2):
@@ -148,6 +251,27 @@ def api_level(et, r, N, kf_full, esz, nf=128, pairs=2):
             "harmonic_check": chk,
             "pageable": {"ms_per_pair_at_kf": tp * 1e3, "effective_GBps": moved / 1e9 / tp, "harmonic_check": chkp,
                          "memory": "pageable host (numpy), EMI_MEM_HOST"}}
+
+
+def recorded_fft_bound(N, nlev, nfld, esz, world, source_hash):
+    """The FFT phase against the bound it is actually on: SIMD issue time -- vector-ALU + LDS + other
+    instruction issue of the FFT launches as a share of their duration, from the SQ counters of tools/pmc_fft.sh, quoted only
+    when the counter file was taken on this very build of the library (same source hash)."""
+    import glob
+    import json
+    if (N, nlev, nfld, esz, world) != (1279, 137, 10, 8, 1):
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_fft.json")), reverse=True):
+        try:
+            js = json.load(open(f))
+        except Exception:
+            continue
+        if js.get("source_hash") == source_hash:
+            return {"bound": "SIMD instruction issue (fp64 vector ALU + LDS + other), chip clock lowered under this load",
+                    "simd_issue_share": js["simd_issue_share"], "wave_life_share": js["wave_life_share"], "fft_ms_per_pair_under_profiler": js["fft_ms_per_pair"],
+                    "source": os.path.basename(f)}
+    return {"bound": None, "source": "no profiles/*_pmc_fft.json for this build (source hash %s): re-run tools/pmc_fft.sh" % source_hash}
 
 
 def recorded_traffic(N, nlev, nfld, esz, world, source_hash):
@@ -370,6 +494,7 @@ def main():
             "fft_hbm": {"algorithmic_GB_per_step": 2 * (wm["fourier_bytes"] + kf * ngptot * float(esz)) / 1e9,
                         "achieved_GBps": 2 * (wm["fourier_bytes"] + kf * ngptot * float(esz)) / 1e9 / max(fft_ms / args.steps * 1e-3, 1e-9),
                         "peak_GBps": 8000.0 * world},
+            "fft_bound": recorded_fft_bound(N, nlev, nfld, esz, world, et.source_hash()),
         }
         if world == 1 and not args.no_api_level:
             # free the device-resident benchmark arrays first: the staging buffers of the host calls need the room
@@ -378,7 +503,7 @@ def main():
             out["api_level"] = api_level(et, r, N, kf, esz)
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
-            out["cpu_baseline"], out["dense"] = cpu_baseline(N, kf, gpu=(et, r, dev) if esz == 8 else None)
+            out["cpu_baseline"], out["dense"], out["cpu_baseline_blas"] = cpu_baseline(N, kf, gpu=(et, r, dev) if esz == 8 else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -29,4 +29,21 @@ with open("gpurun_out/${TAG}_pmc_fft.txt","w") as fh:
             a["SQ_WAIT_ANY"]/a["SQ_WAVE_CYCLES"],a["SQ_WAIT_INST_ANY"]/a["SQ_WAVE_CYCLES"],
             a["SQ_LDS_BANK_CONFLICT"]/max(1.0,a["SQ_LDS_IDX_ACTIVE"])))
 print(open("gpurun_out/${TAG}_pmc_fft.txt").read())
+# machine-readable summary for bench.py's `fft_bound` block: duration-weighted issue shares of all FFT launches of one pair,
+# stamped with the hash of the library sources (bench.py quotes it only for the build it was taken on)
+import json, sys
+sys.path.insert(0, ".")
+import ectrans_amd
+tot = sum(dur.values())
+w = lambda key, den: sum(dur[k] * acc[k][key] / (acc[k]["SQ_BUSY_CYCLES"] / 32.0 * 1024.0 / 4.0 if den == "simd" else acc[k]["SQ_WAVE_CYCLES"]) for k in dur if acc[k].get("SQ_WAVES")) / tot
+js = {"source_hash": ectrans_amd.source_hash(), "workload": "tools/gpu_perf.py 1279 137 10 (TCo1279, KF = 1645, fp64), one pair, all k_fft_* launches",
+      "fft_ms_per_pair": tot, "simd_issue_share": {"valu": w("SQ_ACTIVE_INST_VALU", "simd"), "lds": w("SQ_ACTIVE_INST_LDS", "simd"), "any": w("SQ_ACTIVE_INST_ANY", "simd")},
+      "wave_life_share": {"wait_any": w("SQ_WAIT_ANY", "wave"), "wait_inst_any": w("SQ_WAIT_INST_ANY", "wave")},
+      "kernels": {k: {"ms": dur[k], "valu_per_wave": acc[k]["SQ_INSTS_VALU"] / acc[k]["SQ_WAVES"], "lds_per_wave": acc[k]["SQ_INSTS_LDS"] / acc[k]["SQ_WAVES"],
+                      "clock_GHz": acc[k]["SQ_BUSY_CYCLES"] / 32.0 / dur[k] / 1e6,
+                      "valu_share": acc[k]["SQ_ACTIVE_INST_VALU"] / (acc[k]["SQ_BUSY_CYCLES"] / 32.0 * 256.0), "any_share": acc[k]["SQ_ACTIVE_INST_ANY"] / (acc[k]["SQ_BUSY_CYCLES"] / 32.0 * 256.0),
+                      "lds_bank_conflict_share": acc[k]["SQ_LDS_BANK_CONFLICT"] / max(1.0, acc[k]["SQ_LDS_IDX_ACTIVE"])} for k in dur if acc[k].get("SQ_WAVES")},
+      "method": "rocprofv3 --pmc, two passes (SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_BUSY_CYCLES; SQ_INSTS_* / SQ_LDS_*), kernel trace only; shares = counter (quad-cycles, summed over SIMDs) / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs / 4), weighted by launch duration"}
+json.dump(js, open("gpurun_out/${TAG}_pmc_fft.json", "w"), indent=1)
+print(json.dumps({k: js[k] for k in ("fft_ms_per_pair", "simd_issue_share", "wave_life_share", "source_hash")}))
 PY
