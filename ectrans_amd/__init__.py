@@ -35,7 +35,13 @@ class TransError(RuntimeError):
 
 class _Init(C.Structure):
     _fields_ = [("kmax_resol", C.c_int), ("kprintlev", C.c_int), ("prad", C.c_double), ("nproc", C.c_int),
-                ("myproc", C.c_int), ("device", C.c_int)]
+                ("myproc", C.c_int), ("device", C.c_int), ("nprtrv", C.c_int)]
+
+
+class _VSets(C.Structure):  # emi_vsets_t
+    _fields_ = [("kvsetuv", C.POINTER(C.c_int)), ("nuv_g", C.c_int), ("kvsetsc", C.POINTER(C.c_int)), ("nsc_g", C.c_int),
+                ("kvsetsc2", C.POINTER(C.c_int)), ("nsc2_g", C.c_int), ("kvsetsc3a", C.POINTER(C.c_int)), ("nsc3a_g", C.c_int),
+                ("kvsetsc3b", C.POINTER(C.c_int)), ("nsc3b_g", C.c_int)]
 
 
 class _LegpolIO(C.Structure):
@@ -60,7 +66,7 @@ class _Inv(C.Structure):
                 ("spsc2", C.c_void_p), ("nf_sc2", C.c_int), ("ldscders", C.c_int), ("ldvorgp", C.c_int),
                 ("lddivgp", C.c_int), ("lduvder", C.c_int), ("kproma", C.c_int), ("gp", C.c_void_p),
                 ("gp_nfld", C.c_int), ("gpuv", C.c_void_p), ("gp3a", C.c_void_p), ("gp3b", C.c_void_p),
-                ("gp2", C.c_void_p), ("stream", C.c_void_p), ("ext", C.POINTER(_Ext))]
+                ("gp2", C.c_void_p), ("stream", C.c_void_p), ("ext", C.POINTER(_Ext)), ("vsets", C.POINTER(_VSets))]
 
 
 class _Dir(C.Structure):
@@ -69,7 +75,7 @@ class _Dir(C.Structure):
                 ("sc3a_nvar", C.c_int), ("spsc3b", C.c_void_p), ("sc3b_nlev", C.c_int), ("sc3b_nvar", C.c_int),
                 ("spsc2", C.c_void_p), ("nf_sc2", C.c_int), ("kproma", C.c_int), ("gp", C.c_void_p),
                 ("gp_nfld", C.c_int), ("gpuv", C.c_void_p), ("gp3a", C.c_void_p), ("gp3b", C.c_void_p),
-                ("gp2", C.c_void_p), ("stream", C.c_void_p), ("ext", C.POINTER(_Ext))]
+                ("gp2", C.c_void_p), ("stream", C.c_void_p), ("ext", C.POINTER(_Ext)), ("vsets", C.POINTER(_VSets))]
 
 
 def build(force=False):
@@ -131,6 +137,7 @@ def _bind(L):
     L.emi_gath_grid.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, C.c_int, C.c_void_p]
     L.emi_inq_tasks.argtypes = [ip, ip]
     L.emi_inq_init.argtypes = [ip, dp]
+    L.emi_set_nprtrv.argtypes = [C.c_int]
     return L
 
 
@@ -182,39 +189,45 @@ def _ptr(a, space):
     return a.ctypes.data, a
 
 
-_DIST = {"nproc": 1, "group": None, "device": None}
+_DIST = {"nproc": 1, "nprtrv": 1, "group": None, "device": None}
 
 
 def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, myproc=1, group=None, alltoallv=None,
-                 transport="torch", **unsupported):
+                 transport="torch", kprtrv=1, **unsupported):
     """SETUP_TRANS0 (setup_trans0.h:12-89).
 
     kprtrw > 1: this process is task `myproc` (1-based) of a W-set of `kprtrw` tasks, one per GPU
     (NPRTRV = NPRGPEW = 1); the all-to-all-v between them defaults to torch.distributed on `group`
     (RCCL for CUDA devices, gloo on the CPU test tier) -- see ectrans_amd.dist.
+    kprtrv > 1: NPRTRV V-sets (sump_trans0_mod.F90:49): kprtrw x kprtrv tasks, task `myproc` is (MYSETW, MYSETV) =
+    ((myproc - 1) // kprtrv + 1, (myproc - 1) % kprtrv + 1); fields are dealt to the V-sets by the kvset* arguments of the
+    transforms.
     transport="rccl": the native transport of ectrans_amd/rccl instead (what a Fortran host attaches: grouped
     ncclSend / ncclRecv on the library's stream, no Python callback per field batch); `group` only carries the
     128-byte unique id and the small reductions of SPECNORM."""
     for k, v in unsupported.items():
-        if k.lower() in ("kprgpns", "kprgpew") and v not in (None, 1, kprtrw):
+        if k.lower() in ("kprgpns", "kprgpew") and v not in (None, 1, kprtrw, kprtrw * kprtrv):
             raise TransError("SETUP_TRANS0: %s=%r: only the W-set decomposition (KPRTRW tasks) is supported" % (k, v))
+    nproc_all = kprtrw * max(1, kprtrv)
     if transport == "rccl":
         from . import dist as _dist
-        _dist.rccl_native_attach(kprtrw, myproc, kmax_resol, kprintlev, prad, device, group)  # calls emi_init itself
-        _DIST.update(nproc=kprtrw, group=group if kprtrw > 1 else None,
-                     device=("cuda:%d" % device) if kprtrw > 1 and device is not None and device >= 0 else None)
+        if kprtrv > 1:
+            _chk(lib().emi_set_nprtrv(int(kprtrv)))
+        _dist.rccl_native_attach(nproc_all, myproc, kmax_resol, kprintlev, prad, device, group)  # calls emi_init itself
+        _DIST.update(nproc=nproc_all, nprtrv=max(1, kprtrv), group=group if nproc_all > 1 else None,
+                     device=("cuda:%d" % device) if nproc_all > 1 and device is not None and device >= 0 else None)
         return
-    if kprtrw > 1:
+    if nproc_all > 1:
         from . import dist as _dist
         dev = ("cuda:%d" % device) if device is not None and device >= 0 else "cpu"
         hook = alltoallv if alltoallv is not None else _dist.make_alltoallv_hook(group, dev)
         _chk(lib().emi_set_alltoallv(C.cast(hook, C.c_void_p), None))
         bc, ag = _dist.make_host_collectives(group, dev)  # DIST_x / GATH_x, SPECNORM over several tasks
         _chk(lib().emi_set_host_collectives(C.cast(bc, C.c_void_p), C.cast(ag, C.c_void_p), None))
-        _DIST.update(nproc=kprtrw, group=group, device=dev)
+        _DIST.update(nproc=nproc_all, nprtrv=max(1, kprtrv), group=group, device=dev)
     else:
-        _DIST.update(nproc=1, group=None, device=None)
-    cfg = _Init(kmax_resol, kprintlev, prad if prad else 0.0, kprtrw, myproc, device if device is not None else -1)
+        _DIST.update(nproc=1, nprtrv=1, group=None, device=None)
+    cfg = _Init(kmax_resol, kprintlev, prad if prad else 0.0, nproc_all, myproc, device if device is not None else -1, max(1, kprtrv))
     _chk(lib().emi_init(C.byref(cfg)))
 
 
@@ -278,7 +291,7 @@ def real_dtype(kresol):
 
 
 _INT_SCALARS = ("nspec2", "nspec2g", "nspec2mx", "nspec", "nspecg", "ngptot", "ngptotg", "ngptotmx", "nump", "ndgl",
-                "nsmax", "ndlon", "nproc", "myproc", "nfrstlat", "nlstlat")
+                "nsmax", "ndlon", "nproc", "myproc", "nfrstlat", "nlstlat", "nprtrw", "nprtrv", "mysetw", "mysetv", "ngptot_band")
 _INT_ARRAYS = {"nloen": "ndgl", "nmen": "ndgl", "ndglu": "nsmax+1", "nasm0": "nsmax+1", "myms": "nump",
                "procm": "nsmax+1", "latlo": "nproc+1", "fftwork": "ndgl"}
 _REAL_ARRAYS = {"rmu": "ndgl", "pmu": "ndgl", "rgw": "ndgl", "pgw": "ndgl", "racthe": "ndgl"}
@@ -362,9 +375,28 @@ def _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks, 
     keep.append(ext)
 
 
+def _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b):
+    """KVSETUV / KVSETSC / KVSETSC2 / KVSETSC3A / KVSETSC3B (inv_trans.h:84-101): the V-set (1..NPRTRV) of every GLOBAL field;
+    with them the spectral arrays hold this task's V-set only, the grid arrays all fields."""
+    if all(k is None for k in (kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)):
+        return
+    vs = _VSets()
+    for nm, cnt, k in (("kvsetuv", "nuv_g", kvsetuv), ("kvsetsc", "nsc_g", kvsetsc), ("kvsetsc2", "nsc2_g", kvsetsc2),
+                       ("kvsetsc3a", "nsc3a_g", kvsetsc3a), ("kvsetsc3b", "nsc3b_g", kvsetsc3b)):
+        if k is not None:
+            arr = np.ascontiguousarray(k, dtype=np.int32)
+            keep.append(arr)
+            setattr(vs, nm, arr.ctypes.data_as(C.POINTER(C.c_int)))
+            setattr(vs, cnt, int(arr.size))
+    keep.append(vs)
+    a.vsets = C.pointer(vs)
+    a.ext = None  # the extents block describes one-V-set calls (local == global field counts)
+
+
 def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
               ldscders=False, ldvorgp=False, lddivgp=False, lduvder=False, kproma=None, pgp=None, pgpuv=None,
-              pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+              pgp3a=None, pgp3b=None, pgp2=None, stream=None, kvsetuv=None, kvsetsc=None, kvsetsc2=None, kvsetsc3a=None,
+              kvsetsc3b=None):
     """INV_TRANS (inv_trans.h:12-163): spectral -> grid point, results written into pgp*/..."""
     a, space, keep = _Inv(), [None, real_dtype(kresol)], []
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
@@ -377,11 +409,13 @@ def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
     _chk(lib().emi_inv_trans(kresol, C.byref(a)))
 
 
 def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
-              kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+              kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None, kvsetuv=None, kvsetsc=None,
+              kvsetsc2=None, kvsetsc3a=None, kvsetsc3b=None):
     """DIR_TRANS (dir_trans.h:12-140): grid point -> spectral, results written into psp*."""
     a, space, keep = _Dir(), [None, real_dtype(kresol)], []
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
@@ -393,12 +427,14 @@ def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
     _chk(lib().emi_dir_trans(kresol, C.byref(a)))
 
 
 def inv_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
                 ldscders=False, ldvorgp=False, lddivgp=False, lduvder=False,
-                kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+                kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None, kvsetuv=None, kvsetsc=None,
+                kvsetsc2=None, kvsetsc3a=None, kvsetsc3b=None):
     """INV_TRANSAD (inv_transad.h:12): adjoint of INV_TRANS -- reads pgp*, writes psp* (overwritten).
     Inner products: plain sum in grid-point space, SPECNORM weights (1 for m = 0, 2 for m > 0) in
     spectral space, as tests/trans/test_invtrans_adjoint.F90:243-315.  With ldscders / ldvorgp / lddivgp / lduvder the
@@ -413,11 +449,13 @@ def inv_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, 
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
     _chk(lib().emi_inv_transad(kresol, C.byref(a)))
 
 
 def dir_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, pspsc3b=None, pspsc2=None,
-                kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None):
+                kproma=None, pgp=None, pgpuv=None, pgp3a=None, pgp3b=None, pgp2=None, stream=None, kvsetuv=None, kvsetsc=None,
+                kvsetsc2=None, kvsetsc3a=None, kvsetsc3b=None):
     """DIR_TRANSAD (dir_transad.h:12): adjoint of DIR_TRANS -- reads psp*, writes pgp*."""
     a, space, keep = _Dir(), [None, real_dtype(kresol)], []
     nspec2, ngptot = trans_inq(kresol, "nspec2"), trans_inq(kresol, "ngptot")
@@ -428,6 +466,7 @@ def dir_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, 
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
     _chk(lib().emi_dir_transad(kresol, C.byref(a)))
 
 
@@ -435,9 +474,13 @@ def specnorm(kresol, pspec):
     """SPECNORM (specnorm.h:12): per-field spectral L2 norm, returned as a numpy array (on every
     task; the reference returns it on the master only)."""
     space = [None, real_dtype(kresol)]
-    p, keep = _ptr(pspec, space)
+    if pspec.shape[1] == 0:
+        p, keep, space[0] = None, None, EMI_MEM_HOST
+    else:
+        p, keep = _ptr(pspec, space)
     out = np.zeros(pspec.shape[1])
-    if _DIST["nproc"] == 1:
+    if _DIST["nproc"] == 1 or _DIST.get("nprtrv", 1) > 1:
+        # several V-sets: the library sums over the tasks of this V-set itself (host collectives)
         _chk(lib().emi_specnorm(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
     from . import dist as _dist
@@ -546,7 +589,7 @@ def trans_release(kresol):
 
 def trans_end():
     _chk(lib().emi_finalize())
-    _DIST.update(nproc=1, group=None, device=None)
+    _DIST.update(nproc=1, nprtrv=1, group=None, device=None)
 
 
 def work_model(kresol, nfields):

@@ -219,7 +219,23 @@ struct Plan {
   std::vector<double> rmu, rw, racthe, cos2;
   int ngptotg = 0, nspec2g = 0;
   // ---- this task's share
-  int nproc = 1, me = 0;
+  int nproc = 1, me = 0;  // W-set decomposition (NPRTRW, MYSETW - 1)
+  // V-sets: the band of W-set w (latitudes latlo[w] .. latlo[w+1]) is cut into NPRTRV sub-bands of whole latitudes, the grid
+  // shares of its tasks; vlat[w * nprv + v]: first latitude (0-based, global) of task (w, v), vlat[nproc * nprv] = NDGL
+  int nprv = 1, mev = 0;
+  std::vector<int> vlat;
+  int vfirst(int w, int v) const { return nprv > 1 ? vlat[(size_t)w * nprv + v] : latlo[w]; }        // first latitude of task (w, v)
+  int vlast(int w, int v) const { return nprv > 1 ? vlat[(size_t)w * nprv + v + 1] : latlo[w + 1]; }  // one past its last latitude
+  long long vpoints(int w, int v) const {  // grid points of task (w, v)
+    long long c = 0;
+    for (int j = vfirst(w, v); j < vlast(w, v); j++) c += nloen[j];
+    return c;
+  }
+  long long voffset(int v) const {  // first point of sub-band v inside this task's band
+    long long c = 0;
+    for (int j = latlo[me]; j < vfirst(me, v); j++) c += nloen[j];
+    return c;
+  }
   int nump = 0, nlat = 0, lat0 = 0;
   int ngptot = 0, nspec2 = 0;
   std::vector<int> mval, nasm0;            // [nump]
@@ -290,7 +306,10 @@ static struct {
   bool init = false;
   int max_resol = 1;
   double ra = 6371229.0;
-  int nproc = 1, myproc = 1;
+  int nproc = 1, myproc = 1;  // the W-set decomposition the plans are built on: NPRTRW tasks, this one is MYSETW
+  // NPRTRV > 1 (sump_trans0_mod.F90:49, pe2set_mod.F90:111-112): nproc_all = NPRTRW x NPRTRV tasks; task myproc_all is
+  // (MYSETW, MYSETV) = ((myproc_all - 1) / NPRTRV + 1, mod(myproc_all - 1, NPRTRV) + 1); the tasks of a W-set are neighbours
+  int nproc_all = 1, myproc_all = 1, nprtrv = 1, mysetv = 1, nprtrv_preset = 0;
   std::vector<Plan *> plans;
   int max_batch = 0;
   int profile = 0;  // 1: phase timers per call; 2: accumulated over the calls since emi_set_profile(2)
@@ -306,6 +325,12 @@ static Plan *get_plan(int kresol) {
   return G.plans[kresol - 1];
 }
 
+extern "C" int emi_set_nprtrv(int nprtrv) {
+  if (G.init) EMI_FAIL(EMI_ERR_STATE, "emi_set_nprtrv: after SETUP_TRANS0");
+  if (nprtrv < 1) EMI_FAIL(EMI_ERR_ARG, "emi_set_nprtrv: NPRTRV = %d", nprtrv);
+  G.nprtrv_preset = nprtrv;
+  return EMI_SUCCESS;
+}
 extern "C" int emi_init(const emi_init_t *cfg) {
   // SETUP_TRANS0 is idempotent (setup_trans0.F90:108-111)
   if (G.init) return EMI_SUCCESS;
@@ -313,9 +338,15 @@ extern "C" int emi_init(const emi_init_t *cfg) {
   if (cfg) c = *cfg;
   G.max_resol = c.kmax_resol > 0 ? c.kmax_resol : 1;
   G.ra = c.prad > 0 ? c.prad : 6371229.0;
-  G.nproc = c.nproc > 0 ? c.nproc : 1;
-  G.myproc = c.myproc > 0 ? c.myproc : 1;
-  if (G.myproc > G.nproc) EMI_FAIL(EMI_ERR_ARG, "emi_init: myproc %d > nproc %d", G.myproc, G.nproc);
+  G.nproc_all = c.nproc > 0 ? c.nproc : 1;
+  G.myproc_all = c.myproc > 0 ? c.myproc : 1;
+  if (G.myproc_all > G.nproc_all) EMI_FAIL(EMI_ERR_ARG, "emi_init: myproc %d > nproc %d", G.myproc_all, G.nproc_all);
+  G.nprtrv = c.nprtrv > 0 ? c.nprtrv : (G.nprtrv_preset > 0 ? G.nprtrv_preset : 1);
+  if (G.nproc_all % G.nprtrv != 0)
+    EMI_FAIL(EMI_ERR_ARG, "SUMP_TRANS0: NPROC INCONSISTENT WITH NPRTRW (NPROC = %d is not a multiple of NPRTRV = %d)", G.nproc_all, G.nprtrv);
+  G.nproc = G.nproc_all / G.nprtrv;                 // NPRTRW
+  G.myproc = (G.myproc_all - 1) / G.nprtrv + 1;     // MYSETW
+  G.mysetv = (G.myproc_all - 1) % G.nprtrv + 1;     // MYSETV
 #ifndef EMI_CPU_EMU
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -779,7 +810,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   if (io && io->io && io->io[0]) {
     std::string mode(io->io);
     while (!mode.empty() && mode.back() == ' ') mode.pop_back();
-    if (G.nproc > 1) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS:CDIO_LEGPOL OPTIONS ONLY FOR NPROC=1 ");
+    if (G.nproc_all > 1) EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS:CDIO_LEGPOL OPTIONS ONLY FOR NPROC=1 ");
     if (mode == "readf" || mode == "READF")
       lp_mode = LP_READF;
     else if (mode == "writef" || mode == "WRITEF")
@@ -810,9 +841,9 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   P.nproc = G.nproc;
   P.me = G.myproc - 1;
   const int N = P.nsmax, L = P.ndgl, NP = P.nproc, me = P.me;
-  if (NP > 1 && !G.a2a) {
+  if (G.nproc_all > 1 && !G.a2a) {
     delete pp;
-    EMI_FAIL(EMI_ERR_STATE, "SETUP_TRANS: %d tasks but no all-to-all-v hook registered (emi_set_alltoallv)", NP);
+    EMI_FAIL(EMI_ERR_STATE, "SETUP_TRANS: %d tasks but no all-to-all-v hook registered (emi_set_alltoallv)", G.nproc_all);
   }
   if (NP > L / 2 || NP > N + 1) {
     delete pp;
@@ -907,6 +938,28 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
     P.latlo[r] = j;
   }
   P.latlo[NP] = L;
+  // V-sets: every band in NPRTRV sub-bands of whole latitudes with (nearly) equal numbers of points -- the grid-point
+  // distribution over all NPROC tasks (the reference: sumplat with NPRGPNS = NPROC bands; whole latitudes here as for the bands)
+  P.nprv = G.nprtrv;
+  P.mev = G.mysetv - 1;
+  if (P.nprv > 1) {
+    P.vlat.assign((size_t)NP * P.nprv + 1, L);
+    for (int w = 0; w < NP; w++) {
+      const int a0 = P.latlo[w], a1 = P.latlo[w + 1];
+      if (a1 - a0 < P.nprv) {
+        delete pp;
+        EMI_FAIL(EMI_ERR_ARG, "SETUP_TRANS: too many tasks: band %d has %d latitudes for %d V-sets", w + 1, a1 - a0, P.nprv);
+      }
+      P.vlat[(size_t)w * P.nprv] = a0;
+      for (int v = 1; v < P.nprv; v++) {
+        const long long target = cum[a0] + (cum[a1] - cum[a0]) * v / P.nprv;
+        int j = (int)(std::lower_bound(cum.begin() + a0, cum.begin() + a1, target) - cum.begin());
+        j = std::max(j, P.vlat[(size_t)w * P.nprv + v - 1] + 1);
+        j = std::min(j, a1 - (P.nprv - v));
+        P.vlat[(size_t)w * P.nprv + v] = j;
+      }
+    }
+  }
   P.lat0 = P.latlo[me];
   P.nlat = P.latlo[me + 1] - P.lat0;
   P.ngptot = (int)(cum[P.latlo[me + 1]] - cum[P.lat0]);
@@ -1360,17 +1413,16 @@ extern "C" int emi_inq_int(int kresol, const char *name, int *value) {
     *value = P->nspec2 / 2;
   else if (s == "nspecg")
     *value = P->nspec2g / 2;
-  else if (s == "ngptot")
+  else if (s == "ngptot")  // this task's grid points: its sub-band with V-sets, else its band
+    *value = P->nprv > 1 ? (int)P->vpoints(P->me, P->mev) : P->ngptot;
+  else if (s == "ngptot_band")  // grid points of the whole band of this task's W-set (the FFT work of its V-set)
     *value = P->ngptot;
   else if (s == "ngptotg")
     *value = P->ngptotg;
   else if (s == "ngptotmx") {
     long long mx = 0;
-    for (int r = 0; r < P->nproc; r++) {
-      long long c = 0;
-      for (int j = P->latlo[r]; j < P->latlo[r + 1]; j++) c += P->nloen[j];
-      mx = std::max(mx, c);
-    }
+    for (int r = 0; r < P->nproc; r++)
+      for (int v = 0; v < P->nprv; v++) mx = std::max(mx, P->vpoints(r, v));
     *value = (int)mx;
   } else if (s == "nump")
     *value = P->nump;
@@ -1380,14 +1432,22 @@ extern "C" int emi_inq_int(int kresol, const char *name, int *value) {
     *value = P->nsmax;
   else if (s == "ndlon")
     *value = *std::max_element(P->nloen.begin(), P->nloen.end());
-  else if (s == "nproc" || s == "nprtrw")
+  else if (s == "nproc")
+    *value = P->nproc * P->nprv;
+  else if (s == "nprtrw")
     *value = P->nproc;
-  else if (s == "myproc" || s == "mysetw")
+  else if (s == "nprtrv")
+    *value = P->nprv;
+  else if (s == "myproc")
+    *value = P->me * P->nprv + P->mev + 1;
+  else if (s == "mysetw")
     *value = P->me + 1;
-  else if (s == "nfrstlat")  // first (1-based, global) latitude of this task's band
-    *value = P->lat0 + 1;
+  else if (s == "mysetv")
+    *value = P->mev + 1;
+  else if (s == "nfrstlat")  // first (1-based, global) latitude of this task's grid share (its band; its sub-band with V-sets)
+    *value = P->vfirst(P->me, P->mev) + 1;
   else if (s == "nlstlat")
-    *value = P->lat0 + P->nlat;
+    *value = P->vlast(P->me, P->mev);
   else
     EMI_FAIL(EMI_ERR_ARG, "emi_inq_int: unknown name '%s'", s.c_str());
   return EMI_SUCCESS;
@@ -1415,8 +1475,11 @@ extern "C" int emi_inq_int_array(int kresol, const char *name, int *out, int len
     tmp = P->procm;
     for (auto &x : tmp) x += 1;
     v = &tmp;
-  } else if (s == "latlo") {  // [nproc+1] 0-based first latitude of every task's band
-    v = &P->latlo;
+  } else if (s == "latlo") {  // [nproc+1] 0-based first latitude of every task's grid share, task order
+    if (P->nprv > 1)
+      v = &P->vlat;
+    else
+      v = &P->latlo;
   } else if (s == "fftwork") {  // [ndgl] work length of the FFT of every latitude of this task (0 elsewhere): NLOEN/2 or NLOEN,
     // or the Bluestein length; diagnostic (tests check which specialised kernel a row length selects)
     tmp.assign(P->ndgl, 0);
@@ -1595,23 +1658,33 @@ static int ensure_work(Plan &P, int bfpad, int nfb, emi_stream_t st) {
 
 // TRLTOM / TRMTOL (trltom_mod.F90:96-136, trmtol_mod.F90:101-141): one all-to-all-v of whole
 // row blocks of the Fourier buffers.  to_fft: Legendre-side -> FFT-side (inverse transform).
+// The hook always sees ALL tasks of the job (one entry per task, zero bytes for tasks that are not peers of this exchange): with
+// V-sets TRMTOL / TRLTOM run among the NPRTRW tasks that share this task's V-set (task w * NPRTRV + mysetv), TRLTOG / TRGTOL
+// among the NPRTRV tasks of its W-set -- no sub-communicators, any transport that handles empty blocks works unchanged.
+// Displacements of the empty blocks continue the dense order (the Python transport checks it).
+static int hook_alltoallv(const void *sb, const std::vector<long long> &psc, void *rb, const std::vector<long long> &prc, int npeers, int stride, int first,
+                          emi_stream_t st) {
+  const int NA = G.nproc_all;
+  std::vector<long long> sc(NA, 0), sd(NA, 0), rc(NA, 0), rd(NA, 0);
+  for (int k = 0; k < npeers; k++) sc[first + k * stride] = psc[k], rc[first + k * stride] = prc[k];
+  for (int r = 1; r < NA; r++) sd[r] = sd[r - 1] + sc[r - 1], rd[r] = rd[r - 1] + rc[r - 1];
+  if (G.a2a(G.a2a_user, sb, sc.data(), sd.data(), rb, rc.data(), rd.data(), NA, (void *)st) != 0) EMI_FAIL(EMI_ERR_RUNTIME, "all-to-all-v hook failed");
+  return 0;
+}
 static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st, char *FBl, char *FBf) {
   if (P.nproc == 1) return 0;
   const int NP = P.nproc;
-  std::vector<long long> sc(NP), sd(NP), rc(NP), rd(NP);
+  std::vector<long long> sc(NP), rc(NP);
   const long long rowb = (long long)ldf * P.esz;
   for (int r = 0; r < NP; r++) {
-    const long long lr = P.leg_rows[r] * rowb, ld = P.leg_disp[r] * rowb, fr = P.fft_rows[r] * rowb, fd = P.fft_disp[r] * rowb;
+    // the blocks of both buffers are dense and in task order (leg_disp / fft_disp are the running sums of the rows)
+    const long long lr = P.leg_rows[r] * rowb, fr = P.fft_rows[r] * rowb;
     sc[r] = to_fft ? lr : fr;
-    sd[r] = to_fft ? ld : fd;
     rc[r] = to_fft ? fr : lr;
-    rd[r] = to_fft ? fd : ld;
   }
   const void *sb = to_fft ? FBl : FBf;
   void *rb = to_fft ? FBf : FBl;
-  if (G.a2a(G.a2a_user, sb, sc.data(), sd.data(), rb, rc.data(), rd.data(), NP, (void *)st) != 0)
-    EMI_FAIL(EMI_ERR_RUNTIME, "all-to-all-v hook failed");
-  return 0;
+  return hook_alltoallv(sb, sc, rb, rc, NP, P.nprv, P.mev, st);
 }
 
 static int ensure_desc(Plan &P, size_t bytes);
@@ -2593,14 +2666,46 @@ static int specnorm_sumsq(Plan &P, int mem_space, const void *spec, int nfld, do
   return EMI_SUCCESS;
 }
 
+// V-sets: the fields of PSPEC are this V-set's (spnorm_ctl_mod.F90: KVSET); their wavenumbers are spread over the NPRTRW tasks that
+// share the V-set.  The host collective spans all tasks, and the V-sets may hold different numbers of fields: field counts first,
+// then the partial sums; byv[v][k] = sum over the W-sets of field k of V-set v (the same on every task).
+static int specnorm_vsets(Plan &P, const double *partial, int nfld, std::vector<std::vector<double>> &byv) {
+  if (!G.hc_gather) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: several tasks and no host collectives (emi_set_host_collectives)");
+  const int NA = G.nproc_all;
+  std::vector<long long> one(NA, 8), d1(NA);
+  for (int t = 0; t < NA; t++) d1[t] = 8LL * t;
+  std::vector<long long> nf_all(NA, 0);
+  long long mine = nfld;
+  if (G.hc_gather(G.hc_user, &mine, 8, nf_all.data(), one.data(), d1.data(), NA)) EMI_FAIL(EMI_ERR_RUNTIME, "SPECNORM: all-gather-v failed");
+  std::vector<long long> cnt(NA), dsp(NA);
+  long long tot = 0;
+  for (int t = 0; t < NA; t++) cnt[t] = nf_all[t] * 8, dsp[t] = tot, tot += cnt[t];
+  std::vector<double> all((size_t)(tot / 8) + 1);
+  double dummy = 0.0;
+  if (G.hc_gather(G.hc_user, nfld ? (const void *)partial : (const void *)&dummy, cnt[G.myproc_all - 1], all.data(), cnt.data(), dsp.data(), NA))
+    EMI_FAIL(EMI_ERR_RUNTIME, "SPECNORM: all-gather-v failed");
+  byv.assign(P.nprv, {});
+  for (int v = 0; v < P.nprv; v++) {
+    const long long nfv = nf_all[v];  // task (W-set 1, V-set v)
+    byv[v].assign((size_t)nfv, 0.0);
+    for (int w = 0; w < P.nproc; w++) {
+      const int t = w * P.nprv + v;
+      if (nf_all[t] != nfv) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: tasks %d and %d of V-set %d pass %lld and %lld fields", v + 1, t + 1, v + 1, nfv, nf_all[t]);
+      for (long long i = 0; i < nfv; i++) byv[v][(size_t)i] += all[(size_t)(dsp[t] / 8 + i)];
+    }
+  }
+  return 0;
+}
+
 extern "C" int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms) {
   Plan *Pp = get_plan(kresol);
   if (!Pp) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: unknown resolution %d", kresol);
-  if (!spec || nfld <= 0 || !norms) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
-  if (Pp->nproc > 1 && !G.hc_gather)
+  // V-sets: a task whose V-set holds none of the fields still takes part in the collective (nfld = 0)
+  if (nfld < 0 || (nfld > 0 && (!spec || !norms)) || (nfld == 0 && Pp->nprv == 1)) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
+  if (Pp->nproc > 1 && Pp->nprv == 1 && !G.hc_gather)
     EMI_FAIL(EMI_ERR_STATE, "SPECNORM: several tasks and no host collectives (emi_set_host_collectives): use emi_specnorm_partial and sum over tasks");
-  if (specnorm_sumsq(*Pp, mem_space, spec, nfld, norms)) return EMI_ERR_RUNTIME;
-  if (Pp->nproc > 1) {  // spnormc_mod.F90:49-85 gathers the partial sums on the master; here every task gets the norms
+  if (nfld > 0 && specnorm_sumsq(*Pp, mem_space, spec, nfld, norms)) return EMI_ERR_RUNTIME;
+  if (Pp->nproc > 1 && Pp->nprv == 1) {  // spnormc_mod.F90:49-85 gathers the partial sums on the master; here every task gets the norms
     const int NP = Pp->nproc;
     std::vector<double> all((size_t)NP * nfld);
     std::vector<long long> cnt(NP, (long long)nfld * 8), dsp(NP);
@@ -2611,8 +2716,48 @@ extern "C" int emi_specnorm(int kresol, int mem_space, const void *spec, int nfl
       for (int t = 0; t < NP; t++) s += all[(size_t)t * nfld + i];  // task order: the same sum on every task
       norms[i] = s;
     }
+  } else if (Pp->nprv > 1) {
+    std::vector<std::vector<double>> byv;
+    if (specnorm_vsets(*Pp, norms, nfld, byv)) return EMI_ERR_RUNTIME;
+    for (int i = 0; i < nfld; i++) norms[i] = byv[Pp->mev][i];
   }
   for (int i = 0; i < nfld; i++) norms[i] = std::sqrt(norms[i]);
+  return EMI_SUCCESS;
+}
+
+// SPECNORM with KVSET (specnorm.h:12, spnorm_ctl_mod.F90): PSPEC holds this V-set's fields, PNORM the norms of ALL nfld_g fields
+// (on every task; the reference fills it on the master), kvset[f] the V-set of global field f
+extern "C" int emi_specnorm_kvset(int kresol, int mem_space, const void *spec, int nfld, const int *kvset, int nfld_g, double *norms_g) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "SPECNORM: unknown resolution %d", kresol);
+  Plan &P = *Pp;
+  if (nfld < 0 || nfld_g < 0 || (nfld_g > 0 && (!kvset || !norms_g)) || (nfld > 0 && !spec)) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
+  int mine = 0;
+  for (int f = 0; f < nfld_g; f++) {
+    if (kvset[f] < 1 || kvset[f] > P.nprv) EMI_FAIL(EMI_ERR_ARG, "SPECNORM:KVSET CONTAINS VALUES OUTSIDE RANGE");
+    mine += kvset[f] == P.mev + 1;
+  }
+  if (mine != nfld) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: %d fields of KVSET belong to this V-set, PSPEC holds %d", mine, nfld);
+  if (P.nprv == 1) return emi_specnorm(kresol, mem_space, spec, nfld, norms_g);
+  std::vector<double> part((size_t)nfld + 1, 0.0);
+  if (nfld > 0 && specnorm_sumsq(P, mem_space, spec, nfld, part.data())) return EMI_ERR_RUNTIME;
+  std::vector<std::vector<double>> byv;
+  if (specnorm_vsets(P, part.data(), nfld, byv)) return EMI_ERR_RUNTIME;
+  std::vector<int> k(P.nprv, 0);
+  for (int f = 0; f < nfld_g; f++) {
+    const int v = kvset[f] - 1;
+    if ((size_t)k[v] >= byv[v].size()) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: V-set %d passed fewer fields than KVSET names", v + 1);
+    norms_g[f] = std::sqrt(byv[v][(size_t)k[v]++]);
+  }
+  return EMI_SUCCESS;
+}
+// V-set decomposition (sump_trans0_mod.F90:49, pe2set_mod.F90:111-112): NPRTRW, NPRTRV, MYSETW, MYSETV
+extern "C" int emi_inq_vsets(int *nprtrw, int *nprtrv, int *mysetw, int *mysetv) {
+  if (!G.init) EMI_FAIL(EMI_ERR_STATE, "emi_inq_vsets: SETUP_TRANS0 has not been called");
+  if (nprtrw) *nprtrw = G.nproc;
+  if (nprtrv) *nprtrv = G.nprtrv;
+  if (mysetw) *mysetw = G.myproc;
+  if (mysetv) *mysetv = G.mysetv;
   return EMI_SUCCESS;
 }
 
@@ -2684,8 +2829,8 @@ extern "C" int emi_inq_init(int *kmax_resol, double *prad) {
 }
 extern "C" int emi_inq_tasks(int *nproc, int *myproc) {
   if (!G.init) EMI_FAIL(EMI_ERR_STATE, "emi_inq_tasks: SETUP_TRANS0 has not been called");
-  if (nproc) *nproc = G.nproc;
-  if (myproc) *myproc = G.myproc;
+  if (nproc) *nproc = G.nproc_all;
+  if (myproc) *myproc = G.myproc_all;
   return EMI_SUCCESS;
 }
 namespace {
@@ -2720,6 +2865,10 @@ TaskLayout task_layout(const Plan &P) {
   return L;
 }
 int check_tasks(const Plan &P, const int *k, int nfld, const char *who) {
+  // V-sets: a spectral field lives on the NPRTRW tasks of ONE V-set (KVSET of dist_spec.h / gath_spec.h), a grid field on the
+  // sub-bands of all NPROC tasks; these re-layout helpers know the W-set decomposition only.  Hosts with NPRTRV > 1 move their
+  // global fields themselves (TRANS_INQ gives every task's share: "latlo", "myms", "nasm0", "mysetv").
+  if (P.nprv > 1) EMI_FAIL(EMI_ERR_UNSUPPORTED, "%s: not available with NPRTRV > 1", who);
   if (nfld < 0 || (nfld > 0 && !k)) EMI_FAIL(EMI_ERR_ARG, "%s: task list missing", who);
   for (int f = 0; f < nfld; f++)
     if (k[f] < 1 || k[f] > P.nproc) EMI_FAIL(EMI_ERR_ARG, "%s: task %d of field %d outside 1..%d", who, k[f], f + 1, P.nproc);
@@ -2883,12 +3032,346 @@ extern "C" int emi_crc64(const void *data, size_t bytes, unsigned long long *crc
   return EMI_SUCCESS;
 }
 
+// ------------------------------------------------------------------------------------------
+// V-sets (NPRTRV > 1): INV_TRANS / DIR_TRANS of task (MYSETW, MYSETV).
+// Spectral and Fourier space hold the fields of ONE V-set on the wavenumbers / latitude band of the W-set; grid space holds ALL
+// fields on the task's sub-band (inv_trans.F90:212-300, trltog_mod.F90, trgtol_mod.F90).  The transform of the local fields is
+// the W-set transform above, run into / out of a band-sized device array; TRLTOG / TRGTOL between the NPRTRV tasks of the band
+// is one all-to-all-v of dense [field][point] blocks, packed and unpacked by k_gridcopy.  Field order everywhere: the
+// reference's ([vor] [div] u v scalars [N-S derivatives] [u, v E-W derivatives] [scalar E-W derivatives]); a V-set's fields
+// are the global ones it owns, in global order, group by group.
+// ------------------------------------------------------------------------------------------
+struct StageBuf {  // device scratch from the staging pool
+  void *p = nullptr;
+  explicit StageBuf(size_t bytes) { p = bytes ? emi_stage::acquire(bytes) : nullptr; }
+  ~StageBuf() {
+    if (p) emi_stage::release(p);
+  }
+};
+struct VGroups {
+  int nuv_g = 0;
+  std::vector<int> ouv;            // owner V-set (0-based) of every global u/v field
+  std::vector<ScalarRef> sc_g;     // global scalars in the reference's order
+  std::vector<int> osc;            // their owners
+  int nsc_g[4] = {0, 0, 0, 0};     // global counts: PSPSCALAR fields, PSPSC2 fields, PSPSC3A levels, PSPSC3B levels
+};
+template <class ARGS>
+static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) {
+  const emi_vsets_t *vs = a.vsets;
+  if (!vs) EMI_FAIL(EMI_ERR_ARG, "%s: NPRTRV = %d but no KVSET arrays (emi_vsets_t)", who, P.nprv);
+  auto owners = [&](const int *k, int n, const char *nm, std::vector<int> &out) {
+    out.clear();
+    for (int i = 0; i < n; i++) {
+      if (!k || k[i] < 1 || k[i] > P.nprv) {
+        emi_set_error("%s:%s TOO LONG OR CONTAINS VALUES OUTSIDE RANGE", who, nm);
+        return -1;
+      }
+      out.push_back(k[i] - 1);
+    }
+    return 0;
+  };
+  vg.nuv_g = vs->kvsetuv ? vs->nuv_g : 0;
+  if (owners(vs->kvsetuv, vg.nuv_g, "KVSETUV", vg.ouv)) return EMI_ERR_ARG;
+  const int mine_uv = (int)std::count(vg.ouv.begin(), vg.ouv.end(), P.mev);
+  if (mine_uv != ((a.spvor || a.spdiv) ? a.nf_uv : 0))
+    EMI_FAIL(EMI_ERR_ARG, "%s: %d fields of KVSETUV belong to this V-set, the spectral arrays hold %d", who, mine_uv, (a.spvor || a.spdiv) ? a.nf_uv : 0);
+  std::vector<int> o;
+  vg.sc_g.clear(), vg.osc.clear();
+  auto check_local = [&](const char *nm, int mine, int have) {
+    if (mine != have) {
+      emi_set_error("%s: %d fields of %s belong to this V-set, the spectral array holds %d", who, mine, nm, have);
+      return -1;
+    }
+    return 0;
+  };
+  if (vs->kvsetsc) {  // PSPSCALAR form
+    if (vs->kvsetsc2 || vs->kvsetsc3a || vs->kvsetsc3b) EMI_FAIL(EMI_ERR_ARG, "%s : PSPSCALAR AND PSPSC3A/PSPSC3B/PSPSC2 BOTH PRESENT", who);
+    if (owners(vs->kvsetsc, vs->nsc_g, "KVSETSC", o)) return EMI_ERR_ARG;
+    vg.nsc_g[0] = vs->nsc_g;
+    for (int i = 0; i < vs->nsc_g; i++) vg.sc_g.push_back({0, i, 0}), vg.osc.push_back(o[i]);
+    if (check_local("KVSETSC", (int)std::count(o.begin(), o.end(), P.mev), a.spscalar ? a.nf_scalar : 0)) return EMI_ERR_ARG;
+  } else {
+    if (vs->kvsetsc2) {
+      if (owners(vs->kvsetsc2, vs->nsc2_g, "KVSETSC2", o)) return EMI_ERR_ARG;
+      vg.nsc_g[1] = vs->nsc2_g;
+      for (int i = 0; i < vs->nsc2_g; i++) vg.sc_g.push_back({1, i, 0}), vg.osc.push_back(o[i]);
+      if (check_local("KVSETSC2", (int)std::count(o.begin(), o.end(), P.mev), a.spsc2 ? a.nf_sc2 : 0)) return EMI_ERR_ARG;
+    }
+    if (vs->kvsetsc3a) {
+      if (owners(vs->kvsetsc3a, vs->nsc3a_g, "KVSETSC3A", o)) return EMI_ERR_ARG;
+      vg.nsc_g[2] = vs->nsc3a_g;
+      for (int v = 0; v < a.sc3a_nvar; v++)
+        for (int l = 0; l < vs->nsc3a_g; l++) vg.sc_g.push_back({2, l, v}), vg.osc.push_back(o[l]);
+      if (check_local("KVSETSC3A", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3a ? a.sc3a_nlev : 0)) return EMI_ERR_ARG;
+    }
+    if (vs->kvsetsc3b) {
+      if (owners(vs->kvsetsc3b, vs->nsc3b_g, "KVSETSC3B", o)) return EMI_ERR_ARG;
+      vg.nsc_g[3] = vs->nsc3b_g;
+      for (int v = 0; v < a.sc3b_nvar; v++)
+        for (int l = 0; l < vs->nsc3b_g; l++) vg.sc_g.push_back({3, l, v}), vg.osc.push_back(o[l]);
+      if (check_local("KVSETSC3B", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3b ? a.sc3b_nlev : 0)) return EMI_ERR_ARG;
+    }
+  }
+  return 0;
+}
+// all grid fields of the call in the reference's order, over the caller's (global-count) arrays, with their owner V-sets
+struct VGridList {
+  std::vector<GridFld> g;
+  std::vector<int> owner;
+};
+static void v_grid_fields(const VGroups &vg, bool lvorgp, bool ldivgp, bool lscders, bool luvder, void *gp, int gp_nfld, void *gpuv, int uv_dim3,
+                          void *gp2, void *gp3a, int nvar3a, void *gp3b, int nvar3b, VGridList &out) {
+  const int nuv = vg.nuv_g, nsc = (int)vg.sc_g.size(), dmul = lscders ? 3 : 1;
+  int gcount = 0, uvvar = 0;
+  auto uvf = [&](int lev) {
+    GridFld g{};
+    if (gp) { g.base = gp; g.nf_arr = gp_nfld; g.fidx = gcount; }
+    else { g.base = gpuv; g.nf_arr = nuv * uv_dim3; g.fidx = uvvar * nuv + lev; }
+    out.g.push_back(g), out.owner.push_back(vg.ouv[lev]);
+    gcount++;
+  };
+  auto scf = [&](int isc, int kder) {
+    GridFld g{};
+    const ScalarRef &r = vg.sc_g[isc];
+    if (gp) { g.base = gp; g.nf_arr = gp_nfld; g.fidx = gcount; }
+    else if (r.arr == 1) { g.base = gp2; g.nf_arr = vg.nsc_g[1] * dmul; g.fidx = r.lev + kder * vg.nsc_g[1]; }
+    else if (r.arr == 2) { g.base = gp3a; g.nf_arr = vg.nsc_g[2] * nvar3a * dmul; g.fidx = (r.var + kder * nvar3a) * vg.nsc_g[2] + r.lev; }
+    else { g.base = gp3b; g.nf_arr = vg.nsc_g[3] * nvar3b * dmul; g.fidx = (r.var + kder * nvar3b) * vg.nsc_g[3] + r.lev; }
+    out.g.push_back(g), out.owner.push_back(vg.osc[isc]);
+    gcount++;
+  };
+  if (nuv) {
+    if (lvorgp) { for (int i = 0; i < nuv; i++) uvf(i); uvvar++; }
+    if (ldivgp) { for (int i = 0; i < nuv; i++) uvf(i); uvvar++; }
+    for (int i = 0; i < nuv; i++) uvf(i);
+    uvvar++;
+    for (int i = 0; i < nuv; i++) uvf(i);
+    uvvar++;
+  }
+  for (int i = 0; i < nsc; i++) scf(i, 0);
+  if (lscders) for (int i = 0; i < nsc; i++) scf(i, 1);
+  if (luvder && nuv) {
+    for (int i = 0; i < nuv; i++) uvf(i);
+    uvvar++;
+    for (int i = 0; i < nuv; i++) uvf(i);
+    uvvar++;
+  }
+  if (lscders) for (int i = 0; i < nsc; i++) scf(i, 2);
+}
+// pack / unpack one block of the V-exchange: nf fields x npts points between two lists of grid-field descriptors
+static int v_copy(Plan &P, const std::vector<GridFld> &src, const std::vector<GridFld> &dst, long long sp0, long long dp0, long long npts, long long snp,
+                  long long dnp, std::vector<StageBuf *> &keep, emi_stream_t st) {
+  const int nf = (int)src.size();
+  if (nf == 0 || npts == 0) return 0;
+  StageBuf *d = new StageBuf(2 * (size_t)nf * sizeof(GridFld));
+  keep.push_back(d);
+  if (!d->p) EMI_FAIL(EMI_ERR_RUNTIME, "V-set exchange: no device memory for %d field descriptors", nf);
+  std::vector<GridFld> both(src);
+  both.insert(both.end(), dst.begin(), dst.end());
+  if (emi_h2d(d->p, both.data(), both.size() * sizeof(GridFld), st)) return EMI_ERR_RUNTIME;
+  const long long nblk = ((long long)nf * npts + 255) / 256;
+  EMI_LAUNCH_P(P.esz, k_gridcopy, nblk, 256, 0, st, (const GridFld *)d->p, (const GridFld *)d->p + nf, nf, sp0, dp0, (int)npts, (int)snp, (int)dnp);
+  return 0;
+}
+static GridFld dense_field(void *base, size_t field, long long npts, int esz) {
+  GridFld g{};
+  g.base = (char *)base + field * (size_t)npts * esz;
+  g.nf_arr = 1;
+  g.fidx = 0;
+  return g;
+}
+
+static int inv_trans_vsets(int kresol, const emi_invtrans_t *ap, bool adj) {
+  Plan *Pp = get_plan(kresol);
+  const char *who = adj ? "DIR_TRANSAD" : "INV_TRANS";
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "%s: unknown resolution %d", who, kresol);
+  if (!ap) EMI_FAIL(EMI_ERR_ARG, "%s: null argument block", who);
+  Plan &P = *Pp;
+  const emi_invtrans_t &a = *ap;
+  emi_stream_t st = (emi_stream_t)a.stream;
+  const bool host = a.mem_space == EMI_MEM_HOST;
+  VGroups vg;
+  if (v_groups(P, a, who, vg)) return EMI_ERR_ARG;
+  const int nuvg = vg.nuv_g, nscg = (int)vg.sc_g.size();
+  const bool lscders = a.ldscders && nscg > 0, lvorgp = a.ldvorgp != 0, ldivgp = a.lddivgp != 0 || lvorgp, luvder = a.lduvder && nuvg > 0;
+  const int if_gp_g = 2 * nuvg + nscg + (lscders ? 2 * nscg : 0) + ((nuvg && lvorgp) ? nuvg : 0) + ((nuvg && ldivgp) ? nuvg : 0) + (luvder ? 2 * nuvg : 0);
+  if (if_gp_g == 0) return EMI_SUCCESS;
+  const int nvar_uv = ((nuvg && lvorgp) ? 1 : 0) + ((nuvg && ldivgp) ? 1 : 0) + 2 + (luvder ? 2 : 0), dmul = lscders ? 3 : 1;
+  const long long myp = P.vpoints(P.me, P.mev), bandp = P.ngptot;
+  const int nproma = a.kproma > 0 ? a.kproma : (int)myp;
+  const int ngpblks = (int)((myp - 1) / nproma + 1);
+  if (a.gp) {
+    if (a.gpuv || a.gp3a || a.gp3b || a.gp2) EMI_FAIL(EMI_ERR_ARG, "%s:PGP AND PGPUV/PGP3A/PGP3B/PGP2 CAN NOT BOTH BE PRESENT", who);
+    if (a.gp_nfld < if_gp_g) EMI_FAIL(EMI_ERR_ARG, "%s:SECOND DIMENSION OF PGP TOO SMALL (%d < %d)", who, a.gp_nfld, if_gp_g);
+  } else {
+    if (nuvg > 0 && !a.gpuv) EMI_FAIL(EMI_ERR_ARG, "%s:PGPUV MISSING", who);
+    if (vg.nsc_g[0] > 0) EMI_FAIL(EMI_ERR_ARG, "%s:PGP MISSING (PSPSCALAR needs PGP)", who);
+    if (vg.nsc_g[1] > 0 && !a.gp2) EMI_FAIL(EMI_ERR_ARG, "%s:PGP2 MISSING", who);
+    if (vg.nsc_g[2] * a.sc3a_nvar > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3A MISSING", who);
+    if (vg.nsc_g[3] * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3B MISSING", who);
+  }
+  // ---- the caller's arrays on the device (spectral: local fields; grid: all fields on this task's points)
+  HostStage hs(P.esz);
+  const size_t ns2 = P.nspec2, gsz = (size_t)nproma * ngpblks;
+  const bool gpad = gsz != (size_t)myp;
+  emi_invtrans_t in = a;
+  in.mem_space = EMI_MEM_DEVICE;
+  in.ext = nullptr;
+  in.vsets = nullptr;
+  in.spvor = hs.in(a.spvor, ns2 * a.nf_uv, host, st), in.spdiv = hs.in(a.spdiv, ns2 * a.nf_uv, host, st);
+  in.spscalar = hs.in(a.spscalar, ns2 * a.nf_scalar, host, st), in.spsc2 = hs.in(a.spsc2, ns2 * a.nf_sc2, host, st);
+  in.spsc3a = hs.in(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host, st), in.spsc3b = hs.in(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host, st);
+  void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host, gpad || a.gp_nfld > if_gp_g, st);
+  void *d_gpuv = hs.out(a.gpuv, gsz * nuvg * nvar_uv, host && nuvg, gpad, st);
+  void *d_gp2 = hs.out(a.gp2, gsz * vg.nsc_g[1] * dmul, host, gpad, st);
+  void *d_gp3a = hs.out(a.gp3a, gsz * vg.nsc_g[2] * a.sc3a_nvar * dmul, host, gpad, st);
+  void *d_gp3b = hs.out(a.gp3b, gsz * vg.nsc_g[3] * a.sc3b_nvar * dmul, host, gpad, st);
+  if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
+  VGridList gl;
+  v_grid_fields(vg, lvorgp, ldivgp, lscders, luvder, d_gp, a.gp_nfld, d_gpuv, nvar_uv, d_gp2, d_gp3a, a.sc3a_nvar, d_gp3b, a.sc3b_nvar, gl);
+  std::vector<int> nl(P.nprv, 0);  // grid fields every V-set computes
+  for (int o : gl.owner) nl[o]++;
+  const int nlm = nl[P.mev];
+  // ---- the W-set transform of the local fields into a band-sized array [field][band point]
+  StageBuf tband((size_t)nlm * bandp * P.esz), sbuf((size_t)nlm * bandp * P.esz), rbuf((size_t)if_gp_g * myp * P.esz);
+  if ((nlm && (!tband.p || !sbuf.p)) || !rbuf.p) EMI_FAIL(EMI_ERR_RUNTIME, "%s: no device memory for the exchange between the V-sets", who);
+  if (nlm) {
+    in.gp = tband.p, in.gp_nfld = nlm, in.gpuv = in.gp3a = in.gp3b = in.gp2 = nullptr, in.kproma = (int)bandp;
+    const int rc = inv_trans_impl(kresol, &in, adj);
+    if (rc) return rc;
+  }
+  // ---- TRLTOG: block (me -> v') = my fields on the points of sub-band v'
+  std::vector<StageBuf *> keep;
+  std::vector<long long> sc(P.nprv), rc(P.nprv);
+  std::vector<GridFld> tb(nlm);
+  for (int j = 0; j < nlm; j++) tb[j].base = tband.p, tb[j].nf_arr = nlm, tb[j].fidx = j;
+  int bad = 0;
+  size_t soff = 0;
+  for (int v = 0; v < P.nprv && !bad; v++) {
+    const long long np = P.vpoints(P.me, v);
+    std::vector<GridFld> ds(nlm);
+    for (int j = 0; j < nlm; j++) ds[j] = dense_field((char *)sbuf.p + soff, j, np, P.esz);
+    bad = v_copy(P, tb, ds, P.voffset(v), 0, np, bandp, np, keep, st);
+    sc[v] = (long long)nlm * np * P.esz;
+    rc[v] = (long long)nl[v] * myp * P.esz;
+    soff += (size_t)sc[v];
+  }
+  if (!bad) bad = hook_alltoallv(sbuf.p, sc, rbuf.p, rc, P.nprv, 1, P.me * P.nprv, st);
+  size_t roff = 0;
+  for (int v = 0; v < P.nprv && !bad; v++) {
+    std::vector<GridFld> sr, dd;
+    for (size_t k = 0; k < gl.g.size(); k++)
+      if (gl.owner[k] == v) {
+        sr.push_back(dense_field((char *)rbuf.p + roff, sr.size(), myp, P.esz));
+        dd.push_back(gl.g[k]);
+      }
+    bad = v_copy(P, sr, dd, 0, 0, myp, myp, nproma, keep, st);
+    roff += (size_t)rc[v];
+  }
+  if (host && !bad) hs.flush(st);
+  else emi_stream_sync(st);  // the scratch buffers go back to the pool below
+  for (StageBuf *k : keep) delete k;
+  return bad ? EMI_ERR_RUNTIME : EMI_SUCCESS;
+}
+
+static int dir_trans_vsets(int kresol, const emi_dirtrans_t *ap, bool adj, const AdjOpts *ao) {
+  Plan *Pp = get_plan(kresol);
+  const char *who = adj ? "INV_TRANSAD" : "DIR_TRANS";
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "%s: unknown resolution %d", who, kresol);
+  if (!ap) EMI_FAIL(EMI_ERR_ARG, "%s: null argument block", who);
+  Plan &P = *Pp;
+  const emi_dirtrans_t &a = *ap;
+  if (ao && (ao->scders || ao->vorgp || ao->divgp || ao->uvder))
+    EMI_FAIL(EMI_ERR_UNSUPPORTED, "INV_TRANSAD: LDSCDERS / LDVORGP / LDDIVGP / LDUVDER are not supported with NPRTRV > 1");
+  emi_stream_t st = (emi_stream_t)a.stream;
+  const bool host = a.mem_space == EMI_MEM_HOST;
+  VGroups vg;
+  if (v_groups(P, a, who, vg)) return EMI_ERR_ARG;
+  const int nuvg = vg.nuv_g, nscg = (int)vg.sc_g.size();
+  const int if_gp_g = 2 * nuvg + nscg;
+  if (if_gp_g == 0) return EMI_SUCCESS;
+  const long long myp = P.vpoints(P.me, P.mev), bandp = P.ngptot;
+  const int nproma = a.kproma > 0 ? a.kproma : (int)myp;
+  const int ngpblks = (int)((myp - 1) / nproma + 1);
+  if (a.gp) {
+    if (a.gpuv || a.gp3a || a.gp3b || a.gp2) EMI_FAIL(EMI_ERR_ARG, "%s:PGP AND PGPUV/PGP3A/PGP3B/PGP2 CAN NOT BOTH BE PRESENT", who);
+    if (a.gp_nfld < if_gp_g) EMI_FAIL(EMI_ERR_ARG, "%s:SECOND DIMENSION OF PGP TOO SMALL (%d < %d)", who, a.gp_nfld, if_gp_g);
+  } else {
+    if (nuvg > 0 && !a.gpuv) EMI_FAIL(EMI_ERR_ARG, "%s:PGPUV MISSING", who);
+    if (vg.nsc_g[0] > 0) EMI_FAIL(EMI_ERR_ARG, "%s:PGP MISSING (PSPSCALAR needs PGP)", who);
+    if (vg.nsc_g[1] > 0 && !a.gp2) EMI_FAIL(EMI_ERR_ARG, "%s:PGP2 MISSING", who);
+    if (vg.nsc_g[2] * a.sc3a_nvar > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3A MISSING", who);
+    if (vg.nsc_g[3] * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3B MISSING", who);
+  }
+  HostStage hs(P.esz);
+  const size_t ns2 = P.nspec2, gsz = (size_t)nproma * ngpblks;
+  emi_dirtrans_t in = a;
+  in.mem_space = EMI_MEM_DEVICE;
+  in.ext = nullptr;
+  in.vsets = nullptr;
+  in.spvor = hs.out(a.spvor, ns2 * a.nf_uv, host), in.spdiv = hs.out(a.spdiv, ns2 * a.nf_uv, host);
+  in.spscalar = hs.out(a.spscalar, ns2 * a.nf_scalar, host), in.spsc2 = hs.out(a.spsc2, ns2 * a.nf_sc2, host);
+  in.spsc3a = hs.out(a.spsc3a, ns2 * a.sc3a_nlev * a.sc3a_nvar, host), in.spsc3b = hs.out(a.spsc3b, ns2 * a.sc3b_nlev * a.sc3b_nvar, host);
+  void *d_gp = (void *)hs.in(a.gp, gsz * a.gp_nfld, host, st);
+  void *d_gpuv = (void *)hs.in(a.gpuv, gsz * nuvg * 2, host && nuvg, st);
+  void *d_gp2 = (void *)hs.in(a.gp2, gsz * vg.nsc_g[1], host, st);
+  void *d_gp3a = (void *)hs.in(a.gp3a, gsz * vg.nsc_g[2] * a.sc3a_nvar, host, st);
+  void *d_gp3b = (void *)hs.in(a.gp3b, gsz * vg.nsc_g[3] * a.sc3b_nvar, host, st);
+  if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
+  VGridList gl;  // u(nuv_g) v(nuv_g) scalars: dir_trans.F90:301
+  v_grid_fields(vg, false, false, false, false, d_gp, a.gp_nfld, d_gpuv, 2, d_gp2, d_gp3a, a.sc3a_nvar, d_gp3b, a.sc3b_nvar, gl);
+  std::vector<int> nl(P.nprv, 0);
+  for (int o : gl.owner) nl[o]++;
+  const int nlm = nl[P.mev];
+  StageBuf tband((size_t)nlm * bandp * P.esz), rbuf((size_t)nlm * bandp * P.esz), sbuf((size_t)if_gp_g * myp * P.esz);
+  if ((nlm && (!tband.p || !rbuf.p)) || !sbuf.p) EMI_FAIL(EMI_ERR_RUNTIME, "%s: no device memory for the exchange between the V-sets", who);
+  // ---- TRGTOL: block (me -> v'') = the fields of V-set v'' on my points
+  std::vector<StageBuf *> keep;
+  std::vector<long long> sc(P.nprv), rc(P.nprv);
+  int bad = 0;
+  size_t soff = 0;
+  for (int v = 0; v < P.nprv && !bad; v++) {
+    std::vector<GridFld> sr, dd;
+    for (size_t k = 0; k < gl.g.size(); k++)
+      if (gl.owner[k] == v) {
+        dd.push_back(dense_field((char *)sbuf.p + soff, dd.size(), myp, P.esz));
+        sr.push_back(gl.g[k]);
+      }
+    bad = v_copy(P, sr, dd, 0, 0, myp, nproma, myp, keep, st);
+    sc[v] = (long long)nl[v] * myp * P.esz;
+    rc[v] = (long long)nlm * P.vpoints(P.me, v) * P.esz;
+    soff += (size_t)sc[v];
+  }
+  if (!bad) bad = hook_alltoallv(sbuf.p, sc, rbuf.p, rc, P.nprv, 1, P.me * P.nprv, st);
+  std::vector<GridFld> tb(nlm);
+  for (int j = 0; j < nlm; j++) tb[j].base = tband.p, tb[j].nf_arr = nlm, tb[j].fidx = j;
+  size_t roff = 0;
+  for (int v = 0; v < P.nprv && !bad; v++) {
+    const long long np = P.vpoints(P.me, v);
+    std::vector<GridFld> sr(nlm);
+    for (int j = 0; j < nlm; j++) sr[j] = dense_field((char *)rbuf.p + roff, j, np, P.esz);
+    bad = v_copy(P, sr, tb, 0, P.voffset(v), np, np, bandp, keep, st);
+    roff += (size_t)rc[v];
+  }
+  int rcode = bad ? EMI_ERR_RUNTIME : EMI_SUCCESS;
+  if (!bad && nlm) {
+    in.gp = tband.p, in.gp_nfld = nlm, in.gpuv = in.gp3a = in.gp3b = in.gp2 = nullptr, in.kproma = (int)bandp;
+    rcode = dir_trans_impl(kresol, &in, adj, nullptr);
+  }
+  if (host && rcode == EMI_SUCCESS) hs.flush(st);
+  else emi_stream_sync(st);
+  for (StageBuf *k : keep) delete k;
+  return rcode;
+}
+
 extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *args) {
   EmiRange rg(EMI_LBL_INV);  // GSTATS 4
+  if (G.nprtrv > 1) return inv_trans_vsets(kresol, args, false);
   return inv_trans_impl(kresol, args, false);
 }
 extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *args) {
   EmiRange rg(EMI_LBL_DIR);  // GSTATS 5
+  if (G.nprtrv > 1) return dir_trans_vsets(kresol, args, false, nullptr);
   return dir_trans_impl(kresol, args, false);
 }
 
@@ -2907,10 +3390,12 @@ extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {
   d.gp = a.gp, d.gp_nfld = a.gp_nfld, d.gpuv = a.gpuv, d.gp3a = a.gp3a, d.gp3b = a.gp3b, d.gp2 = a.gp2;
   d.stream = a.stream;
   d.ext = a.ext;
+  d.vsets = a.vsets;
   // LDSCDERS / LDVORGP / LDDIVGP / LDUVDER: the grid arrays then carry the derivative / vorticity / divergence inputs in
   // INV_TRANS's layout (ltinvad_mod.F90:149-225, spnsdead_mod.F90, fscad_mod.F90)
   AdjOpts ao;
   ao.scders = a.ldscders != 0, ao.vorgp = a.ldvorgp != 0, ao.divgp = a.lddivgp != 0 || a.ldvorgp != 0, ao.uvder = a.lduvder != 0;
+  if (G.nprtrv > 1) return dir_trans_vsets(kresol, &d, true, &ao);
   return dir_trans_impl(kresol, &d, true, &ao);
 }
 // DIR_TRANSAD (include/ectrans/dir_transad.h): arguments of DIR_TRANS with the intents swapped
@@ -2929,5 +3414,7 @@ extern "C" int emi_dir_transad(int kresol, const emi_dirtrans_t *ap) {
   a.gp2 = (void *)d.gp2;
   a.stream = d.stream;
   a.ext = d.ext;
+  a.vsets = d.vsets;
+  if (G.nprtrv > 1) return inv_trans_vsets(kresol, &a, true);
   return inv_trans_impl(kresol, &a, true);
 }

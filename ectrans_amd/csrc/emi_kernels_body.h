@@ -2090,6 +2090,24 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
 }
 
 // ==========================================================================================
+// k_gridcopy: TRLTOG / TRGTOL between the V-sets (NPRTRV > 1; trltog_mod.F90:18-964, trgtol_mod.F90:18-968).  Fourier space
+// holds the fields of one V-set on the latitudes of a whole W-set band; grid space holds ALL fields on the sub-band of one
+// task.  The re-distribution is an all-to-all-v among the NPRTRV tasks of a band; this kernel packs / unpacks its blocks:
+// nf fields, npts points, element p of field f from src[f] (point sp0 + p) to dst[f] (point dp0 + p), both addressed as
+// NPROMA-blocked grid arrays (GridFld; a dense [field][point] block is the case nf_arr = 1, NPROMA >= npts).
+// ==========================================================================================
+EMI_KERNEL_LB(256) void k_gridcopy(const GridFld *src, const GridFld *dst, int nf, long long sp0, long long dp0, int npts, int snp, int dnp) {
+  const long long id = (long long)EMI_BID * 256 + EMI_TID;
+  const int f = (int)(id / npts);
+  if (f >= nf) return;
+  const long long p = id - (long long)f * npts;
+  const GridFld s = src[f], d = dst[f];
+  const long long sp = sp0 + p, dp = dp0 + p;
+  const real_t v = ((const real_t *)s.base)[((sp / snp) * s.nf_arr + s.fidx) * (long long)snp + sp % snp];
+  ((real_t *)d.base)[((dp / dnp) * d.nf_arr + d.fidx) * (long long)dnp + dp % dnp] = v;
+}
+
+// ==========================================================================================
 // k_legpol: SUPOLF (supolf_mod.F90:13-251) for m >= 2 on the device -- the normalised associated
 // Legendre functions P_n^m(mu), n = m+par, m+par+2, ..., of one (wavenumber, parity, latitude) per
 // thread, by the reference's 4-term recurrence in n with its 1e+-100 rescaling, written straight into

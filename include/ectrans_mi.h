@@ -49,7 +49,12 @@ typedef struct {
   int nproc;       /* number of ranks sharing the zonal-wavenumber/latitude distribution  */
   int myproc;      /* 1-based rank (MYPROC)                                               */
   int device;      /* HIP device ordinal, -1: keep current                                */
+  int nprtrv;      /* NPRTRV (sump_trans0_mod.F90:49): V-sets; 0 or 1: one.  nproc = NPRTRW x NPRTRV tasks, task
+                    * myproc is (MYSETW, MYSETV) = ((myproc-1) / NPRTRV + 1, mod(myproc-1, NPRTRV) + 1) as PE2SET
+                    * (pe2set_mod.F90:111-112).  0 also takes a value set earlier with emi_set_nprtrv (for hosts whose
+                    * transport calls emi_init: emi_mpi_attach, emi_rccl_attach).                                    */
 } emi_init_t;
+int emi_set_nprtrv(int nprtrv);
 int emi_init(const emi_init_t *cfg);
 
 /* ---- SETUP_TRANS (trans/cpu/external/setup_trans.F90:11-434) ------------------------ */
@@ -116,6 +121,19 @@ typedef struct {
   int gp2[3];    /* UBOUND(PGP2)  = nproma, fields, ngpblks                                                     */
 } emi_extents_t;
 
+/* ---- KVSETUV / KVSETSC / KVSETSC2 / KVSETSC3A / KVSETSC3B (inv_trans.h:84-101, dir_trans.h:75-92) -------------------
+ * With NPRTRV > 1 the fields are dealt to the V-sets in spectral (and Fourier) space: kvset*[f] (1..NPRTRV) names the V-set
+ * of GLOBAL field f, the spectral arrays of a call hold only the fields of this task's V-set (in global order), the grid
+ * arrays hold ALL fields (n*_g of them; levels for the 3-D arrays) on this task's grid points (inv_trans.F90:212-300).  Every
+ * group that is present needs its array; NULL block = one V-set.                                                     */
+typedef struct {
+  const int *kvsetuv;   int nuv_g;    /* KVSETUV(nuv_g)                                            */
+  const int *kvsetsc;   int nsc_g;    /* KVSETSC(nsc_g)                                            */
+  const int *kvsetsc2;  int nsc2_g;   /* KVSETSC2(nsc2_g)                                          */
+  const int *kvsetsc3a; int nsc3a_g;  /* KVSETSC3A(nsc3a_g): V-set of every LEVEL of PSPSC3A       */
+  const int *kvsetsc3b; int nsc3b_g;
+} emi_vsets_t;
+
 /* ---- INV_TRANS (trans/include/ectrans/inv_trans.h:12-163) --------------------------- */
 typedef struct {
   int mem_space;
@@ -142,6 +160,7 @@ typedef struct {
                                * serialised by the library whatever their streams (they share its work
                                * buffers): a call waits, on the device, for the previous call of that handle */
   const emi_extents_t *ext;   /* extents of the arrays above, NULL: unchecked                */
+  const emi_vsets_t *vsets;   /* NPRTRV > 1: the V-set of every global field (nf_uv ... then count LOCAL fields) */
 } emi_invtrans_t;
 int emi_inv_trans(int kresol, const emi_invtrans_t *args);
 
@@ -165,6 +184,7 @@ typedef struct {
   const void *gp3a, *gp3b, *gp2;
   void *stream;
   const emi_extents_t *ext;
+  const emi_vsets_t *vsets;
 } emi_dirtrans_t;
 int emi_dir_trans(int kresol, const emi_dirtrans_t *args);
 
@@ -183,6 +203,12 @@ int emi_dir_transad(int kresol, const emi_dirtrans_t *args);
 
 /* ---- SPECNORM (trans/include/ectrans/specnorm.h:12) --------------------------------- */
 int emi_specnorm(int kresol, int mem_space, const void *spec, int nfld, double *norms /* host */);
+
+/* SPECNORM with KVSET (NPRTRV > 1): spec holds the nfld fields of this task's V-set, norms_g (host) receives the norms of all
+ * nfld_g fields, kvset[f] = V-set of global field f.  Collective over all tasks (host collectives).                   */
+int emi_specnorm_kvset(int kresol, int mem_space, const void *spec, int nfld, const int *kvset, int nfld_g, double *norms_g);
+/* NPRTRW, NPRTRV, MYSETW, MYSETV (sump_trans0_mod.F90:49, pe2set_mod.F90:111-112) of the initialised library                */
+int emi_inq_vsets(int *nprtrw, int *nprtrv, int *mysetw, int *mysetv);
 
 /* ---- TRLTOM / TRMTOL (trans/cpu/internal/trltom_mod.F90:96-136, trmtol_mod.F90:101-141) ---------
  * With nproc > 1 every task owns the zonal wavenumbers of its W-set (zig-zag, suwavedi_mod.F90:118-137)

@@ -31,3 +31,34 @@ def test_wset_sharding_with_alltoallv(world, order):
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("DIST OK rank %d" % rank) in out, out
+
+
+def run_vsets(world, nprtrv, port, device="cpu", extra=None, timeout=1200):
+    """tests/vsets_worker.py on `world` = NPRTRW x `nprtrv` tasks; every task checks its pieces against the oracle"""
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1024", EMI_TEST_NPRTRV=str(nprtrv), EMI_TEST_DEVICE=device)
+        env.update(extra or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "vsets_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("VSETS OK rank %d" % rank) in out, out
+
+
+@pytest.mark.parametrize("world,nprtrv", [(2, 2), (4, 2), (8, 2), (6, 3)])
+def test_vset_sharding(world, nprtrv):
+    """NPRTRV > 1 (sump_trans0_mod.F90:49, inv_trans.F90:212-300): NPRTRW x NPRTRV tasks -- 1 x 2, 2 x 2, 4 x 2 and 2 x 3.
+    Spectral arrays hold the fields of the task's V-set (KVSETUV / KVSETSC / KVSETSC2 / KVSETSC3A), grid arrays ALL fields on
+    the task's latitudes; TRLTOG / TRGTOL between the V-sets of a band is a second all-to-all-v.  Emulator kernels, gloo."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    run_vsets(world, nprtrv, 29530 + world + nprtrv)

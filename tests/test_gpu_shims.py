@@ -199,3 +199,30 @@ print("NATIVE RCCL ATTACH OK")
 """ % ROOT
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "NATIVE RCCL ATTACH OK" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("world,nprtrv,prec", [(2, 2, 8), (4, 2, 8), (6, 3, 8), (4, 2, 4)])
+def test_vset_sharding_on_one_gpu(world, nprtrv, prec):
+    """NPRTRV > 1 with the HIP kernels (round 3; sump_trans0_mod.F90:49, inv_trans.F90:212-300): NPRTRW x NPRTRV tasks share cuda:0,
+    both exchanges -- TRMTOL / TRLTOM inside a V-set, TRLTOG / TRGTOL between the V-sets of a band (k_gridcopy packs) -- staged through
+    gloo; every task checks its wavenumbers x its V-set's fields, and ALL fields on its own latitudes, against the oracle
+    (tests/vsets_worker.py), single PGP with every derivative option and call mode 2 with levels dealt to the V-sets."""
+    from tests.test_dist_gloo import run_vsets
+    run_vsets(world, nprtrv, 29640 + world + nprtrv + (20 if prec == 4 else 0), device="cuda", extra={"EMI_TEST_NSMAX": "63", "EMI_TEST_PRECISION": str(prec)})
+
+
+@pytest.mark.parametrize("ntasks", [2, 4])
+def test_fortran_shim_with_two_vsets(ntasks):
+    """The Fortran drop-in with NPRTRV = 2 (tests/fortran/test_shim_vsets.F90 under mpiexec -n 2 / -n 4: 1 x 2 and 2 x 2 tasks):
+    SETUP_TRANS0(KPRTRW = NPROC / 2), KVSETSC honoured by INV_TRANS / DIR_TRANS, TRANS_INQ's KMYSETW / KMYSETV / KFRSTLAT, SPECNORM
+    with KVSET.  Checks without an oracle: field f = f P_1^0 lands as f sqrt(3) mu in slot f of PGP on every task's own
+    latitudes, and dense fields survive INV_TRANS -> DIR_TRANS.  Skipped without MPI."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec) or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI installation")
+    d = os.path.join(ROOT, "ectrans_amd", "fortran")
+    subprocess.check_call(["make", "-s", "-C", d, "test_shim_vsets"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([mpiexec, "-n", str(ntasks), os.path.join(d, "test_shim_vsets")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and p.stdout.count("FORTRAN SHIM VSETS OK") == ntasks, p.stdout + p.stderr
