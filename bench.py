@@ -309,6 +309,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs: cpu_baseline and the dense sub-record")
     ap.add_argument("--no-api-level", action="store_true", help="skip the host-array (PCIe-inclusive) measurement")
     ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--nprtrv", type=int, default=int(os.environ.get("EMI_BENCH_NPRTRV", "1")),
+                    help="V-sets (N > 1 only): NPRTRW = N / NPRTRV; levels dealt to the V-sets as ectrans-benchmark.F90:329-344, 440-447")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -352,8 +354,13 @@ def main():
         transport = "rccl"
     transport_note = None
     ok = 1
+    nprtrv = max(1, args.nprtrv)
+    if world % nprtrv:
+        raise SystemExit("bench.py: --nprtrv %d does not divide %d tasks" % (nprtrv, world))
+    nprtrw = world // nprtrv
+    mysetv = rank % nprtrv + 1
     try:
-        et.setup_trans0(kmax_resol=2, device=local, kprtrw=world, myproc=rank + 1, transport=transport)
+        et.setup_trans0(kmax_resol=2, device=local, kprtrw=nprtrw, kprtrv=nprtrv, myproc=rank + 1, transport=transport)
     except OSError as e:
         if transport != "rccl":
             raise
@@ -372,7 +379,7 @@ def main():
                 _ed.rccl_native_lib().emi_rccl_detach()
             transport_note = transport_note or "native attach failed on another rank"
             transport = "torch"
-            et.setup_trans0(kmax_resol=2, device=local, kprtrw=world, myproc=rank + 1)
+            et.setup_trans0(kmax_resol=2, device=local, kprtrw=nprtrw, kprtrv=nprtrv, myproc=rank + 1)
     if args.max_batch:
         et.set_max_batch(args.max_batch)
     t0 = time.time()
@@ -387,18 +394,27 @@ def main():
     def z(*shape):
         return torch.zeros(shape, dtype=torch.float64 if esz == 8 else torch.float32, device=dev)
 
-    # call mode 2 arrays of the reference harness (ectrans-benchmark.F90:450-479)
-    spvor, spdiv, spsc3a, spsc2 = z(nspec2, nlev), z(nspec2, nlev), z(nfld, nspec2, nlev), z(nspec2, 1)
+    # call mode 2 arrays of the reference harness (ectrans-benchmark.F90:450-479); with V-sets the levels go to them in
+    # contiguous runs and the surface field to V-set min(nlev + 1, NPRTRV) (:329-344, 440-447)
+    kv = {}
+    nlevl, nsc2l = nlev, 1
+    if nprtrv > 1:
+        numll = [nlev // nprtrv + (1 if v < nlev % nprtrv else 0) for v in range(nprtrv)]
+        ivset = [v + 1 for v in range(nprtrv) for _ in range(numll[v])]
+        ivsetsc2 = [min(nlev + 1, nprtrv)]
+        kv = {"kvsetuv": ivset, "kvsetsc3a": ivset, "kvsetsc2": ivsetsc2}
+        nlevl, nsc2l = numll[mysetv - 1], int(ivsetsc2[0] == mysetv)
+    spvor, spdiv, spsc3a, spsc2 = z(nspec2, nlevl), z(nspec2, nlevl), z(nfld, nspec2, nlevl), z(nspec2, nsc2l)
     if i419 is not None:
         for a in (spvor, spdiv, spsc2):
             a[i419] = 1.0
         spsc3a[:, i419] = 1.0
     gpuv, gp3a, gp2 = z(1, 2, nlev, ngptot), z(1, nfld, nlev, ngptot), z(1, 1, ngptot)
-    n0 = et.specnorm(r, spsc2)[0]
+    n0 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
 
     def step():
-        et.inv_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
-        et.dir_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+        et.inv_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
+        et.dir_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
 
     def barrier():
         if world > 1:
@@ -417,8 +433,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i].record()
-        et.inv_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
-        et.dir_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2)
+        et.inv_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
+        et.dir_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
     ev[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -427,13 +443,14 @@ def main():
     pack_ms, leg_ms, fft_ms = et.last_phase_ms()
     leg_launches = et.last_phase_launches()[1]
     et.set_profile(0)
-    wm = et.work_model(r, kf)
+    kf_l = 2 * nlevl + nfld * nlevl + nsc2l  # Legendre / Fourier-space fields of this rank (= kf without V-sets)
+    wm = et.work_model(r, kf_l)
     # algorithmic HBM bytes of this rank (each array touched once per phase it belongs to, both directions)
-    nmen_sum = float(wm["fourier_bytes"]) / (2.0 * esz * kf)  # Fourier rows (lat, m <= NMEN) of this rank
+    nmen_sum = float(wm["fourier_bytes"]) / (2.0 * esz * max(kf_l, 1))  # Fourier rows (lat, m <= NMEN) of this rank
     ndglu = et.trans_inq(r, "ndglu")
     myms = et.trans_inq(r, "myms")
     pan_bytes = float(sum(int(min(N + 1, ndglu[m])) * (N - m + 2) for m in myms)) * esz  # Legendre matrices, read once per direction
-    spec_bytes = float(nspec2) * kf * esz
+    spec_bytes = float(nspec2) * kf_l * esz
     grid_bytes = float(ngptot) * kf * esz
     # per Legendre launch: packed spectral + panels + Fourier rows (read or written once)
     alg_leg_bytes = spec_bytes + pan_bytes + wm["fourier_bytes"]
@@ -450,7 +467,7 @@ def main():
         wm["legendre_flops"], wm["fourier_bytes"], ngptot = float(red[0]), float(red[1]), int(red[2].item())
         alg_leg_bytes, alg_pair_bytes = float(red[3]), float(red[4])
         leg_ms, fft_ms, pack_ms = (float(x) for x in mx)
-    n1 = et.specnorm(r, spsc2)[0]
+    n1 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
 
     if rank == 0:
         # per launch: algorithmic flops of the launch (all ranks) / average launch duration (slowest rank)
@@ -470,9 +487,10 @@ def main():
             "config": {"workload": "TCo%d/O%d, %d levels x %d 3-D fields + vor/div + 1 surface field, KF=%d, "
                                    "device-resident call-mode-2 arrays" % (N, N + 1, nlev, nfld, kf),
                        "parallelism": "1 GPU" if world == 1 else
-                       "%d GPUs: zonal wavenumbers zig-zag + latitude bands, all-to-all-v per direction over %s" % (
-                           world, ("RCCL (native grouped ncclSend / ncclRecv, ectrans_amd/rccl)" if transport == "rccl" else "RCCL (torch.distributed nccl)")
+                       "%d GPUs (w%dv%d): zonal wavenumbers zig-zag + latitude bands%s, all-to-all-v per direction over %s" % (
+                           world, nprtrw, nprtrv, " x %d V-sets of levels (second all-to-all-v in grid space)" % nprtrv if nprtrv > 1 else "", ("RCCL (native grouped ncclSend / ncclRecv, ectrans_amd/rccl)" if transport == "rccl" else "RCCL (torch.distributed nccl)")
                            if backend == "nccl" else backend + " (test configuration, host staged)"),
+                       "nprtrw": nprtrw, "nprtrv": nprtrv,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": None if world == 1 else ("rccl-native" if transport == "rccl" else backend),
                        "transport_note": transport_note, "pipeline_batches": int(os.environ.get("EMI_PIPELINE_DIST", "4")) if world > 1 else 1,

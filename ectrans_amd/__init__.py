@@ -126,6 +126,7 @@ def _bind(L):
     L.emi_last_phase_ms.argtypes = [dp]
     L.emi_set_max_batch.argtypes = [C.c_int]
     L.emi_specnorm_partial.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, dp]
+    L.emi_specnorm_kvset.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, dp]
     L.emi_set_alltoallv.argtypes = [C.c_void_p, C.c_void_p]
     L.emi_set_profile.argtypes = [C.c_int]
     L.emi_last_phase_launches.argtypes = [ip]
@@ -470,21 +471,28 @@ def dir_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, 
     _chk(lib().emi_dir_transad(kresol, C.byref(a)))
 
 
-def specnorm(kresol, pspec):
+def specnorm(kresol, pspec, kvset=None):
     """SPECNORM (specnorm.h:12): per-field spectral L2 norm, returned as a numpy array (on every
-    task; the reference returns it on the master only)."""
+    task; the reference returns it on the master only).  kvset (NPRTRV > 1, specnorm.F90:82-101): V-set of every GLOBAL
+    field; pspec holds this task's fields of its own V-set and the norms of all len(kvset) fields come back."""
     space = [None, real_dtype(kresol)]
     if pspec.shape[1] == 0:
         p, keep, space[0] = None, None, EMI_MEM_HOST
     else:
         p, keep = _ptr(pspec, space)
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    if kvset is not None and _DIST.get("nprtrv", 1) > 1:
+        kv = np.ascontiguousarray(kvset, dtype=np.int32)
+        out = np.zeros(kv.size)
+        _chk(lib().emi_specnorm_kvset(kresol, space[0], p, pspec.shape[1], kv.ctypes.data_as(C.POINTER(C.c_int)), kv.size, pd(out)))
+        return out
     out = np.zeros(pspec.shape[1])
     if _DIST["nproc"] == 1 or _DIST.get("nprtrv", 1) > 1:
         # several V-sets: the library sums over the tasks of this V-set itself (host collectives)
-        _chk(lib().emi_specnorm(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
+        _chk(lib().emi_specnorm(kresol, space[0], p, pspec.shape[1], pd(out)))
         return out
     from . import dist as _dist
-    _chk(lib().emi_specnorm_partial(kresol, space[0], p, pspec.shape[1], out.ctypes.data_as(C.POINTER(C.c_double))))
+    _chk(lib().emi_specnorm_partial(kresol, space[0], p, pspec.shape[1], pd(out)))
     return np.sqrt(_dist.all_reduce_sum(out, _DIST["group"], _DIST["device"]))  # every task gets the norms
 
 

@@ -93,6 +93,7 @@ int emi_mpi_attach(MPI_Comm comm, int kmax_resol, int kprintlev, double prad, in
     device = rank % ndev;
   }
   emi_init_t cfg;
+  memset(&cfg, 0, sizeof(cfg)); /* nprtrv = 0: emi_set_nprtrv's value, else 1 */
   cfg.kmax_resol = kmax_resol;
   cfg.kprintlev = kprintlev;
   cfg.prad = prad;

@@ -91,16 +91,17 @@ def test_decomposition_invariance_and_checksum_dumps(tmp_path):
     check_invariance(res)
 
 
-@pytest.mark.parametrize("ngpus", [2, 4, 8])
-def test_bench_multi_rank_launch(ngpus):
+@pytest.mark.parametrize("ngpus,nprtrv", [(2, 1), (4, 1), (8, 1), (8, 2), (4, 4)])
+def test_bench_multi_rank_launch(ngpus, nprtrv):
     """`bench.py --gpus N` in its test configuration (EMI_BENCH_BACKEND=gloo, EMI_BENCH_ONE_GPU=1: N ranks share the one
     GPU, the exchange is staged through the host) at TCo399: the launcher, the sharded set-up, the timed loop and the
-    JSON line -- so that the first run on an 8-GPU node cannot fail for software reasons."""
+    JSON line -- so that the first run on an 8-GPU node cannot fail for software reasons.  (8, 2) is the split the
+    reference's benchmark picks for 8 tasks (ectrans-benchmark.F90:280-306): `--nprtrv 2`, levels dealt to two V-sets."""
     import json
     import sys
     env = dict(os.environ, EMI_BENCH_BACKEND="gloo", EMI_BENCH_ONE_GPU="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ngpus), "--nsmax", "399", "--nlev", "30", "--nfld", "2",
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--nprtrv", str(nprtrv)], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout + p.stderr
@@ -109,6 +110,7 @@ def test_bench_multi_rank_launch(ngpus):
     assert out["value"] > 0 and np.isfinite(out["value"]) and abs(out["ms_per_step"] * out["value"] - 1000.0) < 1e-6 * 1000
     assert abs(out["roofline"]["peak"] - ngpus * 78.6) < 1e-9 and 0 < out["roofline"]["frac"] < 1
     assert out["config"]["world_size"] == ngpus and out["config"]["backend"] == "gloo"
+    assert out["config"]["nprtrv"] == nprtrv and out["config"]["nprtrw"] * nprtrv == ngpus
     assert out["spectral_norm_rel_error"] < 1e-12
 
 

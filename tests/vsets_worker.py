@@ -86,6 +86,8 @@ def main():
     if len(lsc):
         errs.append(rel_err(back(s2), sr[gidx][:, lsc]))
         e_norm = np.abs(norms / o.specnorm(sc)[lsc] - 1.0).max()
+    # SPECNORM with KVSET (specnorm.F90:82-101): the norms of ALL fields on every task
+    e_norm = max(e_norm, np.abs(et.specnorm(r, to(loc(sc, lsc)), kvset=kvsc) / o.specnorm(sc) - 1.0).max())
     e_dir = max(errs) if errs else 0.0
     # ---- call mode 2: PGPUV / PGP3A / PGP2 with levels dealt to the V-sets (KVSETSC3A per level)
     nlev, nvar = 4, 2
