@@ -82,7 +82,7 @@ def build(force=False):
     """Compile libectrans_mi.so for gfx950 with hipcc (in-tree)."""
     import subprocess
     src = os.path.join(_HERE, "csrc", "ectrans_mi.hip")
-    deps = [src] + [os.path.join(_HERE, "csrc", f) for f in ("emi_kernels.h", "emi_kernels_body.h", "emi_types.h", "emi_rt.h", "emi_setup.h", "emi_stage.h")]
+    deps = [src] + [os.path.join(_HERE, "csrc", f) for f in ("emi_kernels.h", "emi_kernels_body.h", "emi_mr_body.h", "emi_mr_tables.h", "emi_types.h", "emi_rt.h", "emi_setup.h", "emi_stage.h")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "ectrans_mi.h"))
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(d) for d in deps):
         return _LIBPATH

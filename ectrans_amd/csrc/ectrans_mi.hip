@@ -190,6 +190,7 @@ struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a w
   int nthr = 0, fbk = 0;
   int hot = 0;  // > 0: specialised kernel k_fft_*_hot<hot> (EMI_HOT_PLAN_LIST)
   int r16 = 0;  // > 0: register-resident kernel k_fft_*_r16<r16> (EMI_R16_LIST)
+  int mr = 0;   // 1: direct mixed-radix kernels k_fft_*_mr (EMI_MR_RADICES)
   int gmem = 0;  // 1: the work array does not fit the LDS; k_fft_*_gm on a global scratch buffer (elems: complex numbers per workgroup)
   long long gm_elems = 0;
   std::vector<int> lats;
@@ -367,6 +368,68 @@ extern "C" int emi_init(const emi_init_t *cfg) {
 // ------------------------------------------------------------------------------------------
 static int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
+// Direct mixed-radix plan of k_fft_*_mr for a complex length sz: radices A, B, C (B, C may be 1) from EMI_MR_RADICES and the
+// workgroup threads for `nf` fields per workgroup, by a lane-time model: a pass of radix R costs ops(R) / R + 15 lane
+// operations per point (butterfly; LDS round trip, twiddle, addressing), times the idle share of its last sweep.
+static double mr_radix_ops(int R) {
+  switch (R) {
+    case 2: return 4; case 3: return 14; case 4: return 16; case 5: return 36; case 7: return 66; case 11: return 150;
+    case 13: return 204; case 17: return 336; case 19: return 414; case 23: return 594;
+    case 6: return 3 * 4 + 2 * 14 + 12; case 8: return 4 * 4 + 2 * 16 + 18; case 9: return 6 * 14 + 24; case 10: return 5 * 4 + 2 * 36 + 24;
+    case 12: return 4 * 14 + 3 * 16 + 36; case 14: return 7 * 4 + 2 * 66 + 36; case 15: return 5 * 14 + 3 * 36 + 48; case 16: return 8 * 16 + 54;
+    default: return -1;
+  }
+}
+static bool mr_choose(int sz, int esz, int fac[3], int &fbk, int &nthr) {
+  static const int rs[] = {
+#define EMI_MR_ROW(r_) r_,
+      EMI_MR_RADICES(EMI_MR_ROW)
+#undef EMI_MR_ROW
+  };
+  double best = 1e300;
+  bool found = false;
+  auto consider = [&](int A, int B, int C) {
+    const int P1 = (B * C) | 1;
+    const size_t per_field = (size_t)A * P1 * 2 * esz;
+    if (per_field > 160 * 1024 || A * P1 > 65535) return;
+    int fb = 16;
+    const size_t lds_budget = getenv("EMI_FFT_MR_LDS") ? (size_t)atol(getenv("EMI_FFT_MR_LDS")) : 40960;
+    while (fb > 1 && fb * per_field > lds_budget) fb >>= 1;
+    const int R[3] = {A, B, C};
+    const int nt_only = getenv("EMI_FFT_MR_NT") ? atoi(getenv("EMI_FFT_MR_NT")) : 0;  // experiments: one workgroup size for every row
+    for (int nt = 64; nt <= 256; nt += 64) {
+      if (nt_only ? nt != nt_only : nt < 128) continue;
+      double cost = 0;
+      for (int ip = 0; ip < 3; ip++) {
+        if (R[ip] == 1) continue;
+        const long long nb = (long long)fb * (sz / R[ip]);
+        const long long sweeps = (nb + nt - 1) / nt;
+        cost += (double)(sweeps * nt) / (double)nb * (mr_radix_ops(R[ip]) / R[ip] + 15.0);
+      }
+      // the LDS footprint fixes the workgroups per CU, so a smaller workgroup means fewer waves to hide latencies behind: measured at
+      // TCo1279, one size for all rows: 256 threads 38.8 ms, 192 42.1 ms, 128 51.2 ms, 64 66 ms (per pair, the rows these kernels carry)
+      cost *= 1.0 + 0.12 * (256 - nt) / 64.0;
+      if (cost < best * (1.0 - 1e-9) || (cost <= best * (1.0 + 1e-9) && nt > nthr)) {
+        best = cost, found = true;
+        fac[0] = A, fac[1] = B, fac[2] = C, fbk = fb, nthr = nt;
+      }
+    }
+  };
+  for (int A : rs) {
+    if (sz % A) continue;
+    const int m1 = sz / A;
+    if (m1 == 1) consider(A, 1, 1);
+    for (int B : rs) {
+      if (m1 % B) continue;
+      const int C = m1 / B;
+      if (C == 1) consider(A, B, 1);
+      for (int Cc : rs)
+        if (Cc == C) consider(A, B, C);
+    }
+  }
+  return found;
+}
+
 static int build_fft_plans(Plan &P) {
   // Pass 1 (serial, cheap): one plan per distinct row length; table offsets.  The twiddle tables and
   // the digit-reversal table depend only on the work size S and its factor list, so all plans with the
@@ -376,7 +439,7 @@ static int build_fft_plans(Plan &P) {
   struct Shared {
     int S, tw_off, perm_off, ptw_off[14];
     std::vector<int> fac;
-    int r16 = 0;
+    int r16 = 0, mr = 0;
   };
   std::map<int, int> idx;            // row length -> plan
   std::map<int, int> sidx;           // work size -> shared tables
@@ -403,7 +466,17 @@ static int build_fft_plans(Plan &P) {
     // point the generic kernels cost 8.7 ps and row, the convolution 5.5 - 6 ps per work point (profiles/r3c_pmc_fft.txt), although it
     // does four times the arithmetic -- every one of those 100-odd row lengths has its own factor list, which the generic kernels
     // walk at run time.
-    if (!pl.cmode && !(getenv("EMI_FFT_R16") && atoi(getenv("EMI_FFT_R16")) == 0)) {
+    // Direct mixed-radix kernels (k_fft_*_mr, round 3): even rows whose half-length is a product of at most three radices of
+    // EMI_MR_RADICES -- no convolution.  EMI_FFT_MR=0: off; EMI_FFT_MR_MIN=sz: only half-lengths of at least sz.
+    int mr_fbk = 0, mr_nthr = 0, mr_fac[3] = {1, 1, 1};
+    if (!pl.cmode && pl.sz >= 2 && !(getenv("EMI_FFT_MR") && atoi(getenv("EMI_FFT_MR")) == 0) &&
+        pl.sz >= (getenv("EMI_FFT_MR_MIN") ? atoi(getenv("EMI_FFT_MR_MIN")) : 0))
+      pl.mr = mr_choose(pl.sz, P.esz, mr_fac, mr_fbk, mr_nthr) ? 1 : 0;
+    if (pl.mr) {
+      pl.blue = 0;
+      fac.assign(mr_fac, mr_fac + 3);
+    }
+    if (!pl.mr && !pl.cmode && !(getenv("EMI_FFT_R16") && atoi(getenv("EMI_FFT_R16")) == 0)) {
       static const int r1s[] = {
 #define EMI_R16_ROW(r_) r_,
           EMI_R16_LIST(EMI_R16_ROW)
@@ -464,16 +537,27 @@ static int build_fft_plans(Plan &P) {
     if (pl.S > 65535 || fac.size() > 14) EMI_FAIL(EMI_ERR_UNSUPPORTED, "FFT length %d not supported (work size %d)", n, pl.S);
     pl.nfac = (int)fac.size();
     for (int i = 0; i < pl.nfac; i++) pl.fac[i] = fac[i];
-    const int skey = pl.S * 16 + (pl.r16 ? 15 : pl.nfac);  // the tables depend on the factor list: merged and plain lists differ in length
+    const int skey = pl.S * 16 + (pl.r16 ? 15 : (pl.mr ? 14 : pl.nfac));  // the tables depend on the factor list: merged and plain lists differ in length
     auto si = sidx.find(skey);
     if (si == sidx.end()) {
       Shared sh{};
       sh.S = pl.S;
       sh.fac = fac;
       sh.r16 = pl.r16;
+      sh.mr = pl.mr;
       sh.tw_off = (int)n_tw;
       sh.perm_off = (int)n_perm;
-      if (pl.r16) {
+      if (pl.mr) {
+        // twiddle bases of pass 2, [k1]: w^(C k1), and of pass 3, [k1 + A k2]: w^(k1 + A k2) (input r of a butterfly times base^r);
+        // perm[k] = LDS position of coefficient k
+        const int A = fac[0], B = fac[1];
+        sh.ptw_off[0] = (int)n_ptw;
+        n_ptw += (size_t)A;
+        sh.ptw_off[1] = (int)n_ptw;
+        n_ptw += (size_t)A * B;
+        sh.ptw_off[2] = (int)n_ptw;
+        n_perm += pl.S;
+      } else if (pl.r16) {
         // the digit twiddles of A1 / B1: rows 0..2 = w^(t qa), qa = 1..3; rows 3..6 = w^(4 t qb), qb = 1..4; w = exp(-2 pi i / S), t < 256
         sh.ptw_off[0] = (int)n_ptw;
         n_ptw += 7 * 256;
@@ -552,11 +636,17 @@ static int build_fft_plans(Plan &P) {
       pl.fbk = 1;
       nthr = 16 * pl.r16 > 256 ? roundup(16 * pl.r16, 64) : 256;
     }
+    if (pl.mr) {
+      hot = 0;
+      fbk = mr_fbk;
+      pl.fbk = fbk;
+      nthr = mr_nthr;
+    }
     for (int i = 0; i < pl.nfac; i++)
-      if (!hot && !pl.r16 && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
+      if (!hot && !pl.r16 && !pl.mr && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
     int cls = -1;
     for (size_t c = 0; c < P.fclass.size(); c++)
-      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot && P.fclass[c].r16 == pl.r16 && P.fclass[c].gmem == (gmem ? 1 : 0)) cls = (int)c;
+      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot && P.fclass[c].r16 == pl.r16 && P.fclass[c].mr == pl.mr && P.fclass[c].gmem == (gmem && !pl.mr ? 1 : 0)) cls = (int)c;
     if (cls < 0) {
       cls = (int)P.fclass.size();
       P.fclass.emplace_back();
@@ -564,7 +654,8 @@ static int build_fft_plans(Plan &P) {
       P.fclass[cls].fbk = fbk;
       P.fclass[cls].hot = hot;
       P.fclass[cls].r16 = pl.r16;
-      P.fclass[cls].gmem = gmem ? 1 : 0;
+      P.fclass[cls].mr = pl.mr;
+      P.fclass[cls].gmem = gmem && !pl.mr ? 1 : 0;
     }
     pl.lds_class = cls;
     int id = (int)P.fplans.size();
@@ -578,6 +669,18 @@ static int build_fft_plans(Plan &P) {
   emi::parallel_for((int)shared.size(), [&](int is) {
     const Shared &sh = shared[is];
     const int S = sh.S;
+    if (sh.mr) {
+      const int A = sh.fac[0], B = sh.fac[1], C = sh.fac[2], P1 = (B * C) | 1;
+      auto w = [&](long long e) {
+        long double a = 2.0L * (long double)M_PIl * (long double)(e % S) / (long double)S;
+        return d2{(double)cosl(a), (double)-sinl(a)};
+      };
+      d2 *t1 = ptw.data() + sh.ptw_off[0], *t2 = ptw.data() + sh.ptw_off[1];
+      for (int k1 = 0; k1 < A; k1++) t1[k1] = w((long long)C * k1);
+      for (int q = 0; q < A * B; q++) t2[q] = w((long long)q);
+      for (int k = 0; k < S; k++) perm[sh.perm_off + k] = (uint16_t)((k % A) * P1 + ((k / A) % B) * C + k / (A * B));
+      return;
+    }
     if (sh.r16) {
       d2 *dst = ptw.data() + sh.ptw_off[0];
       for (int row = 0; row < 7; row++) {
@@ -665,6 +768,8 @@ static int build_fft_plans(Plan &P) {
     fc.lats.push_back(j);
     if (fc.gmem)
       fc.gm_elems = std::max(fc.gm_elems, (long long)pl.fbk * FFT_LDS_ELEMS(pl.S));
+    else if (fc.mr)
+      fc.lds = std::max(fc.lds, (size_t)pl.fbk * pl.fac[0] * ((pl.fac[1] * pl.fac[2]) | 1) * 2 * P.esz);
     else if (fc.r16)
       fc.lds = (size_t)fc.r16 * 272 * 8 + 240 * 2 * P.esz;
     else
@@ -672,8 +777,8 @@ static int build_fft_plans(Plan &P) {
   }
   if (getenv("EMI_DEBUG_FFT"))
     for (const FftClass &fc : P.fclass)
-      fprintf(stderr, "emi: FFT launch group: %zu latitudes, %d threads, %d fields per workgroup, hot %d, r16 %d, gmem %d, LDS %zu bytes\n", fc.lats.size(), fc.nthr,
-              fc.fbk, fc.hot, fc.r16, fc.gmem, fc.lds);
+      fprintf(stderr, "emi: FFT launch group: %zu latitudes, %d threads, %d fields per workgroup, hot %d, r16 %d, mr %d, gmem %d, LDS %zu bytes\n", fc.lats.size(), fc.nthr,
+              fc.fbk, fc.hot, fc.r16, fc.mr, fc.gmem, fc.lds);
   // exp(-2 pi i c k1 / 256), [k1 - 1][c]: the small twiddles of k_fft_*_r16
   std::vector<d2> tw256(15 * 16);
   for (int k1 = 1; k1 < 16; k1++)
@@ -1890,6 +1995,13 @@ static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, in
         else
           EMI_LAUNCH(emi_f32::k_fft_dir_gm, nblocks, nthr, 0, st, P.g, P.ftab, lc, d_flds, nfld, (float *)FB, ldf, nproma, (f2 *)P.d_fftscr, fc.gm_elems);
       }
+      continue;
+    }
+    if (fc.mr) {
+      if (inverse)
+        EMI_LAUNCH_P(P.esz, k_fft_inv_mr, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);
+      else
+        EMI_LAUNCH_P(P.esz, k_fft_dir_mr, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
       continue;
     }
     if (fc.r16) {
@@ -3418,3 +3530,13 @@ extern "C" int emi_dir_transad(int kresol, const emi_dirtrans_t *ap) {
   if (G.nprtrv > 1) return inv_trans_vsets(kresol, &a, true);
   return inv_trans_impl(kresol, &a, true);
 }
+
+#if defined(EMI_MR_STAMP) && !defined(EMI_CPU_EMU)
+// experiments only (-DEMI_MR_STAMP): read and clear the stage clocks of k_fft_dir_mr
+extern "C" int emi_debug_mr_stamps(unsigned long long *out) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(emi_mr_stamp), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(emi_mr_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -13,6 +13,11 @@
 #include "emi_rt.h"
 
 #include "emi_types.h"
+#include <type_traits>
+#include "emi_mr_tables.h"
+#if defined(EMI_MR_STAMP) && !defined(EMI_CPU_EMU)
+__device__ unsigned long long emi_mr_stamp[16];
+#endif
 
 // fp64 library (the _dp build of the reference) and fp32 library (_sp): same kernel source, the
 // matrix-core instruction and the accumulator row map differ

@@ -2089,6 +2089,8 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   }
 }
 
+#include "emi_mr_body.h"
+
 // ==========================================================================================
 // k_gridcopy: TRLTOG / TRGTOL between the V-sets (NPRTRV > 1; trltog_mod.F90:18-964, trgtol_mod.F90:18-968).  Fourier space
 // holds the fields of one V-set on the latitudes of a whole W-set band; grid space holds ALL fields on the sub-band of one

@@ -38,6 +38,9 @@
     __builtin_amdgcn_wave_barrier();                      \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
+// pointer known to address global memory (a pointer loaded from a descriptor is generic to the compiler: flat_load / flat_store, which
+// also count against lgkmcnt): EMI_GLOBAL_AS real2 *p = (EMI_GLOBAL_AS real2 *)q; access the members, not the struct
+#define EMI_GLOBAL_AS __attribute__((address_space(1)))
 #define EMI_LDS_DECL extern __shared__ __attribute__((aligned(16))) char emi_lds_raw[]
 // workgroup barrier that orders LDS accesses only: unlike __syncthreads() it does not wait for the wave's outstanding
 // global loads (vmcnt), so table loads issued ahead of an LDS exchange stay in flight across it
@@ -158,6 +161,7 @@ template <class V>
 inline void emi_buf_st(const EmiBuf &b, unsigned voff, unsigned soff, V v) {
   if ((size_t)voff + sizeof(V) <= b.bytes) memcpy((char *)b.p + voff + soff, &v, sizeof(V));
 }
+#define EMI_GLOBAL_AS
 #define EMI_LDS_DECL
 #define EMI_OPAQUE(x) ((void)0)
 #define EMI_PRIO_HI() ((void)0)

@@ -85,6 +85,7 @@ struct FftPlanDev {
   int ptw_off[14];  // per pass (DIT order): table [(t-1)*lenp + j] = exp(-2 pi i j t/(lenp*R))
   int fbk;  // fields per workgroup
   int lds_class;
+  int mr;   // 1: direct mixed-radix kernels k_fft_*_mr: fac = A, B, C (B, C may be 1), ptw_off[0 / 1] the twiddles after pass 1 / 2, perm = LDS position of coefficient k
   int r16;  // > 0: register-resident kernels k_fft_*_r16<r16>, S = 256 r16; ptw_off[0]: the 7 x 256 digit twiddles, bhat in [k2][16 k0 + k1] order
 };
 struct FftTabDev {
@@ -124,6 +125,10 @@ struct FftLaunchDev {
 // rows of TCo1279; R1 = 20: 21.2 against 15.8): their first / last butterflies hold 72 / 80 data registers of the 128 a wave
 // may use at four waves per SIMD, and 16 R1 threads make five-wave workgroups of which only three fit a CU.
 #define EMI_R16_LIST(X) X(8) X(10) X(12) X(16)
+// radices of the direct mixed-radix kernels k_fft_*_mr (emi_mr_body.h)
+#ifndef EMI_MR_RADICES
+#define EMI_MR_RADICES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(19) X(23)
+#endif
 
 // Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors[5], fields per
 // workgroup).  The factor lists are what emi::factorize_smooth yields for S and the field count what the

@@ -66,9 +66,10 @@ HOT_E = [254, 318, 382, 510, 574, 638, 766, 958, 1022, 1278]  # ... and the last
 
 
 @pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4), (HOT_C, 4), (HOT_D, 8), (HOT_E, 8)])
-def test_specialised_fft_kernels_match_oracle(et, half, precision):
+def test_specialised_fft_kernels_match_oracle(et, half, precision, monkeypatch):
     """k_fft_inv_hot / k_fft_dir_hot (work lengths 1280 ... 5120, the rows that carry TCo1279): a
     16-latitude grid whose rows select each of them, against the oracle."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     nuv, nsc = (1, 1) if half[0] > 1000 else (2, 7)  # short rows: 13 Fourier fields = ragged chunks of 2, 4 and 8
     e_inv, e_dir = run_case(et, Oracle, XP, 15, half + half[::-1], nuv, nsc, dict(scders=True), None, precision=precision)
     tol = TOL if precision == 8 else 2e-5
@@ -78,17 +79,43 @@ def test_specialised_fft_kernels_match_oracle(et, half, precision):
 R16_ROWS = [1540, 2044, 2052, 2556, 2564, 3068, 3076, 4092]  # first and last row length of the work lengths 256 R1, R1 = 8, 10, 12, 16
 
 
+# k_fft_*_mr (direct mixed radix): row lengths 2 A B C that exercise every radix of EMI_MR_RADICES, one-, two- and three-pass plans,
+# one and several fields per workgroup
+MR_SHORT = [20, 24, 28, 32, 34, 38, 44, 46, 52, 68, 92, 286, 646, 480]            # 10, 12, 14, 16, 17, 19, 2*11, 23, 2*13, 2*17, 2*23, 11*13, 17*19, 6*8*5
+MR_MID = [512, 1058, 1890, 1430, 1938, 2244, 1716, 1292]                          # 16*16, 23*23, 9*15*7, 10*11*13, 3*17*19, 6*11*17, 6*11*13, 2*17*19
+MR_LONG = [4004, 4096, 5060, 5120, 4522, 4394, 4800, 4862]                        # 14*11*13, 16*16*8, 10*11*23, 16*16*10, 7*17*19, 13^3, 16*15*10, 11*13*17
+
+
+@pytest.mark.parametrize("rows,precision,nproma", [(MR_SHORT, 8, None), (MR_MID, 8, None), (MR_LONG, 8, None), (MR_SHORT, 4, None), (MR_LONG, 4, None),
+                                                   (MR_SHORT, 8, 37), (MR_LONG, 8, 1000)])
+def test_direct_mixed_radix_fft_kernels_match_oracle(et, rows, precision, nproma):
+    """k_fft_dir_mr / k_fft_inv_mr against the oracle: winds, scalars and derivatives (13 Fourier fields for the short rows: ragged
+    field chunks), with and without NPROMA blocks that cut the rows."""
+    nuv, nsc = (1, 1) if rows[0] > 1000 else (2, 7)
+    e_inv, e_dir = run_case(et, Oracle, XP, 15, rows + rows[::-1], nuv, nsc, dict(scders=True, uvder=True), nproma, precision=precision)
+    tol = TOL if precision == 8 else 2e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+def test_direct_mixed_radix_fft_kernels_adjoints(et):
+    """the `adj` scalings of k_fft_*_mr: dot-product identity of INV_TRANSAD / DIR_TRANSAD"""
+    e_inv, e_dir = adjoint_case(et, XP, 15, MR_MID + MR_MID[::-1], 1, 1, nproma=3000)
+    assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
+
+
 @pytest.mark.parametrize("precision", [8, 4])
-def test_register_resident_fft_kernels_blocked_rows(et, precision):
+def test_register_resident_fft_kernels_blocked_rows(et, precision, monkeypatch):
     """k_fft_dir_r16 / k_fft_inv_r16 with NPROMA blocks that cut the rows (the element-wise grid path; the unblocked
     specialised-kernel cases above take the row-as-one-buffer path), winds and derivatives."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     e_inv, e_dir = run_case(et, Oracle, XP, 15, R16_ROWS + R16_ROWS[::-1], 1, 1, dict(scders=True, uvder=True), 1000, precision=precision)
     tol = TOL if precision == 8 else 2e-5
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
-def test_register_resident_fft_kernels_adjoints(et):
+def test_register_resident_fft_kernels_adjoints(et, monkeypatch):
     """the `adj` scalings of the register-resident kernels: dot-product identity of INV_TRANSAD / DIR_TRANSAD"""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     e_inv, e_dir = adjoint_case(et, XP, 15, R16_ROWS + R16_ROWS[::-1], 1, 1, nproma=3000)
     assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
 
@@ -96,13 +123,14 @@ def test_register_resident_fft_kernels_adjoints(et):
 def test_unmerged_radix_fft_kernels_match_oracle(et, monkeypatch):
     """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists 8*8*8*2*3 ... (the default merges the last two
     factors into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     monkeypatch.setenv("EMI_FFT_MERGE", "0")
     half = [2564, 3068, 4100, 4604, 4612, 5116, 2052, 4092]
     e_inv, e_dir = run_case(et, Oracle, XP, 15, half + half[::-1], 1, 1, dict(scders=True), None)
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
-@pytest.mark.parametrize("env", [("EMI_NO_FUSE_DIR", "1"), ("EMI_FB_TABLE", "1"), ("EMI_FB_ORDER", "m"), ("EMI_FFT_NO_HOT", "1")])
+@pytest.mark.parametrize("env", [("EMI_NO_FUSE_DIR", "1"), ("EMI_FB_TABLE", "1"), ("EMI_FB_ORDER", "m"), ("EMI_FFT_NO_HOT", "1"), ("EMI_FFT_MR", "0")])
 def test_ab_switches_keep_parity(et, monkeypatch, env):
     """The environment switches kept for A/B measurements select code that must stay correct: every field through
     W and k_postpack_dir; Fourier rows through the row table on one task; wavenumber-major Fourier rows; the

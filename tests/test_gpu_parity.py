@@ -118,9 +118,10 @@ HOT_E = [254, 318, 382, 510, 574, 638, 766, 958, 1022, 1278]  # ... and the last
 
 @pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4), (HOT_B, 4), (HOT_C, 4), (HOT_C, 8), (HOT_D, 8), (HOT_E, 8),
                                             (HOT_D, 4)])
-def test_specialised_fft_kernels_match_oracle(et, dev, half, precision):
+def test_specialised_fft_kernels_match_oracle(et, dev, half, precision, monkeypatch):
     """k_fft_inv_hot / k_fft_dir_hot (the Bluestein work lengths 1280 ... 5120 that carry TCo1279): a
     16-latitude grid whose rows select each of them, against the oracle."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     from oracle.oracle import Oracle as O
     nsc = 3 if half[0] > 1000 else 9  # short rows: 13 Fourier fields + derivatives = ragged chunks of 2, 4 and 8 fields
     e_inv, e_dir = run_case(et, O, dev, 15, half + half[::-1], 2, nsc, dict(scders=True, uvder=True), None, precision=precision)
@@ -131,6 +132,7 @@ def test_specialised_fft_kernels_match_oracle(et, dev, half, precision):
 def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
     """The specialised kernels run the same passes in the same order; only the compiler's fma
     contraction may differ: agreement to a few ulp."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     to, back = dev
     nloen = np.array(HOT_A + HOT_A[::-1], dtype=np.int32)
     rng = np.random.default_rng(5)
@@ -152,14 +154,69 @@ def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
     assert not np.array_equal(outs[0][0], np.zeros_like(outs[0][0]))
 
 
+# k_fft_*_mr (direct mixed radix, round 3): row lengths 2 A B C that exercise every radix of EMI_MR_RADICES, one-, two- and three-pass
+# plans, one and several fields per workgroup
+MR_SHORT = [20, 24, 28, 32, 34, 38, 44, 46, 52, 68, 92, 286, 646, 480]            # 10, 12, 14, 16, 17, 19, 2*11, 23, 2*13, 2*17, 2*23, 11*13, 17*19, 6*8*5
+MR_MID = [512, 1058, 1890, 1430, 1938, 2244, 1716, 1292]                          # 16*16, 23*23, 9*15*7, 10*11*13, 3*17*19, 6*11*17, 6*11*13, 2*17*19
+MR_LONG = [4004, 4096, 5060, 5120, 4522, 4394, 4800, 4862]                        # 14*11*13, 16*16*8, 10*11*23, 16*16*10, 7*17*19, 13^3, 16*15*10, 11*13*17
+
+
+@pytest.mark.parametrize("rows,precision,nproma", [(MR_SHORT, 8, None), (MR_MID, 8, None), (MR_LONG, 8, None), (MR_SHORT, 4, None), (MR_MID, 4, None),
+                                                   (MR_LONG, 4, None), (MR_SHORT, 8, 37), (MR_MID, 8, 1000), (MR_LONG, 8, 4094), (MR_LONG, 4, 1000)])
+def test_direct_mixed_radix_fft_kernels_match_oracle(et, dev, rows, precision, nproma):
+    """k_fft_dir_mr / k_fft_inv_mr (rows whose half-length is a product of at most three radices from 2..16, 17, 19, 23: butterflies
+    in registers, no chirp-z convolution) against the oracle: winds, scalars and all derivatives (ragged field chunks for the
+    short rows), both precisions, rows inside one NPROMA block (grid rows read and written by the first / last pass) and
+    rows cut by NPROMA blocks (copied through the LDS)."""
+    from oracle.oracle import Oracle as O
+    nsc = 3 if rows[0] > 1000 else 9
+    e_inv, e_dir = run_case(et, O, dev, 15, rows + rows[::-1], 2, nsc, dict(scders=True, uvder=True, vorgp=True, divgp=True), nproma, precision=precision)
+    tol = TOL if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+def test_direct_mixed_radix_and_convolution_fft_kernels_agree(et, dev, monkeypatch):
+    """EMI_FFT_MR=0 sends the same rows through the chirp-z kernels (or, the short 7-smooth ones, the generic mixed-radix
+    kernels): both are the same transform to rounding, and really two different kernels."""
+    to, back = dev
+    rows = MR_SHORT[-3:] + MR_MID[:5] + MR_LONG
+    nloen = np.array(rows + rows[::-1], dtype=np.int32)
+    rng = np.random.default_rng(5)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("EMI_FFT_MR", "0")
+        r = et.setup_trans(15, len(nloen), nloen)
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        if not outs:
+            sp = random_spectrum(rng, et.trans_inq(r, "nasm0"), 15, ns2, 3, False)
+        gp = to(np.zeros((1, 3, ng)))
+        et.inv_trans(r, pspscalar=to(sp), pgp=gp)
+        s2 = to(np.zeros((ns2, 3)))
+        et.dir_trans(r, pspscalar=s2, pgp=gp)
+        outs.append((back(gp).copy(), back(s2).copy()))
+        et.trans_release(r)
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-13 and rel_err(outs[0][1], outs[1][1]) < 1e-13
+    assert not np.array_equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("precision", [8, 4])
+def test_direct_mixed_radix_fft_kernels_adjoints(et, dev, precision):
+    """INV_TRANSAD / DIR_TRANSAD on rows that take k_fft_*_mr (their `adj` scalings): the reference's dot-product identity"""
+    e_inv, e_dir = adjoint_case(et, dev, 15, MR_MID + MR_MID[::-1], 1, 2, nproma=3000, precision=precision)
+    tol = 1e-12 if precision == 8 else 2e-4
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
 R16_ROWS = [1540, 2044, 2052, 2556, 2564, 3068, 3076, 4092]  # first and last row length of the work lengths 256 R1, R1 = 8, 10, 12, 16
 
 
 @pytest.mark.parametrize("precision,nproma", [(8, 1000), (4, 1000), (8, 4094)])
-def test_register_resident_fft_kernels_blocked_rows(et, dev, precision, nproma):
+def test_register_resident_fft_kernels_blocked_rows(et, dev, precision, nproma, monkeypatch):
     """k_fft_dir_r16 / k_fft_inv_r16 (round 3: rows whose Bluestein work length is 256 R1, points in registers, LDS as the
     exchange medium) with NPROMA blocks that cut the rows: the element-wise grid path instead of the row-as-one-buffer
     path the unblocked cases take; winds, derivatives and both precisions."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     from oracle.oracle import Oracle as O
     e_inv, e_dir = run_case(et, O, dev, 15, R16_ROWS + R16_ROWS[::-1], 2, 3, dict(scders=True, uvder=True, vorgp=True, divgp=True), nproma, precision=precision)
     tol = TOL if precision == 8 else 3e-5
@@ -169,6 +226,7 @@ def test_register_resident_fft_kernels_blocked_rows(et, dev, precision, nproma):
 def test_register_resident_and_lds_fft_kernels_agree(et, dev, monkeypatch):
     """EMI_FFT_R16=0 sends the same rows through the in-place LDS kernels (other work lengths for some of them, another
     factorisation for all): both are the same transform to rounding."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     to, back = dev
     nloen = np.array(R16_ROWS + R16_ROWS[::-1], dtype=np.int32)
     rng = np.random.default_rng(5)
@@ -191,9 +249,10 @@ def test_register_resident_and_lds_fft_kernels_agree(et, dev, monkeypatch):
 
 
 @pytest.mark.parametrize("precision", [8, 4])
-def test_register_resident_fft_kernels_adjoints(et, dev, precision):
+def test_register_resident_fft_kernels_adjoints(et, dev, precision, monkeypatch):
     """INV_TRANSAD / DIR_TRANSAD on rows that take the register-resident kernels (their `adj` scalings): the reference's
     dot-product identity (tests/trans/test_invtrans_adjoint.F90: 2000 epsilon)."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     e_inv, e_dir = adjoint_case(et, dev, 15, R16_ROWS + R16_ROWS[::-1], 1, 2, nproma=3000, precision=precision)
     tol = 1e-12 if precision == 8 else 2e-4
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
@@ -202,6 +261,7 @@ def test_register_resident_fft_kernels_adjoints(et, dev, precision):
 def test_unmerged_radix_fft_kernels_match_oracle(et, dev, monkeypatch):
     """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists (the default merges the last two factors
     into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     from oracle.oracle import Oracle as O
     monkeypatch.setenv("EMI_FFT_MERGE", "0")
     half = [2564, 3068, 4100, 4604, 4612, 5116, 2052, 4092]
