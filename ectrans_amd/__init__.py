@@ -121,6 +121,7 @@ def _bind(L):
     L.emi_dir_transad.argtypes = [C.c_int, C.POINTER(_Dir)]
     L.emi_release.argtypes = [C.c_int]
     L.emi_finalize.argtypes = []
+    L.emi_trim_cache.argtypes = []
     L.emi_last_error.restype = C.c_char_p
     L.emi_work_model.argtypes = [C.c_int, C.c_int, dp, dp, dp]
     L.emi_last_phase_ms.argtypes = [dp]
@@ -593,6 +594,11 @@ def dist_grid(kresol, pgpg, kfdistg, kfrom=1, kproma=None):
 
 def trans_release(kresol):
     _chk(lib().emi_release(kresol))
+
+
+def trim_cache():
+    """Frees the idle device staging buffers of host-array calls (emi_trim_cache); TRANS_RELEASE and TRANS_END do it too."""
+    _chk(lib().emi_trim_cache())
 
 
 def trans_end():

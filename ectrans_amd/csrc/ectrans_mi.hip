@@ -1484,6 +1484,16 @@ extern "C" int emi_release(int kresol) {
   P->active = false;
   delete P;
   G.plans[kresol - 1] = nullptr;
+  emi_stage::trim();  // the idle staging buffers of host-array calls were sized for this resolution
+  return EMI_SUCCESS;
+}
+
+// Frees the idle device staging buffers kept between host-array calls (several GiB after a large call; other allocators of
+// the process -- torch, the host model -- cannot see or reclaim them).  Waits for the work queued on the null stream first:
+// a buffer is idle once its call has returned, but that call's last copies may still be in flight.
+extern "C" int emi_trim_cache(void) {
+  emi_stream_sync(0);
+  emi_stage::trim();
   return EMI_SUCCESS;
 }
 
@@ -3048,7 +3058,7 @@ static int dist_impl(int kresol, const void *glob, int nfld, const int *kfrom, c
   return EMI_SUCCESS;
 }
 
-// every task's share -> global fields on their target tasks.  One all-gather-v of the packed local fields.
+// every task's share -> global fields on their target tasks.  An all-gather-v of the packed local fields per chunk of fields.
 template <bool SPEC>
 static int gath_impl(int kresol, void *glob, int nfld, const int *kto, int kproma, const void *loc, const char *who) {
   Plan *Pp = get_plan(kresol);
@@ -3061,50 +3071,60 @@ static int gath_impl(int kresol, void *glob, int nfld, const int *kto, int kprom
   const int NP = P.nproc, nproma = kproma > 0 ? kproma : P.ngptot;
   const long long nglob = SPEC ? (long long)P.nspec2g : (long long)P.ngptotg;
   auto nloc = [&](int t) { return SPEC ? L.nspec2[t] : L.ngp[t]; };
-  // pack [field][local element]
-  std::vector<char> mine((size_t)nfld * nloc(P.me) * esz);
-  for (int f = 0; f < nfld; f++) {
-    char *dst = mine.data() + (size_t)f * nloc(P.me) * esz;
-    if (SPEC) {
-      for (long long e = 0; e < nloc(P.me); e++) memcpy(dst + (size_t)e * esz, (const char *)loc + ((size_t)e * nfld + f) * esz, esz);
-    } else {
-      for (long long p0 = 0; p0 < nloc(P.me); p0 += nproma) {
-        const long long w = std::min<long long>(nproma, nloc(P.me) - p0), blk = p0 / nproma;
-        memcpy(dst + (size_t)p0 * esz, (const char *)loc + ((size_t)(blk * nfld + f) * nproma) * esz, (size_t)w * esz);
+  // Fields in chunks whose gathered image stays below 256 MiB: every task receives every field of a chunk whatever KTO says (the
+  // host collectives offer an all-gather-v only), so an unchunked GATH_GRID of 137 levels at TCo1279 would put 7 GB on every task.
+  const long long per_field = nglob * (long long)esz;
+  const long long budget = (getenv("EMI_GATH_CHUNK") && *getenv("EMI_GATH_CHUNK")) ? atoll(getenv("EMI_GATH_CHUNK")) : (256LL << 20);  // bytes (tests: a few fields per chunk)
+  const int chunk = (int)std::max<long long>(1, std::min<long long>(nfld, budget / std::max<long long>(per_field, 1)));
+  long long i_mine = 0;
+  std::vector<char> mine, all;
+  std::vector<long long> cnt(NP), dsp(NP);
+  for (int fa = 0; fa < nfld; fa += chunk) {
+    const int nf = std::min(chunk, nfld - fa);
+    // pack [field][local element]
+    mine.resize((size_t)nf * nloc(P.me) * esz);
+    for (int fc = 0; fc < nf; fc++) {
+      const int f = fa + fc;
+      char *dst = mine.data() + (size_t)fc * nloc(P.me) * esz;
+      if (SPEC) {
+        for (long long e = 0; e < nloc(P.me); e++) memcpy(dst + (size_t)e * esz, (const char *)loc + ((size_t)e * nfld + f) * esz, esz);
+      } else {
+        for (long long p0 = 0; p0 < nloc(P.me); p0 += nproma) {
+          const long long w = std::min<long long>(nproma, nloc(P.me) - p0), blk = p0 / nproma;
+          memcpy(dst + (size_t)p0 * esz, (const char *)loc + ((size_t)(blk * nfld + f) * nproma) * esz, (size_t)w * esz);
+        }
       }
     }
-  }
-  std::vector<char> all;
-  std::vector<long long> cnt(NP), dsp(NP);
-  const char *base = mine.data();
-  if (NP > 1) {
-    long long tot = 0;
-    for (int t = 0; t < NP; t++) {
-      cnt[t] = (long long)nfld * nloc(t) * (long long)esz;
-      dsp[t] = tot;
-      tot += cnt[t];
+    const char *base = mine.data();
+    if (NP > 1) {
+      long long tot = 0;
+      for (int t = 0; t < NP; t++) {
+        cnt[t] = (long long)nf * nloc(t) * (long long)esz;
+        dsp[t] = tot;
+        tot += cnt[t];
+      }
+      all.resize((size_t)tot);
+      if (G.hc_gather(G.hc_user, mine.data(), cnt[P.me], all.data(), cnt.data(), dsp.data(), NP)) EMI_FAIL(EMI_ERR_RUNTIME, "%s: all-gather-v failed", who);
+      base = all.data();
+    } else {
+      dsp[0] = 0;
     }
-    all.resize((size_t)tot);
-    if (G.hc_gather(G.hc_user, mine.data(), cnt[P.me], all.data(), cnt.data(), dsp.data(), NP)) EMI_FAIL(EMI_ERR_RUNTIME, "%s: all-gather-v failed", who);
-    base = all.data();
-  } else {
-    dsp[0] = 0;
-  }
-  long long i_mine = 0;
-  for (int f = 0; f < nfld; f++) {
-    if (kto[f] != P.me + 1) continue;
-    if (!glob) EMI_FAIL(EMI_ERR_ARG, "%s: this task is the target of field %d but passes no global array", who, f + 1);
-    char *g = (char *)glob + (size_t)i_mine * nglob * esz;
-    i_mine++;
-    for (int t = 0; t < NP; t++) {
-      const char *src = base + dsp[t] + (size_t)f * nloc(t) * esz;
-      if (SPEC) {
-        for (size_t k = 0; k < L.ms[t].size(); k++) {
-          const long long cnte = 2LL * (P.nsmax - L.ms[t][k] + 1);
-          memcpy(g + (size_t)L.iasm0g[L.ms[t][k]] * esz, src + (size_t)L.start[t][k] * esz, (size_t)cnte * esz);
+    for (int fc = 0; fc < nf; fc++) {
+      const int f = fa + fc;
+      if (kto[f] != P.me + 1) continue;
+      if (!glob) EMI_FAIL(EMI_ERR_ARG, "%s: this task is the target of field %d but passes no global array", who, f + 1);
+      char *g = (char *)glob + (size_t)i_mine * nglob * esz;
+      i_mine++;
+      for (int t = 0; t < NP; t++) {
+        const char *src = base + dsp[t] + (size_t)fc * nloc(t) * esz;
+        if (SPEC) {
+          for (size_t k = 0; k < L.ms[t].size(); k++) {
+            const long long cnte = 2LL * (P.nsmax - L.ms[t][k] + 1);
+            memcpy(g + (size_t)L.iasm0g[L.ms[t][k]] * esz, src + (size_t)L.start[t][k] * esz, (size_t)cnte * esz);
+          }
+        } else {
+          memcpy(g + (size_t)L.gp0[t] * esz, src, (size_t)L.ngp[t] * esz);
         }
-      } else {
-        memcpy(g + (size_t)L.gp0[t] * esz, src, (size_t)L.ngp[t] * esz);
       }
     }
   }

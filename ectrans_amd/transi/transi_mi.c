@@ -382,7 +382,14 @@ int trans_distgrid(struct DistGrid_t *a) {
   if (!a->trans || !a->rgp || !a->nfrom || a->nfld <= 0 || a->nproma <= 0) return TRANS_MISSING_ARG;
   const long ng = a->trans->ngptot, np = a->nproma, nb = (ng - 1) / np + 1;
   if (a->ngpblks < nb) return TRANS_ERROR;
-  return emi_dist_grid(a->trans->handle, a->rgpg, a->nfld, a->nfrom, NULL, a->nproma, a->rgp) ? TRANS_ERROR : TRANS_SUCCESS;
+  if (emi_dist_grid(a->trans->handle, a->rgpg, a->nfld, a->nfrom, NULL, a->nproma, a->rgp)) return TRANS_ERROR;
+  /* the padding of the last NPROMA block (and any further block): zero, as the Fortran DIST_GRID of the shim leaves it -- a
+   * malloc'ed rgp must not carry NaNs into a later trans_dirtrans or a checksum */
+  for (long b = nb - 1; b < a->ngpblks; b++) {
+    const long first = b == nb - 1 ? ng - (nb - 1) * np : 0;
+    for (int f = 0; f < a->nfld; f++) memset(a->rgp + ((size_t)b * a->nfld + f) * np + first, 0, sizeof(double) * (size_t)(np - first));
+  }
+  return TRANS_SUCCESS;
 }
 int trans_gathgrid(struct GathGrid_t *a) {
   if (a->count++ > 0) return TRANS_STALE_ARG;

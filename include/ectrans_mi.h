@@ -253,6 +253,9 @@ int emi_inq_init(int *kmax_resol, double *prad);
 /* ---- TRANS_RELEASE / TRANS_END (trans/cpu/external/trans_release.F90, trans_end.F90) -- */
 int emi_release(int kresol);
 int emi_finalize(void);
+/* Frees the idle device staging buffers that host-array calls (mem_space = EMI_MEM_HOST) keep between calls; also done by
+ * emi_release and emi_finalize.  EMI_STAGE_POOL=0 in the environment keeps no buffers at all.                          */
+int emi_trim_cache(void);
 
 const char *emi_last_error(void);
 

@@ -17,7 +17,8 @@ def test_wset_sharding_with_alltoallv(world, order):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1024", EMI_TEST_NSMAX="9", EMI_FB_ORDER=order)
+                   OMP_NUM_THREADS="1024", EMI_TEST_NSMAX="9", EMI_FB_ORDER=order,
+                   EMI_GATH_CHUNK="1000" if world == 3 else "")  # world 3: GATH_* in chunks of one or two fields (the bounded-memory path)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
