@@ -127,6 +127,10 @@ def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=6
     import scipy.fft
     import torch
     from concurrent.futures import ThreadPoolExecutor
+    # 32 threads at most: with one MKL thread per core of the 256-core GPU box the ~5000 panel products of a pair took 0.25 s EACH
+    # (161 s for 640 of them at TCo639; 0.09 s with 32 threads -- tools/blas_diag.py), and 8-16 pool workers are the best the
+    # GIL-bound row loop of the Fourier transforms gets; `cores` of the record = the threads really used
+    cores = min(cores, 32)
     torch.set_num_threads(cores)
     nloen = octahedral(nsmax)
     ndgl, H = len(nloen), len(nloen) // 2
@@ -143,7 +147,7 @@ def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=6
         # [k][lat], n = m + 2 k (+ 1); the panels also hold the row n = N + 1 the wind stencils use: dropped here (scalars only)
         Ps.append(torch.from_numpy(ps[::-1][:(nsmax - m) // 2 + 1].copy()))
         Pa.append(torch.from_numpy(pa[::-1][:(nsmax - m + 1) // 2].copy()))
-    pool = ThreadPoolExecutor(max_workers=min(cores, 64))
+    pool = ThreadPoolExecutor(max_workers=min(cores, 16))
 
     def coeffs(spec, m):
         i0 = nasm0[m] - 1
@@ -201,6 +205,14 @@ def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=6
                 z[:, 1] = 0.0
         return spec
 
+    # guard: the leg must stay a bounded sample whatever the host's BLAS threading does -- a probe of 32 panel products first
+    t = time.time()
+    for m in range(0, nsmax + 1, max(1, (nsmax + 1) // 32)):
+        _ = Ps[m].T @ coeffs(sc, m)[0]
+    t_probe = time.time() - t
+    if t_probe * (2 * (nsmax + 1) / 32.0) * 2 > 120.0:
+        pool.shutdown()
+        return {"error": "skipped: 32 panel products took %.1f s with %d BLAS threads on this host" % (t_probe, cores)}
     t = time.time()
     g = inverse(sc)
     s2 = direct(g)
