@@ -65,7 +65,7 @@ HOT_D = [194, 258, 322, 386, 514, 578, 642, 770, 962, 1026]  # short rows, 2 ...
 HOT_E = [254, 318, 382, 510, 574, 638, 766, 958, 1022, 1278]  # ... and the last row length of each
 
 
-@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_A, 4), (HOT_C, 4), (HOT_D, 8), (HOT_E, 8)])
+@pytest.mark.parametrize("half,precision", [(HOT_A, 8), (HOT_B, 8), (HOT_C, 4), (HOT_D, 8)])  # (HOT_A, 4), (HOT_E, 8): GPU tier only
 def test_specialised_fft_kernels_match_oracle(et, half, precision, monkeypatch):
     """k_fft_inv_hot / k_fft_dir_hot (work lengths 1280 ... 5120, the rows that carry TCo1279): a
     16-latitude grid whose rows select each of them, against the oracle."""
@@ -86,8 +86,7 @@ MR_MID = [512, 1058, 1890, 1430, 1938, 2244, 1716, 1292]                        
 MR_LONG = [4004, 4096, 5060, 5120, 4522, 4394, 4800, 4862]                        # 14*11*13, 16*16*8, 10*11*23, 16*16*10, 7*17*19, 13^3, 16*15*10, 11*13*17
 
 
-@pytest.mark.parametrize("rows,precision,nproma", [(MR_SHORT, 8, None), (MR_MID, 8, None), (MR_LONG, 8, None), (MR_SHORT, 4, None), (MR_LONG, 4, None),
-                                                   (MR_SHORT, 8, 37), (MR_LONG, 8, 1000)])
+@pytest.mark.parametrize("rows,precision,nproma", [(MR_SHORT, 8, None), (MR_MID, 8, None), (MR_LONG, 8, None), (MR_LONG, 4, None), (MR_SHORT, 8, 37)])
 def test_direct_mixed_radix_fft_kernels_match_oracle(et, rows, precision, nproma):
     """k_fft_dir_mr / k_fft_inv_mr against the oracle: winds, scalars and derivatives (13 Fourier fields for the short rows: ragged
     field chunks), with and without NPROMA blocks that cut the rows."""
