@@ -377,6 +377,36 @@ def main():
         if transport != "rccl":
             raise
         ok, transport_note = 0, str(e)
+    preflight = None
+    if (transport == "rccl" or os.environ.get("EMI_BENCH_PREFLIGHT")) and ok and world > 1:
+        # pre-flight of the native exchange (its grouped ncclSend / ncclRecv have only ever run inside one-GPU tests): a T63 pair
+        # of the benchmark harmonic on two fields; an exception or a wrong norm sends every rank to the torch.distributed callback
+        try:
+            n_ = 63
+            rr = et.setup_trans(n_, 2 * (n_ + 1), octahedral(n_), precision=args.precision)
+            ns_, ng_ = et.trans_inq(rr, "nspec2"), et.trans_inq(rr, "ngptot")
+            a4_ = int(et.trans_inq(rr, "nasm0")[4])
+            dt_ = torch.float64 if args.precision == 8 else torch.float32
+            sp_ = torch.zeros((ns_, 2), dtype=dt_, device=dev)
+            if a4_ > 0:
+                sp_[a4_ - 1 + 2 * (19 - 4)] = 1.0
+            gp_ = torch.zeros((1, 2, ng_), dtype=dt_, device=dev)
+            kw_ = {"kvsetsc": [1, 1]} if nprtrv > 1 else {}
+            if nprtrv > 1 and mysetv != 1:
+                sp_ = sp_[:, :0]
+            na_ = et.specnorm(rr, sp_, **({"kvset": [1, 1]} if nprtrv > 1 else {}))[0]
+            et.inv_trans(rr, pspscalar=sp_ if sp_.shape[1] else None, pgp=gp_, **kw_)
+            et.dir_trans(rr, pspscalar=sp_ if sp_.shape[1] else None, pgp=gp_, **kw_)
+            torch.cuda.synchronize()
+            nb_ = et.specnorm(rr, sp_, **({"kvset": [1, 1]} if nprtrv > 1 else {}))[0]
+            et.trans_release(rr)
+            preflight = "ok"
+            if not (na_ > 0 and abs(nb_ / na_ - 1.0) < (1e-10 if args.precision == 8 else 1e-4)):
+                ok, transport_note = 0, "exchange pre-flight: norm %r -> %r" % (na_, nb_)
+                preflight = transport_note
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the other transport is the answer
+            ok, transport_note = 0, "exchange pre-flight: %r" % (e,)
+            preflight = transport_note
     if transport == "rccl":
         if world > 1:  # every rank must take the same path: fall back together if the native attach failed anywhere
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
@@ -385,7 +415,7 @@ def main():
         else:
             all_ok = ok
         if not all_ok:
-            if ok:
+            if et.lib().emi_inq_tasks(None, None) == 0:  # the library is attached on this rank: detach before the other transport
                 et.trans_end()
                 from ectrans_amd import dist as _ed
                 _ed.rccl_native_lib().emi_rccl_detach()
@@ -505,7 +535,7 @@ def main():
                        "nprtrw": nprtrw, "nprtrv": nprtrv,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": None if world == 1 else ("rccl-native" if transport == "rccl" else backend),
-                       "transport_note": transport_note, "pipeline_batches": int(os.environ.get("EMI_PIPELINE_DIST", "4")) if world > 1 else 1,
+                       "transport_note": transport_note, "exchange_preflight": preflight, "pipeline_batches": int(os.environ.get("EMI_PIPELINE_DIST", "4")) if world > 1 else 1,
                        "setup_s": round(t_setup, 2)},
             # the reference reports 1 / median step time (ectrans-benchmark.F90:906-943); `value` is steps / wall time
             "pairs_per_s_median": 1e3 / med_ms, "ms_per_step_median": med_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],

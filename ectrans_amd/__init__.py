@@ -222,7 +222,7 @@ def setup_trans0(kmax_resol=1, kprintlev=0, prad=None, device=-1, kprtrw=1, mypr
     if nproc_all > 1:
         from . import dist as _dist
         dev = ("cuda:%d" % device) if device is not None and device >= 0 else "cpu"
-        hook = alltoallv if alltoallv is not None else _dist.make_alltoallv_hook(group, dev)
+        hook = alltoallv if alltoallv is not None else _dist.make_alltoallv_hook(group, dev, p2p=kprtrv > 1)
         _chk(lib().emi_set_alltoallv(C.cast(hook, C.c_void_p), None))
         bc, ag = _dist.make_host_collectives(group, dev)  # DIST_x / GATH_x, SPECNORM over several tasks
         _chk(lib().emi_set_host_collectives(C.cast(bc, C.c_void_p), C.cast(ag, C.c_void_p), None))

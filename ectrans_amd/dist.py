@@ -40,7 +40,7 @@ def _as_tensor(ptr, nbytes, device):
     return torch.from_numpy(arr)
 
 
-def make_alltoallv_hook(group=None, device=None):
+def make_alltoallv_hook(group=None, device=None, p2p=False):
     """C callback implementing emi_alltoallv_fn with torch.distributed.all_to_all_single.
 
     The collective is queued behind the transform kernels already on the current torch stream and the
@@ -50,6 +50,30 @@ def make_alltoallv_hook(group=None, device=None):
     device = torch.device(device) if device is not None else torch.device("cpu")
 
     staged = device.type == "cuda" and dist.get_backend(group) == "gloo"
+
+    def exchange(recv, send, osz, isz):
+        """all_to_all_single over the whole group -- or, with V-sets, point-to-point transfers between the tasks that really
+        exchange a block: TRMTOL / TRLTOM run inside a V-set, TRLTOG / TRGTOL inside a W-set, and two V-sets need not make the
+        same number of calls (fields per V-set differ, a V-set may hold none), which a collective over all tasks cannot take"""
+        if not p2p:
+            dist.all_to_all_single(recv, send, output_split_sizes=osz, input_split_sizes=isz, group=group)
+            return
+        me = dist.get_rank(group)
+        ro, so = np.concatenate([[0], np.cumsum(osz)]), np.concatenate([[0], np.cumsum(isz)])
+        if isz[me]:
+            recv[ro[me]:ro[me + 1]].copy_(send[so[me]:so[me + 1]])
+        ops = []
+        for r in range(len(isz)):
+            if r == me:
+                continue
+            peer = r if group is None else dist.get_global_rank(group, r)
+            if osz[r]:
+                ops.append(dist.P2POp(dist.irecv, recv[ro[r]:ro[r + 1]], peer, group))
+            if isz[r]:
+                ops.append(dist.P2POp(dist.isend, send[so[r]:so[r + 1]], peer, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
 
     def hook(user, sb, sc, sd, rb, rc, rd, nproc, stream):
         try:
@@ -70,7 +94,7 @@ def make_alltoallv_hook(group=None, device=None):
                 with torch.cuda.stream(es):
                     hs = send.cpu()
                 hr = torch.empty(recv.shape, dtype=recv.dtype)
-                dist.all_to_all_single(hr, hs, output_split_sizes=osz, input_split_sizes=isz, group=group)
+                exchange(hr, hs, osz, isz)
                 with torch.cuda.stream(es):
                     recv.copy_(hr)
                 es.synchronize()
@@ -78,9 +102,9 @@ def make_alltoallv_hook(group=None, device=None):
                 # the transform runs on a caller-supplied HIP stream: make it torch's current stream so
                 # that the collective is ordered behind the kernels queued on it and ahead of the next ones
                 with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device)):
-                    dist.all_to_all_single(recv, send, output_split_sizes=osz, input_split_sizes=isz, group=group)
+                    exchange(recv, send, osz, isz)
             else:
-                dist.all_to_all_single(recv, send, output_split_sizes=osz, input_split_sizes=isz, group=group)
+                exchange(recv, send, osz, isz)
             return 0
         except Exception:  # never let an exception cross the C boundary
             traceback.print_exc(file=sys.stderr)

@@ -45,17 +45,51 @@ static int hook(void *user, const void *sendbuf, const long long *sc, const long
   MPI_Datatype t16;
   MPI_Type_contiguous(16, MPI_BYTE, &t16);
   MPI_Type_commit(&t16);
+  /* With V-sets the exchanges run inside a V-set (TRMTOL / TRLTOM) or inside a W-set (TRLTOG / TRGTOL), and two V-sets need not make
+   * the same number of calls (their field counts differ, one may hold none): a collective over all tasks cannot take that, so
+   * the blocks travel point to point between the tasks that really exchange one */
+  int nprtrv = 1;
+  (void)emi_inq_vsets(NULL, &nprtrv, NULL, NULL);
+#define EMI_MPI_EXCHANGE(sb_, rb_)                                                                                          \
+  do {                                                                                                                      \
+    if (nprtrv <= 1) {                                                                                                      \
+      if (MPI_Alltoallv(sb_, isc, isd, t16, rb_, irc, ird, t16, g_comm) != MPI_SUCCESS) rcode = -1;                         \
+    } else {                                                                                                                \
+      int me_ = 0, nreq_ = 0;                                                                                               \
+      MPI_Comm_rank(g_comm, &me_);                                                                                          \
+      MPI_Request *rq_ = malloc(sizeof(MPI_Request) * 2 * (size_t)nproc);                                                   \
+      for (int r = 0; r < nproc; r++)                                                                                       \
+        if (r != me_ && irc[r] > 0 && MPI_Irecv((char *)(rb_) + rd[r], irc[r], t16, r, 77, g_comm, &rq_[nreq_++]) != MPI_SUCCESS) rcode = -1; \
+      for (int r = 0; r < nproc; r++)                                                                                       \
+        if (r != me_ && isc[r] > 0 && MPI_Isend((const char *)(sb_) + sd[r], isc[r], t16, r, 77, g_comm, &rq_[nreq_++]) != MPI_SUCCESS) rcode = -1; \
+      if (isc[me_] > 0) memcpy_own = 1;                                                                                     \
+      if (MPI_Waitall(nreq_, rq_, MPI_STATUSES_IGNORE) != MPI_SUCCESS) rcode = -1;                                          \
+      free(rq_);                                                                                                            \
+    }                                                                                                                       \
+  } while (0)
+  int memcpy_own = 0;
 #ifdef EMI_MPI_GPU_AWARE
   if (hipStreamSynchronize(st) != hipSuccess) rcode = -1; /* producer kernels done; MPI reads the device blocks */
-  if (!rcode && MPI_Alltoallv(sendbuf, isc, isd, t16, recvbuf, irc, ird, t16, g_comm) != MPI_SUCCESS) rcode = -1;
+  if (!rcode) EMI_MPI_EXCHANGE(sendbuf, recvbuf);
+  if (!rcode && memcpy_own) {
+    int me = 0;
+    MPI_Comm_rank(g_comm, &me);
+    if (hipMemcpy((char *)recvbuf + rd[me], (const char *)sendbuf + sd[me], (size_t)sc[me], hipMemcpyDeviceToDevice) != hipSuccess) rcode = -1;
+  }
 #else
   if (grow_pinned(&g_hs, &g_cap_s, (size_t)stot) || grow_pinned(&g_hr, &g_cap_r, (size_t)rtot)) rcode = -1;
   if (!rcode && stot && hipMemcpyAsync(g_hs, sendbuf, (size_t)stot, hipMemcpyDeviceToHost, st) != hipSuccess) rcode = -1;
   if (!rcode && hipStreamSynchronize(st) != hipSuccess) rcode = -1;
-  if (!rcode && MPI_Alltoallv(g_hs, isc, isd, t16, g_hr, irc, ird, t16, g_comm) != MPI_SUCCESS) rcode = -1;
+  if (!rcode) EMI_MPI_EXCHANGE(g_hs, g_hr);
+  if (!rcode && memcpy_own) {
+    int me = 0;
+    MPI_Comm_rank(g_comm, &me);
+    memcpy(g_hr + rd[me], g_hs + sd[me], (size_t)sc[me]);
+  }
   if (!rcode && rtot && hipMemcpyAsync(recvbuf, g_hr, (size_t)rtot, hipMemcpyHostToDevice, st) != hipSuccess) rcode = -1;
   if (!rcode && hipStreamSynchronize(st) != hipSuccess) rcode = -1; /* the staging buffer is reused by the next call */
 #endif
+#undef EMI_MPI_EXCHANGE
   MPI_Type_free(&t16);
   free(isc);
   return rcode;

@@ -99,7 +99,7 @@ def test_bench_multi_rank_launch(ngpus, nprtrv):
     reference's benchmark picks for 8 tasks (ectrans-benchmark.F90:280-306): `--nprtrv 2`, levels dealt to two V-sets."""
     import json
     import sys
-    env = dict(os.environ, EMI_BENCH_BACKEND="gloo", EMI_BENCH_ONE_GPU="1")
+    env = dict(os.environ, EMI_BENCH_BACKEND="gloo", EMI_BENCH_ONE_GPU="1", EMI_BENCH_PREFLIGHT="1")  # the T63 pre-flight pair of the exchange too
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ngpus), "--nsmax", "399", "--nlev", "30", "--nfld", "2",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--nprtrv", str(nprtrv)], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
@@ -111,6 +111,7 @@ def test_bench_multi_rank_launch(ngpus, nprtrv):
     assert abs(out["roofline"]["peak"] - ngpus * 78.6) < 1e-9 and 0 < out["roofline"]["frac"] < 1
     assert out["config"]["world_size"] == ngpus and out["config"]["backend"] == "gloo"
     assert out["config"]["nprtrv"] == nprtrv and out["config"]["nprtrw"] * nprtrv == ngpus
+    assert out["config"]["exchange_preflight"] == "ok"
     assert out["spectral_norm_rel_error"] < 1e-12
 
 

@@ -120,6 +120,16 @@ def main():
                     max(rel_err(back(s3o)[v], sr3[gidx][:, 1 + v * nlev + l3]) for v in range(nvar)))
     if own2:
         e_m2d = max(e_m2d, rel_err(back(s2o), sr3[gidx][:, 0:1]))
+    # ---- a call in which only the last V-set holds a field (the benchmark's surface field on its own): the other V-sets make no
+    # TRMTOL / TRLTOM exchange at all -- transports must not need them (point-to-point blocks, no collective over all tasks)
+    gp1 = to(np.zeros((1, 1, ng)))
+    et.inv_trans(r, pspsc2=to(loc(sc2, [0])) if own2 else None, pgp2=gp1, kvsetsc2=kv2)
+    e_one = rel_err(back(gp1)[0], g3[2 * nlev:2 * nlev + 1, sl], axis=1)
+    s1o = to(np.zeros((ns2, 1)))
+    et.dir_trans(r, pspsc2=s1o if own2 else None, pgp2=gp1, kvsetsc2=kv2)
+    if own2:
+        e_one = max(e_one, rel_err(back(s1o), sr3[gidx][:, 0:1]))
+    e_m2 = max(e_m2, e_one)
     print("rank %d/%d (W-set %d, V-set %d): nump %d lats %d..%d uv %s sc %s  e_inv %.2e e_dir %.2e e_norm %.2e mode2 %.2e %.2e" % (
         rank, world, myw, myv, len(myms), lat0 + 1, lat1, list(luv), list(lsc), e_inv, e_dir, e_norm, e_m2, e_m2d), flush=True)
     tol = (1e-12, 1e-13) if PREC == 8 else (3e-5, 1e-5)
