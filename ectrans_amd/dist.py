@@ -237,13 +237,15 @@ def rccl_native_attach(nproc, myproc, kmax_resol=1, kprintlev=0, prad=0.0, devic
     import torch.distributed as dist
     L = rccl_native_lib()
     uid = C.create_string_buffer(128)
-    if myproc == 1:
-        if L.emi_rccl_get_unique_id(uid):
-            raise OSError("emi_rccl_get_unique_id: " + (L.emi_rccl_last_error() or b"").decode())
-    box = [uid.raw if myproc == 1 else None]
-    if nproc > 1:
+    err = None
+    if myproc == 1 and L.emi_rccl_get_unique_id(uid):
+        err = "emi_rccl_get_unique_id: " + (L.emi_rccl_last_error() or b"").decode()
+    box = [(uid.raw if err is None else err) if myproc == 1 else None]
+    if nproc > 1:  # a failure on task 1 travels too: every task raises, none is left waiting in the broadcast
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group)
+    if not isinstance(box[0], bytes):
+        raise OSError(str(box[0]))
     uid2 = C.create_string_buffer(box[0], 128)
     rc = L.emi_rccl_attach(uid2, int(nproc), int(myproc), int(kmax_resol), int(kprintlev), float(prad or 0.0), int(device if device is not None else -1))
     if rc:
