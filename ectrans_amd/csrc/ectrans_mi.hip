@@ -397,18 +397,21 @@ static bool mr_choose(int sz, int esz, int fac[3], int &fbk, int &nthr) {
     while (fb > 1 && fb * per_field > lds_budget) fb >>= 1;
     const int R[3] = {A, B, C};
     const int nt_only = getenv("EMI_FFT_MR_NT") ? atoi(getenv("EMI_FFT_MR_NT")) : 0;  // experiments: one workgroup size for every row
-    for (int nt = 64; nt <= 256; nt += 64) {
-      if (nt_only ? nt != nt_only : nt < 128) continue;
+    for (int nt = 64; nt <= 512; nt += 64) {
+      if (nt_only ? nt != nt_only : (nt < 128 || nt > 256)) continue;
       double cost = 0;
       for (int ip = 0; ip < 3; ip++) {
         if (R[ip] == 1) continue;
         const long long nb = (long long)fb * (sz / R[ip]);
         const long long sweeps = (nb + nt - 1) / nt;
-        cost += (double)(sweeps * nt) / (double)nb * (mr_radix_ops(R[ip]) / R[ip] + 15.0);
+        cost += (double)(sweeps * nt) / (double)nb * (mr_radix_ops(R[ip]) / R[ip] + 15.0);  // (the 15: 0 ... 60 change the phase by < 1 %)
       }
-      // the LDS footprint fixes the workgroups per CU, so a smaller workgroup means fewer waves to hide latencies behind: measured at
-      // TCo1279, one size for all rows: 256 threads 38.8 ms, 192 42.1 ms, 128 51.2 ms, 64 66 ms (per pair, the rows these kernels carry)
-      cost *= 1.0 + 0.12 * (256 - nt) / 64.0;
+      // The LDS footprint fixes the workgroups per CU, so a smaller workgroup means fewer waves to hide latencies behind, and the
+      // Fourier-space stages run over all threads of the workgroup whatever the passes use.  Measured at TCo1279 (per pair, the
+      // rows these kernels carry): one size for all rows 64 threads 66 ms, 128: 51.2, 192: 42.1, 256: 38.8 (first version); final
+      // kernels with a premium of 0 / 0.12 / 0.25 / 0.5 per wave less: 28.5 / 26.9 / 25.9 / 25.3 ms (0.5 = 256 threads for every
+      // row); 320 / 384 / 512 threads: 35.7 / 35.2 / 31.1 ms.
+      cost *= 1.0 + 0.5 * (256 - nt) / 64.0;
       if (cost < best * (1.0 - 1e-9) || (cost <= best * (1.0 + 1e-9) && nt > nthr)) {
         best = cost, found = true;
         fac[0] = A, fac[1] = B, fac[2] = C, fbk = fb, nthr = nt;
