@@ -8,7 +8,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,order", [(2, "lat"), (3, "lat"), (4, "lat"), (2, "m")])
+@pytest.mark.parametrize("world,order", [(2, "lat"), (3, "lat"), (2, "m")])  # 4 tasks and more: GPU tier (tests/test_gpu_shims.py)
 def test_wset_sharding_with_alltoallv(world, order):
     """order: row order inside the exchanged Fourier blocks -- latitude-major (default) or wavenumber-major
     (EMI_FB_ORDER=m, kept for A/B measurements)."""
@@ -56,9 +56,9 @@ def run_vsets(world, nprtrv, port, device="cpu", extra=None, timeout=1200):
         assert p.returncode == 0 and ("VSETS OK rank %d" % rank) in out, out
 
 
-@pytest.mark.parametrize("world,nprtrv", [(2, 2), (4, 2), (6, 3)])
+@pytest.mark.parametrize("world,nprtrv", [(2, 2), (4, 2)])  # 2 x 3: GPU tier
 def test_vset_sharding(world, nprtrv):
-    """NPRTRV > 1 (sump_trans0_mod.F90:49, inv_trans.F90:212-300): NPRTRW x NPRTRV tasks -- 1 x 2, 2 x 2 and 2 x 3 (4 x 2: bench launch test on the GPU tier).
+    """NPRTRV > 1 (sump_trans0_mod.F90:49, inv_trans.F90:212-300): NPRTRW x NPRTRV tasks -- 1 x 2 and 2 x 2 (2 x 3, 4 x 2: GPU tier).
     Spectral arrays hold the fields of the task's V-set (KVSETUV / KVSETSC / KVSETSC2 / KVSETSC3A), grid arrays ALL fields on
     the task's latitudes; TRLTOG / TRGTOL between the V-sets of a band is a second all-to-all-v.  Emulator kernels, gloo."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])

@@ -102,7 +102,7 @@ def test_direct_mixed_radix_fft_kernels_adjoints(et):
     assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
 
 
-@pytest.mark.parametrize("precision", [8, 4])
+@pytest.mark.parametrize("precision", [8])  # fp32: GPU tier
 def test_register_resident_fft_kernels_blocked_rows(et, precision, monkeypatch):
     """k_fft_dir_r16 / k_fft_inv_r16 with NPROMA blocks that cut the rows (the element-wise grid path; the unblocked
     specialised-kernel cases above take the row-as-one-buffer path), winds and derivatives."""
@@ -117,16 +117,6 @@ def test_register_resident_fft_kernels_adjoints(et, monkeypatch):
     monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
     e_inv, e_dir = adjoint_case(et, XP, 15, R16_ROWS + R16_ROWS[::-1], 1, 1, nproma=3000)
     assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
-
-
-def test_unmerged_radix_fft_kernels_match_oracle(et, monkeypatch):
-    """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists 8*8*8*2*3 ... (the default merges the last two
-    factors into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""
-    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
-    monkeypatch.setenv("EMI_FFT_MERGE", "0")
-    half = [2564, 3068, 4100, 4604, 4612, 5116, 2052, 4092]
-    e_inv, e_dir = run_case(et, Oracle, XP, 15, half + half[::-1], 1, 1, dict(scders=True), None)
-    assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
 @pytest.mark.parametrize("env", [("EMI_NO_FUSE_DIR", "1"), ("EMI_FB_TABLE", "1"), ("EMI_FB_ORDER", "m"), ("EMI_FFT_NO_HOT", "1"), ("EMI_FFT_MR", "0")])
