@@ -229,3 +229,29 @@ def test_fortran_shim_with_two_vsets(ntasks):
     env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     p = subprocess.run([mpiexec, "-n", str(ntasks), os.path.join(d, "test_shim_vsets")], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and p.stdout.count("FORTRAN SHIM VSETS OK") == ntasks, p.stdout + p.stderr
+
+
+def test_bench_line_contract():
+    """`bench.py` on one GPU at a small size with every leg on (oracle port, library BLAS + FFT, dense parity, host-array rate): ONE JSON line
+    with the driver's keys and the two blocks this tier adds -- `roofline` (bound, achieved, peak, unit, frac, traffic) and
+    `cpu_baseline` (value, unit, cores, kind, sample) -- plus `cpu_baseline_blas`, `fft_bound`, `dense`."""
+    import json
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nsmax", "159", "--nlev", "10", "--nfld", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout + p.stderr
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "pairs/s" and out["dtype"] == "f64" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "pairs/s" and "sample" in cb
+    bl = out["cpu_baseline_blas"]
+    assert ("error" in bl) or (bl["value"] > 0 and bl["inv_max_rel_err_vs_oracle"] < 1e-12 and bl["dir_max_rel_err_vs_oracle"] < 1e-12 and bl["cores"] <= 32)
+    assert "fft_bound" in out and out["dense"]["inv_max_rel_err"] < 1e-11 and out["dense"]["dir_max_rel_err"] < 1e-11
+    assert out["spectral_norm_rel_error"] < 1e-12
