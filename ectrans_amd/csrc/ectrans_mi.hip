@@ -377,15 +377,20 @@ static double mr_radix_ops(int R) {
     case 13: return 204; case 17: return 336; case 19: return 414; case 23: return 594;
     case 6: return 3 * 4 + 2 * 14 + 12; case 8: return 4 * 4 + 2 * 16 + 18; case 9: return 6 * 14 + 24; case 10: return 5 * 4 + 2 * 36 + 24;
     case 12: return 4 * 14 + 3 * 16 + 36; case 14: return 7 * 4 + 2 * 66 + 36; case 15: return 5 * 14 + 3 * 36 + 48; case 16: return 8 * 16 + 54;
+    case 18: return 9 * 4 + 2 * 108 + 48; case 20: return 5 * 16 + 4 * 36 + 72; case 21: return 7 * 14 + 3 * 66 + 72;
     default: return -1;
   }
 }
 static bool mr_choose(int sz, int esz, int fac[3], int &fbk, int &nthr) {
-  static const int rs[] = {
+  std::vector<int> rs = {
 #define EMI_MR_ROW(r_) r_,
       EMI_MR_RADICES(EMI_MR_ROW)
-#undef EMI_MR_ROW
   };
+#ifdef EMI_MR_RADICES_F32
+  if (esz == 4)
+    for (int r : {EMI_MR_RADICES_F32(EMI_MR_ROW)}) rs.push_back(r);
+#endif
+#undef EMI_MR_ROW
   double best = 1e300;
   bool found = false;
   auto consider = [&](int A, int B, int C) {

@@ -29,7 +29,9 @@ namespace emi_f64 {
 #define EMI_MFMA emi_mfma_f64
 #define EMI_ACC_ROW(l, i) (((l) >> 4) + 4 * (i))
 #define EMI_FFT_WAVES 4
+#define EMI_MR_EXTRA(X)
 #include "emi_kernels_body.h"
+#undef EMI_MR_EXTRA
 #undef EMI_REAL
 #undef EMI_REAL2
 #undef EMI_ACC4
@@ -45,7 +47,13 @@ namespace emi_f32 {
 #define EMI_MFMA emi_mfma_f32
 #define EMI_ACC_ROW(l, i) (4 * ((l) >> 4) + (i))
 #define EMI_FFT_WAVES 4
+#ifdef EMI_MR_RADICES_F32
+#define EMI_MR_EXTRA(X) EMI_MR_RADICES_F32(X)
+#else
+#define EMI_MR_EXTRA(X)
+#endif
 #include "emi_kernels_body.h"
+#undef EMI_MR_EXTRA
 #undef EMI_REAL
 #undef EMI_REAL2
 #undef EMI_ACC4

@@ -1,7 +1,7 @@
 // emi_mr_body.h -- direct mixed-radix FFT kernels k_fft_dir_mr / k_fft_inv_mr (round 3), included by emi_kernels_body.h
 // inside namespace emi_f64 / emi_f32.  (No include guard on purpose.)
 // ==========================================================================================
-// Rows whose half-length sz = NLOEN / 2 is a product of at most three radices A B C, each from {2..16, 17, 19, 23}, need no
+// Rows whose half-length sz = NLOEN / 2 is a product of at most three radices A B C, each from {2..16, 17, 19, 23} (fp32 library: also 18, 20, 21), need no
 // chirp-z convolution: at TCo1279 that is 24 % of the grid by weight (7.7 % with a 7-smooth half-length), and a direct
 // transform does about a sixth of the arithmetic of the three work-length transforms of a Bluestein row.  What the
 // reference does for every length (FFTW plans, tpm_fftw.F90:251-377; ftdir_mod.F90:67-84 / ftinv_mod.F90:65-84) --
@@ -17,8 +17,8 @@
 //     element (n1 | k1, n2 | k2, n3 | k3) at n1 P1 + n2 C + n3, P1 = BC made odd -- the three access patterns (lanes along
 //     j = n2 C + n3; along n3 then k1; along k1 then k2) are then free of bank conflicts up to the wrap of the faster index;
 //   * a butterfly lives in registers: odd primes as the symmetric DFT matrix (sums / differences of x_j, x_(P-j); 4 m^2 + 10 m
-//     operations, m = (P-1)/2, the cos / sin entries instruction literals), 2 and 4 by hand, composite radices as two such
-//     stages with constant twiddles; outputs are stored as they are produced, so that a radix-23 butterfly fits 128 VGPRs;
+//     operations, m = (P-1)/2, the cos / sin entries instruction literals), 2 and 4 by hand, composite radices (6 ... 21) as two such
+//     stages with constant twiddles; outputs are stored as they are produced (radix 19 fits 125 VGPRs, radix 23 spills 24);
 //   * the first pass of the direct transform reads the grid row straight from memory (TRGTOL local copy), the last pass of the
 //     inverse transform writes it (TRLTOG local copy): thread j handles points j + cnt r, coalesced for every r;
 //   * the inverse transform is conj(DFT(conj Z)): one set of (forward) butterflies and twiddle tables;
@@ -98,7 +98,7 @@ EMI_DEVFN void mr_mulw(real_t &xr, real_t &xi) {
 
 // how a composite radix splits: R = mr_split_a(R) * (R / mr_split_a(R)); 0: prime (or 4), a butterfly of its own
 EMI_DEVFN constexpr int mr_split_a(int R) {
-  return R == 6 ? 2 : R == 8 ? 2 : R == 9 ? 3 : R == 10 ? 2 : R == 12 ? 3 : R == 14 ? 2 : R == 15 ? 3 : R == 16 ? 4 : 0;
+  return R == 6 ? 2 : R == 8 ? 2 : R == 9 ? 3 : R == 10 ? 2 : R == 12 ? 3 : R == 14 ? 2 : R == 15 ? 3 : R == 16 ? 4 : R == 18 ? 2 : R == 20 ? 4 : R == 21 ? 3 : 0;
 }
 
 // forward DFT of R values in registers; emit(integral_constant<k>, re, im) is called once per output
@@ -260,6 +260,7 @@ EMI_DEVFN void mr_pass_any(int R, real2 *a, int fs, int nfl, const MrPassArgs &p
 #define EMI_MR_CASE(r_) \
   case r_: mr_pass<r_, IO>(a, fs, nfl, pa, flds, blk0, rem0, nproma); break;
     EMI_MR_RADICES(EMI_MR_CASE)
+    EMI_MR_EXTRA(EMI_MR_CASE)
 #undef EMI_MR_CASE
     default: break;
   }

@@ -128,6 +128,10 @@ struct FftLaunchDev {
 // radices of the direct mixed-radix kernels k_fft_*_mr (emi_mr_body.h)
 #ifndef EMI_MR_RADICES
 #define EMI_MR_RADICES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(19) X(23)
+// ... and of the fp32 library only: the long rows of TCo2559 (half-lengths above 16^3) need a radix above 16, and the composite ones
+// give 16.3 instead of 10.9 % of that grid a direct plan (FFT phase 584 -> 568 ms).  In the fp64 kernels their butterflies spill and
+// the TCo1279 rows they would add (1.5 % of the grid) cost what they cost on the convolution kernels -- measured, left out.
+#define EMI_MR_RADICES_F32(X) X(18) X(20) X(21)
 #endif
 
 // Work lengths with a specialised FFT kernel (k_fft_*_hot<pc>): X(pc, S, nfac, factors[5], fields per

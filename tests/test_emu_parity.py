@@ -83,7 +83,7 @@ R16_ROWS = [1540, 2044, 2052, 2556, 2564, 3068, 3076, 4092]  # first and last ro
 # one and several fields per workgroup
 MR_SHORT = [20, 24, 28, 32, 34, 38, 44, 46, 52, 68, 92, 286, 646, 480]            # 10, 12, 14, 16, 17, 19, 2*11, 23, 2*13, 2*17, 2*23, 11*13, 17*19, 6*8*5
 MR_MID = [512, 1058, 1890, 1430, 1938, 2244, 1716, 1292]                          # 16*16, 23*23, 9*15*7, 10*11*13, 3*17*19, 6*11*17, 6*11*13, 2*17*19
-MR_LONG = [4004, 4096, 5060, 5120, 4522, 4394, 4800, 4862]                        # 14*11*13, 16*16*8, 10*11*23, 16*16*10, 7*17*19, 13^3, 16*15*10, 11*13*17
+MR_LONG = [4004, 4096, 5060, 5120, 4522, 4394, 4800, 4862, 2916, 4000, 4116]      # 14*11*13, 16*16*8, 10*11*23, 16*16*10, 7*17*19, 13^3, 16*15*10, 11*13*17, 18*9*9, 20*10*10, 21*14*7
 
 
 @pytest.mark.parametrize("rows,precision,nproma", [(MR_SHORT, 8, None), (MR_MID, 8, None), (MR_LONG, 8, None), (MR_LONG, 4, None), (MR_SHORT, 8, 37)])
