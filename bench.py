@@ -378,6 +378,13 @@ def main():
             raise
         ok, transport_note = 0, str(e)
     preflight = None
+    if transport == "rccl" and world > 1:
+        # agree on the attach BEFORE the pre-flight: its grouped ncclSend / ncclRecv would wait for ever on a rank whose attach
+        # failed and which therefore never posts its side
+        flag0 = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag0, op=dist.ReduceOp.MIN)
+        if not int(flag0.item()) and ok:
+            ok, transport_note = 0, "native attach failed on another rank"
     if (transport == "rccl" or os.environ.get("EMI_BENCH_PREFLIGHT")) and ok and world > 1:
         # pre-flight of the native exchange (its grouped ncclSend / ncclRecv have only ever run inside one-GPU tests): a T63 pair
         # of the benchmark harmonic on two fields; an exception or a wrong norm sends every rank to the torch.distributed callback

@@ -41,7 +41,7 @@ class _Init(C.Structure):
 class _VSets(C.Structure):  # emi_vsets_t
     _fields_ = [("kvsetuv", C.POINTER(C.c_int)), ("nuv_g", C.c_int), ("kvsetsc", C.POINTER(C.c_int)), ("nsc_g", C.c_int),
                 ("kvsetsc2", C.POINTER(C.c_int)), ("nsc2_g", C.c_int), ("kvsetsc3a", C.POINTER(C.c_int)), ("nsc3a_g", C.c_int),
-                ("kvsetsc3b", C.POINTER(C.c_int)), ("nsc3b_g", C.c_int)]
+                ("kvsetsc3b", C.POINTER(C.c_int)), ("nsc3b_g", C.c_int), ("nvar3a_g", C.c_int), ("nvar3b_g", C.c_int)]
 
 
 class _LegpolIO(C.Structure):
@@ -377,7 +377,7 @@ def _fill_grid(a, space, keep, pgp, pgpuv, pgp3a, pgp3b, pgp2, nproma, ngpblks, 
     keep.append(ext)
 
 
-def _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b):
+def _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b, pgp3a=None, pgp3b=None, dmul=1):
     """KVSETUV / KVSETSC / KVSETSC2 / KVSETSC3A / KVSETSC3B (inv_trans.h:84-101): the V-set (1..NPRTRV) of every GLOBAL field;
     with them the spectral arrays hold this task's V-set only, the grid arrays all fields."""
     if all(k is None for k in (kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)):
@@ -390,6 +390,10 @@ def _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b):
             keep.append(arr)
             setattr(vs, nm, arr.ctypes.data_as(C.POINTER(C.c_int)))
             setattr(vs, cnt, int(arr.size))
+    # the variable count of the 3-D arrays from the GRID side (every task holds all fields there), so that a task whose V-set owns
+    # no level -- and passes no PSPSC3A -- still lists the same global fields as its peers (the reference: UBOUND(PSPSC3A,3))
+    vs.nvar3a_g = 0 if pgp3a is None or pgp3a.ndim != 4 else int(pgp3a.shape[1]) // dmul
+    vs.nvar3b_g = 0 if pgp3b is None or pgp3b.ndim != 4 else int(pgp3b.shape[1]) // dmul
     keep.append(vs)
     a.vsets = C.pointer(vs)
     a.ext = None  # the extents block describes one-V-set calls (local == global field counts)
@@ -411,7 +415,7 @@ def inv_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
-    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b, pgp3a, pgp3b, 3 if ldscders else 1)
     _chk(lib().emi_inv_trans(kresol, C.byref(a)))
 
 
@@ -429,7 +433,7 @@ def dir_trans(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, ps
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
-    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b, pgp3a, pgp3b)
     _chk(lib().emi_dir_trans(kresol, C.byref(a)))
 
 
@@ -451,7 +455,7 @@ def inv_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, 
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
-    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b, pgp3a, pgp3b, 3 if ldscders else 1)
     _chk(lib().emi_inv_transad(kresol, C.byref(a)))
 
 
@@ -468,7 +472,7 @@ def dir_transad(kresol, pspvor=None, pspdiv=None, pspscalar=None, pspsc3a=None, 
     a.kproma = nproma
     a.mem_space = space[0] if space[0] is not None else EMI_MEM_HOST
     a.stream = stream
-    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b)
+    _fill_vsets(a, keep, kvsetuv, kvsetsc, kvsetsc2, kvsetsc3a, kvsetsc3b, pgp3a, pgp3b)
     _chk(lib().emi_dir_transad(kresol, C.byref(a)))
 
 

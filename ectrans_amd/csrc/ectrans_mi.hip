@@ -2163,6 +2163,19 @@ static int set_lds_attrs() {
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // direct mixed-radix plans hold up to 160 KiB per field (mr_choose) and have no global-scratch variant: fp64 rows such as
+  // n = 8704 (half-length 4352 = 16 x 16 x 17) need 69 888 B
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv_mr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir_mr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv_mr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_mr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define EMI_R16_ATTR(r_)                                                                                                                     \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv_r16<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir_r16<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv_r16<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_r16<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_R16_LIST(EMI_R16_ATTR)
+#undef EMI_R16_ATTR
   done = true;
   return 0;
 }
@@ -3194,6 +3207,7 @@ struct VGroups {
   std::vector<ScalarRef> sc_g;     // global scalars in the reference's order
   std::vector<int> osc;            // their owners
   int nsc_g[4] = {0, 0, 0, 0};     // global counts: PSPSCALAR fields, PSPSC2 fields, PSPSC3A levels, PSPSC3B levels
+  int nvar3a = 0, nvar3b = 0;      // variables of PSPSC3A / PSPSC3B = IF_SC3A_G3 / IF_SC3B_G3 (inv_trans.F90:277, 310): the same on every task
 };
 template <class ARGS>
 static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) {
@@ -3240,14 +3254,25 @@ static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) 
     if (vs->kvsetsc3a) {
       if (owners(vs->kvsetsc3a, vs->nsc3a_g, "KVSETSC3A", o)) return EMI_ERR_ARG;
       vg.nsc_g[2] = vs->nsc3a_g;
-      for (int v = 0; v < a.sc3a_nvar; v++)
+      // The reference takes the variable count from UBOUND(PSPSC3A,3), which a task whose V-set owns no level still passes as a
+      // zero-level array (inv_trans.F90:272-277 aborts without it).  Here such a task may have no spectral array at all, so the
+      // count also travels in the KVSET block (from the grid array); without either the peers would disagree on the field list.
+      vg.nvar3a = vs->nvar3a_g > 0 ? vs->nvar3a_g : a.sc3a_nvar;
+      if (vg.nvar3a <= 0) EMI_FAIL(EMI_ERR_ARG, "%s:KVSETSC3A BUT NOT PSPSC3A (number of variables unknown: pass sc3a_nvar or emi_vsets_t.nvar3a_g)", who);
+      if (a.sc3a_nvar > 0 && a.sc3a_nvar != vg.nvar3a)
+        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PSPSC3A INCONSISTENT (%d, IF_SC3A_G3 = %d)", who, a.sc3a_nvar, vg.nvar3a);
+      for (int v = 0; v < vg.nvar3a; v++)
         for (int l = 0; l < vs->nsc3a_g; l++) vg.sc_g.push_back({2, l, v}), vg.osc.push_back(o[l]);
       if (check_local("KVSETSC3A", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3a ? a.sc3a_nlev : 0)) return EMI_ERR_ARG;
     }
     if (vs->kvsetsc3b) {
       if (owners(vs->kvsetsc3b, vs->nsc3b_g, "KVSETSC3B", o)) return EMI_ERR_ARG;
       vg.nsc_g[3] = vs->nsc3b_g;
-      for (int v = 0; v < a.sc3b_nvar; v++)
+      vg.nvar3b = vs->nvar3b_g > 0 ? vs->nvar3b_g : a.sc3b_nvar;
+      if (vg.nvar3b <= 0) EMI_FAIL(EMI_ERR_ARG, "%s:KVSETSC3B BUT NOT PSPSC3B (number of variables unknown: pass sc3b_nvar or emi_vsets_t.nvar3b_g)", who);
+      if (a.sc3b_nvar > 0 && a.sc3b_nvar != vg.nvar3b)
+        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PSPSC3B INCONSISTENT (%d, IF_SC3B_G3 = %d)", who, a.sc3b_nvar, vg.nvar3b);
+      for (int v = 0; v < vg.nvar3b; v++)
         for (int l = 0; l < vs->nsc3b_g; l++) vg.sc_g.push_back({3, l, v}), vg.osc.push_back(o[l]);
       if (check_local("KVSETSC3B", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3b ? a.sc3b_nlev : 0)) return EMI_ERR_ARG;
     }
@@ -3347,8 +3372,8 @@ static int inv_trans_vsets(int kresol, const emi_invtrans_t *ap, bool adj) {
     if (nuvg > 0 && !a.gpuv) EMI_FAIL(EMI_ERR_ARG, "%s:PGPUV MISSING", who);
     if (vg.nsc_g[0] > 0) EMI_FAIL(EMI_ERR_ARG, "%s:PGP MISSING (PSPSCALAR needs PGP)", who);
     if (vg.nsc_g[1] > 0 && !a.gp2) EMI_FAIL(EMI_ERR_ARG, "%s:PGP2 MISSING", who);
-    if (vg.nsc_g[2] * a.sc3a_nvar > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3A MISSING", who);
-    if (vg.nsc_g[3] * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3B MISSING", who);
+    if (vg.nsc_g[2] * vg.nvar3a > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3A MISSING", who);
+    if (vg.nsc_g[3] * vg.nvar3b > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3B MISSING", who);
   }
   // ---- the caller's arrays on the device (spectral: local fields; grid: all fields on this task's points)
   HostStage hs(P.esz);
@@ -3364,11 +3389,11 @@ static int inv_trans_vsets(int kresol, const emi_invtrans_t *ap, bool adj) {
   void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host, gpad || a.gp_nfld > if_gp_g, st);
   void *d_gpuv = hs.out(a.gpuv, gsz * nuvg * nvar_uv, host && nuvg, gpad, st);
   void *d_gp2 = hs.out(a.gp2, gsz * vg.nsc_g[1] * dmul, host, gpad, st);
-  void *d_gp3a = hs.out(a.gp3a, gsz * vg.nsc_g[2] * a.sc3a_nvar * dmul, host, gpad, st);
-  void *d_gp3b = hs.out(a.gp3b, gsz * vg.nsc_g[3] * a.sc3b_nvar * dmul, host, gpad, st);
+  void *d_gp3a = hs.out(a.gp3a, gsz * vg.nsc_g[2] * vg.nvar3a * dmul, host, gpad, st);
+  void *d_gp3b = hs.out(a.gp3b, gsz * vg.nsc_g[3] * vg.nvar3b * dmul, host, gpad, st);
   if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
   VGridList gl;
-  v_grid_fields(vg, lvorgp, ldivgp, lscders, luvder, d_gp, a.gp_nfld, d_gpuv, nvar_uv, d_gp2, d_gp3a, a.sc3a_nvar, d_gp3b, a.sc3b_nvar, gl);
+  v_grid_fields(vg, lvorgp, ldivgp, lscders, luvder, d_gp, a.gp_nfld, d_gpuv, nvar_uv, d_gp2, d_gp3a, vg.nvar3a, d_gp3b, vg.nvar3b, gl);
   std::vector<int> nl(P.nprv, 0);  // grid fields every V-set computes
   for (int o : gl.owner) nl[o]++;
   const int nlm = nl[P.mev];
@@ -3440,8 +3465,8 @@ static int dir_trans_vsets(int kresol, const emi_dirtrans_t *ap, bool adj, const
     if (nuvg > 0 && !a.gpuv) EMI_FAIL(EMI_ERR_ARG, "%s:PGPUV MISSING", who);
     if (vg.nsc_g[0] > 0) EMI_FAIL(EMI_ERR_ARG, "%s:PGP MISSING (PSPSCALAR needs PGP)", who);
     if (vg.nsc_g[1] > 0 && !a.gp2) EMI_FAIL(EMI_ERR_ARG, "%s:PGP2 MISSING", who);
-    if (vg.nsc_g[2] * a.sc3a_nvar > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3A MISSING", who);
-    if (vg.nsc_g[3] * a.sc3b_nvar > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3B MISSING", who);
+    if (vg.nsc_g[2] * vg.nvar3a > 0 && !a.gp3a) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3A MISSING", who);
+    if (vg.nsc_g[3] * vg.nvar3b > 0 && !a.gp3b) EMI_FAIL(EMI_ERR_ARG, "%s:PGP3B MISSING", who);
   }
   HostStage hs(P.esz);
   const size_t ns2 = P.nspec2, gsz = (size_t)nproma * ngpblks;
@@ -3455,11 +3480,11 @@ static int dir_trans_vsets(int kresol, const emi_dirtrans_t *ap, bool adj, const
   void *d_gp = (void *)hs.in(a.gp, gsz * a.gp_nfld, host, st);
   void *d_gpuv = (void *)hs.in(a.gpuv, gsz * nuvg * 2, host && nuvg, st);
   void *d_gp2 = (void *)hs.in(a.gp2, gsz * vg.nsc_g[1], host, st);
-  void *d_gp3a = (void *)hs.in(a.gp3a, gsz * vg.nsc_g[2] * a.sc3a_nvar, host, st);
-  void *d_gp3b = (void *)hs.in(a.gp3b, gsz * vg.nsc_g[3] * a.sc3b_nvar, host, st);
+  void *d_gp3a = (void *)hs.in(a.gp3a, gsz * vg.nsc_g[2] * vg.nvar3a, host, st);
+  void *d_gp3b = (void *)hs.in(a.gp3b, gsz * vg.nsc_g[3] * vg.nvar3b, host, st);
   if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
   VGridList gl;  // u(nuv_g) v(nuv_g) scalars: dir_trans.F90:301
-  v_grid_fields(vg, false, false, false, false, d_gp, a.gp_nfld, d_gpuv, 2, d_gp2, d_gp3a, a.sc3a_nvar, d_gp3b, a.sc3b_nvar, gl);
+  v_grid_fields(vg, false, false, false, false, d_gp, a.gp_nfld, d_gpuv, 2, d_gp2, d_gp3a, vg.nvar3a, d_gp3b, vg.nvar3b, gl);
   std::vector<int> nl(P.nprv, 0);
   for (int o : gl.owner) nl[o]++;
   const int nlm = nl[P.mev];

@@ -233,16 +233,42 @@ EMI_DEVFN void mr_pass(real2 *a, int fs, int nfl, const MrPassArgs &pa, const Gr
       });
     }
     if (IO != 1 && pa.tw) {  // (uniform) x_r *= w^r
-      real_t cr = w.x, ci = w.y;
-      mr_for<1, R>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        if constexpr (r > 1) {
-          const real_t t0 = cr * w.x - ci * w.y;
-          ci = cr * w.y + ci * w.x, cr = t0;
-        }
-        const real_t t1 = xr[r] * cr - xi[r] * ci;
-        xi[r] = xr[r] * ci + xi[r] * cr, xr[r] = t1;
-      });
+      if constexpr (sizeof(real_t) == 4 && (R > 8)) {
+        // fp32 library: four interleaved chains w^r = w^(r-4) w^4 instead of one chain w^r = w^(r-1) w -- the rounding error of a
+        // power grows with the number of products behind it, 22 at radix 23 (about 1e-6 relative in single precision, which the
+        // yardstick of tests/common.py sees on the long rows of TCo2559), 2 + r / 4 here, for the same one product per power.
+        // The fp64 kernels keep the single chain: 20 double ulps are far below their tolerance and radix 19 / 23 have no
+        // registers for four live powers.
+        real_t qr[4], qi[4];
+        qr[1] = w.x, qi[1] = w.y;
+        mr_for<1, R>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if constexpr (r == 2) {
+            qr[2] = w.x * w.x - w.y * w.y, qi[2] = 2 * w.x * w.y;
+          } else if constexpr (r == 3) {
+            qr[3] = qr[2] * w.x - qi[2] * w.y, qi[3] = qr[2] * w.y + qi[2] * w.x;
+          } else if constexpr (r == 4) {
+            qr[0] = qr[2] * qr[2] - qi[2] * qi[2], qi[0] = 2 * qr[2] * qi[2];
+            w = mk2(qr[0], qi[0]);  // w^4 from here on
+          } else if constexpr (r > 4) {
+            const real_t t0 = qr[r & 3] * w.x - qi[r & 3] * w.y;
+            qi[r & 3] = qr[r & 3] * w.y + qi[r & 3] * w.x, qr[r & 3] = t0;
+          }
+          const real_t t1 = xr[r] * qr[r & 3] - xi[r] * qi[r & 3];
+          xi[r] = xr[r] * qi[r & 3] + xi[r] * qr[r & 3], xr[r] = t1;
+        });
+      } else {
+        real_t cr = w.x, ci = w.y;
+        mr_for<1, R>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if constexpr (r > 1) {
+            const real_t t0 = cr * w.x - ci * w.y;
+            ci = cr * w.y + ci * w.x, cr = t0;
+          }
+          const real_t t1 = xr[r] * cr - xi[r] * ci;
+          xi[r] = xr[r] * ci + xi[r] * cr, xr[r] = t1;
+        });
+      }
     }
     MrDft<R>::run(xr, xi, [&](auto kc, real_t re, real_t im) {
       constexpr int k = decltype(kc)::value;

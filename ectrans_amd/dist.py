@@ -50,6 +50,13 @@ def make_alltoallv_hook(group=None, device=None, p2p=False):
     device = torch.device(device) if device is not None else torch.device("cpu")
 
     staged = device.type == "cuda" and dist.get_backend(group) == "gloo"
+    if p2p and device.type == "cuda" and dist.get_backend(group) == "nccl":
+        # With V-sets the first point-to-point call may involve only some tasks (a V-set that holds no field of a call makes no
+        # TRMTOL / TRLTOM exchange), but the first batch_isend_irecv on an NCCL group must be entered by ALL its ranks (it creates
+        # the communicator): one collective over the whole group here, where every task passes, creates it once for all.
+        warm = torch.zeros(1, dtype=torch.float64, device=device)
+        dist.all_reduce(warm, group=group)
+        torch.cuda.synchronize(device)
 
     def exchange(recv, send, osz, isz):
         """all_to_all_single over the whole group -- or, with V-sets, point-to-point transfers between the tasks that really

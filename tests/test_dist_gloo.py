@@ -63,3 +63,12 @@ def test_vset_sharding(world, nprtrv):
     the task's latitudes; TRLTOG / TRGTOL between the V-sets of a band is a second all-to-all-v.  Emulator kernels, gloo."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
     run_vsets(world, nprtrv, 29530 + world + nprtrv)
+
+
+def test_vset_that_owns_no_level():
+    """NPRTRV = 2 with ONE level: the task of V-set 2 passes no PSPSC3A, so it cannot name the variable count of PGP3A from its
+    spectral array -- the reference takes it from UBOUND(PSPSC3A,3) of a zero-level array (inv_trans.F90:272-277); here it also
+    travels from the grid array (emi_vsets_t.nvar3a_g), or the tasks would list different global fields and the TRLTOG / TRGTOL
+    counts would disagree."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    run_vsets(2, 2, 29549, extra={"EMI_TEST_NLEV": "1"})

@@ -159,7 +159,7 @@ def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
 MR_SHORT = [20, 24, 28, 32, 34, 38, 44, 46, 52, 68, 92, 286, 646, 480]            # 10, 12, 14, 16, 17, 19, 2*11, 23, 2*13, 2*17, 2*23, 11*13, 17*19, 6*8*5
 MR_MID = [512, 1058, 1890, 1430, 1938, 2244, 1716, 1292]                          # 16*16, 23*23, 9*15*7, 10*11*13, 3*17*19, 6*11*17, 6*11*13, 2*17*19
 MR_LONG = [4004, 4096, 5060, 5120, 4522, 4394, 4800, 4862, 2916, 4000, 4116]      # 14*11*13, 16*16*8, 10*11*23, 16*16*10, 7*17*19, 13^3, 16*15*10, 11*13*17, 18*9*9, 20*10*10, 21*14*7
-MR_XL = [8192, 8398, 9728, 9826, 10336, 9120, 10488, 9568, 9216, 10240, 9408]    # TCo2559-sized rows: 16^3, 13*17*19, 16*16*19, 17^3, 16*17*19, 15*16*19, 12*19*23, 16*13*23, 16*16*18, 16*16*20, 14*16*21
+MR_XL = [8192, 8398, 9728, 9826, 10336, 9120, 10488, 9568, 9216, 10240, 9408, 8704]    # TCo2559-sized rows: 16^3, 13*17*19, 16*16*19, 17^3, 16*17*19, 15*16*19, 12*19*23, 16*13*23, 16*16*18, 16*16*20, 14*16*21, 16*16*17 (fp64: more than 64 KiB of LDS per row, set_lds_attrs)
 
 
 @pytest.mark.parametrize("rows,precision,nproma", [(MR_SHORT, 8, None), (MR_MID, 8, None), (MR_LONG, 8, None), (MR_SHORT, 4, None), (MR_MID, 4, None),

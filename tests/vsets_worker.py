@@ -90,7 +90,7 @@ def main():
     e_norm = max(e_norm, np.abs(et.specnorm(r, to(loc(sc, lsc)), kvset=kvsc) / o.specnorm(sc) - 1.0).max())
     e_dir = max(errs) if errs else 0.0
     # ---- call mode 2: PGPUV / PGP3A / PGP2 with levels dealt to the V-sets (KVSETSC3A per level)
-    nlev, nvar = 4, 2
+    nlev, nvar = int(os.environ.get("EMI_TEST_NLEV", "4")), 2  # NLEV < NPRTRV: a V-set that owns no level passes no PSPSC3A at all
     kv3 = np.array([(l % nprv) + 1 for l in range(nlev)], dtype=np.int32)
     kv2 = np.array([nprv], dtype=np.int32)
     l3 = np.flatnonzero(kv3 == myv)
