@@ -1108,7 +1108,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
         specw.push_back(m == 0 ? 1.0 : 2.0);
         specw.push_back(m == 0 ? 0.0 : 2.0);
       }
-      P.wrows[ml] = roundup(N + 2 - m, 16);
+      P.wrows[ml] = roundup(N + 2 - m, P.esz == 4 ? 32 : 16);  // whole stages of k_leg_inv: 8 (fp64) | 16 (fp32) rows per parity (LG_KR)
       P.wbase[ml + 1] = P.wbase[ml] + P.wrows[ml];
       int nd = std::min(P.ndgnh, P.ndglu[m]);
       P.lbase[ml + 1] = P.lbase[ml] + nd;
@@ -1118,7 +1118,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       P.offA[ml] = poff + pan;
       poff += 2 * pan;
       P.ldk[ml] = roundup(P.wrows[ml] / 2, 64);
-      long long pant = (long long)roundup(std::max(nd, 1), 16) * P.ldk[ml];  // k_leg_dir reads 16-latitude stages
+      long long pant = (long long)roundup(std::max(nd, 1), P.esz == 4 ? 32 : 16) * P.ldk[ml];  // k_leg_dir reads stages of 16 (fp64) | 32 (fp32) latitudes (LG_LS)
       P.offTS[ml] = ptoff;
       P.offTA[ml] = ptoff + pant;
       ptoff += 2 * pant;
@@ -1335,7 +1335,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
         return rc;
       };
       if (put(P.d_P + P.offS[ml] * esz, pan)) bad = 1;
-      const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), 16);
+      const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), esz == 4 ? 32 : 16);  // = the panel extent behind offTA (pant)
       std::vector<double> pt((size_t)2 * ndp * ldk, 0.0);
       for (int par = 0; par < 2; par++)
         for (int k = 0; k < nk; k++)
@@ -1866,7 +1866,9 @@ static int ensure_desc(Plan &P, size_t bytes) {
 // mg (1, 2, 4 or 8): the XCDs work in mg groups of 8/mg; consecutive wavenumbers go to different groups, and inside
 // a group every XCD takes a range of column tiles (and a residue class of row tiles when there are fewer column
 // tiles than XCDs in the group).  mg = 1: all eight XCDs share every wavenumber.
-static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int mg, int2 **d_map, long long *nblocks) {
+// order 0: column tiles innermost (consecutive tiles of an XCD share the panel rows); 1: row tiles innermost (they share the
+// column stream: the Fourier rows of k_leg_dir, the packed spectral rows of k_leg_inv).
+static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int mg, int order, int2 **d_map, long long *nblocks) {
   const int nx = 8 / mg;  // XCDs per group
   int gx = 1;
   while (gx * 2 <= std::min(nct, nx)) gx *= 2;
@@ -1882,8 +1884,13 @@ static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, i
       // more work than those with 3)
       const int xc = (xi + mlg) % gx, xl = (xi / gx + mlg) % gy;
       const int c0 = (int)((long long)xc * nct / gx), c1 = (int)((long long)(xc + 1) * nct / gx);
-      for (int rt = xl; rt < nrt; rt += gy)
-        for (int ct = c0; ct < c1; ct++) per[x].push_back(int2{ml, (rt << 16) | ct});
+      if (order == 1) {
+        for (int ct = c0; ct < c1; ct++)
+          for (int rt = xl; rt < nrt; rt += gy) per[x].push_back(int2{ml, (rt << 16) | ct});
+      } else {
+        for (int rt = xl; rt < nrt; rt += gy)
+          for (int ct = c0; ct < c1; ct++) per[x].push_back(int2{ml, (rt << 16) | ct});
+      }
     }
   }
   size_t mx = 0;
@@ -1904,8 +1911,12 @@ static int leg_tilemaps(Plan &P, int nct, LegMaps **out) {
       const int v = e ? atoi(e) : dflt;
       return (v == 1 || v == 2 || v == 4 || v == 8) ? v : dflt;
     };
-    if (build_tilemap(P, P.lattile_pref, nct, groups("EMI_LEG_INV_MGROUPS", 1), &lm.d_inv, &lm.n_inv) ||
-        build_tilemap(P, P.ktile_pref, nct, groups("EMI_LEG_DIR_MGROUPS", 1), &lm.d_dir, &lm.n_dir))
+    auto order = [](const char *name, int dflt) {
+      const char *e = getenv(name);
+      return e ? atoi(e) : dflt;
+    };
+    if (build_tilemap(P, P.lattile_pref, nct, groups("EMI_LEG_INV_MGROUPS", 1), order("EMI_LEG_INV_ORDER", 0), &lm.d_inv, &lm.n_inv) ||
+        build_tilemap(P, P.ktile_pref, nct, groups("EMI_LEG_DIR_MGROUPS", 1), order("EMI_LEG_DIR_ORDER", 0), &lm.d_dir, &lm.n_dir))
       return EMI_ERR_RUNTIME;
     it = P.legmaps.emplace(nct, lm).first;
   }
@@ -2774,7 +2785,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
     emi_dev_memset(FBl + (size_t)lrows_call * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
     const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
     LegMaps *lmaps = bmaps[ib];
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * ((P.ndgnh + 16) & ~15) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * roundup(P.ndgnh + 1, P.esz == 4 ? 32 : 16) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);

@@ -226,6 +226,20 @@ struct LegAcc<true> {
   static EMI_DEVFN int row(int l, int i) { return (l >> 4) + 4 * i; }
 };
 
+// Loader vectors are 16 bytes in both libraries: a real2 in the fp64 one, FOUR floats in the fp32 one.  With the same six loads and
+// six LDS stores per thread a stage of the fp32 kernels therefore carries twice the rows (inverse: 16 per parity, direct: 32
+// latitudes) and twice the MFMAs, whose v_mfma_f32_16x16x4_f32 take half the cycles: the matrix phase between two barriers lasts as
+// long as in the fp64 kernels instead of half as long against the same barrier / LDS-write / first-fragment gap (round 4; the 8 / 16
+// row stages of the fp64 kernels ran the fp32 library at 0.66 - 0.69 of its matrix peak against 0.75 for fp64).
+typedef typename std::conditional<sizeof(real_t) == 8, real2, v4f>::type lgvec;
+#define LGV (16 / (int)sizeof(real_t))  // elements of a loader vector: 2 | 4
+#define LG_KR (4 * LGV)                 // k_leg_inv: rows per parity and stage: 8 | 16
+#define LG_LS (8 * LGV)                 // k_leg_dir: latitudes per stage: 16 | 32
+EMI_DEVFN real2 lg_add(real2 a, real2 b) { return cadd(a, b); }
+EMI_DEVFN real2 lg_sub(real2 a, real2 b) { return csub(a, b); }
+EMI_DEVFN v4f lg_add(v4f a, v4f b) { return a + b; }
+EMI_DEVFN v4f lg_sub(v4f a, v4f b) { return a - b; }
+
 // ---- inverse: FB[lat][m][col] = sum_n P[lat,n] W[m][n][col]; north = S+A, south = S-A
 // (leinv_mod.F90:92-186 DGEMM('N','N') x2, asre1b_mod.F90:83-102)
 // tile: 64 latitudes x 128 columns, both parities; wave (wm, wn) owns 32 lat x 64 col.
@@ -234,12 +248,12 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
   typedef typename LegAcc<WIDE>::type acc_t;
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
-  real_t *Bs = As + 2 * 8 * LG_LDA;
+  real_t *Bs = As + 2 * LG_KR * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int wm = w & 1, wn = w >> 1;
   const int ld = g.ldp[m];
   const int lat0 = lt * 64, col0 = ct * LG_BN;
-  const int nst = g.wrows[m] >> 4;
+  const int nst = g.wrows[m] / (2 * LG_KR);
 
   acc_t acc[2][2][4];
 #pragma unroll
@@ -249,53 +263,55 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[p][i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
 
-  // global -> register prefetch pointers (advance by one stage per iteration)
-  const int arow = tid >> 5, ac2 = tid & 31;
-  const real_t *pS = (const real_t *)g.P + g.offS[m] + (long long)arow * ld + lat0 + 2 * ac2;
-  const real_t *pA = (const real_t *)g.P + g.offA[m] + (long long)arow * ld + lat0 + 2 * ac2;
-  const int brow = tid >> 6, bc2 = tid & 63;  // rows brow, brow+4, brow+8, brow+12 of the stage
-  const real_t *pW = W + ((long long)g.wbase[m] + brow) * ldw + col0 + 2 * bc2;
-  const long long stepA = 8LL * ld, stepW = 16LL * ldw, rowW4 = 4LL * ldw;
-  real_t *sA0 = As + (0 * 8 + arow) * LG_LDA + 2 * ac2;
-  real_t *sA1 = As + (1 * 8 + arow) * LG_LDA + 2 * ac2;
-  // W row r of the stage -> parity r&1, k = r>>1 ; r = brow + 4*i
-  real_t *sB0 = Bs + (((brow + 0) & 1) * 8 + ((brow + 0) >> 1)) * LG_LDB + 2 * bc2;
-  real_t *sB1 = Bs + (((brow + 4) & 1) * 8 + ((brow + 4) >> 1)) * LG_LDB + 2 * bc2;
-  real_t *sB2 = Bs + (((brow + 8) & 1) * 8 + ((brow + 8) >> 1)) * LG_LDB + 2 * bc2;
-  real_t *sB3 = Bs + (((brow + 12) & 1) * 8 + ((brow + 12) >> 1)) * LG_LDB + 2 * bc2;
-  real2 ra0 = *(const real2 *)pS, ra1 = *(const real2 *)pA;
-  real2 rb0 = *(const real2 *)pW, rb1 = *(const real2 *)(pW + rowW4), rb2 = *(const real2 *)(pW + 2 * rowW4), rb3 = *(const real2 *)(pW + 3 * rowW4);
+  // global -> register prefetch pointers (advance by one stage per iteration): a panel row of the tile is 64 / LGV lanes wide, a
+  // packed spectral row 128 / LGV lanes
+  constexpr int LA = 64 / LGV, LB = LG_BN / LGV, RPP = LG_THREADS / LB;  // RPP: W rows per pass of the workgroup (4 | 8)
+  const int arow = tid / LA, ac = (tid % LA) * LGV;
+  const real_t *pS = (const real_t *)g.P + g.offS[m] + (long long)arow * ld + lat0 + ac;
+  const real_t *pA = (const real_t *)g.P + g.offA[m] + (long long)arow * ld + lat0 + ac;
+  const int brow = tid / LB, bc = (tid % LB) * LGV;  // rows brow + RPP i, i = 0..3, of the stage
+  const real_t *pW = W + ((long long)g.wbase[m] + brow) * ldw + col0 + bc;
+  const long long stepA = (long long)LG_KR * ld, stepW = 2LL * LG_KR * ldw, rowW4 = (long long)RPP * ldw;
+  real_t *sA0 = As + (0 * LG_KR + arow) * LG_LDA + ac;
+  real_t *sA1 = As + (1 * LG_KR + arow) * LG_LDA + ac;
+  // W row r of the stage -> parity r&1, k = r>>1 ; r = brow + RPP*i
+  real_t *sB0 = Bs + (((brow + 0 * RPP) & 1) * LG_KR + ((brow + 0 * RPP) >> 1)) * LG_LDB + bc;
+  real_t *sB1 = Bs + (((brow + 1 * RPP) & 1) * LG_KR + ((brow + 1 * RPP) >> 1)) * LG_LDB + bc;
+  real_t *sB2 = Bs + (((brow + 2 * RPP) & 1) * LG_KR + ((brow + 2 * RPP) >> 1)) * LG_LDB + bc;
+  real_t *sB3 = Bs + (((brow + 3 * RPP) & 1) * LG_KR + ((brow + 3 * RPP) >> 1)) * LG_LDB + bc;
+  lgvec ra0 = *(const lgvec *)pS, ra1 = *(const lgvec *)pA;
+  lgvec rb0 = *(const lgvec *)pW, rb1 = *(const lgvec *)(pW + rowW4), rb2 = *(const lgvec *)(pW + 2 * rowW4), rb3 = *(const lgvec *)(pW + 3 * rowW4);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
-    *(real2 *)sA0 = ra0;
-    *(real2 *)sA1 = ra1;
-    *(real2 *)sB0 = rb0;
-    *(real2 *)sB1 = rb1;
-    *(real2 *)sB2 = rb2;
-    *(real2 *)sB3 = rb3;
+    *(lgvec *)sA0 = ra0;
+    *(lgvec *)sA1 = ra1;
+    *(lgvec *)sB0 = rb0;
+    *(lgvec *)sB1 = rb1;
+    *(lgvec *)sB2 = rb2;
+    *(lgvec *)sB3 = rb3;
     EMI_SYNC();
     if (s + 1 < nst) {
       pS += stepA;
       pA += stepA;
       pW += stepW;
-      ra0 = *(const real2 *)pS;
-      ra1 = *(const real2 *)pA;
-      rb0 = *(const real2 *)pW;
-      rb1 = *(const real2 *)(pW + rowW4);
-      rb2 = *(const real2 *)(pW + 2 * rowW4);
-      rb3 = *(const real2 *)(pW + 3 * rowW4);
+      ra0 = *(const lgvec *)pS;
+      ra1 = *(const lgvec *)pA;
+      rb0 = *(const lgvec *)pW;
+      rb1 = *(const lgvec *)(pW + rowW4);
+      rb2 = *(const lgvec *)(pW + 2 * rowW4);
+      rb3 = *(const lgvec *)(pW + 3 * rowW4);
     }
     EMI_PRIO_HI();
 #pragma unroll
     for (int p = 0; p < 2; p++)
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
+      for (int ks = 0; ks < LG_KR / 4; ks++) {
         const int kk = 4 * ks + (l >> 4);
         real_t a[2], b[4];
 #pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = As[(p * 8 + kk) * LG_LDA + wm * 32 + i * 16 + (l & 15)];
+        for (int i = 0; i < 2; i++) a[i] = As[(p * LG_KR + kk) * LG_LDA + wm * 32 + i * 16 + (l & 15)];
 #pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = Bs[(p * 8 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
+        for (int j = 0; j < 4; j++) b[j] = Bs[(p * LG_KR + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -349,13 +365,13 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   typedef typename LegAcc<WIDE>::type acc_t;
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
-  real_t *Bs = As + 2 * 16 * LG_LDA;
+  real_t *Bs = As + 2 * LG_LS * LG_LDA;
   const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
   const int par = w & 1, wn = w >> 1;
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
-  const int nst = (ndglu + 15) >> 4;  // stages of 16 latitudes: 32 MFMAs per wave between barriers
+  const int nst = (ndglu + LG_LS - 1) / LG_LS;  // stages of 16 | 32 latitudes: 64 | 128 MFMAs per wave between barriers
   const long long wb = g.wbase[m];
 
   acc_t acc[4][4];
@@ -364,24 +380,26 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
 
-  // P^T tile: 16 latitudes x 64 k per parity, k contiguous in HBM (coalesced 512-B rows) and in LDS
-  const int arow = tid >> 5, ac2 = tid & 31;  // latitude rows arow and arow+8 of the stage
+  // P^T tile: LG_LS latitudes x 64 k per parity, k contiguous in HBM (coalesced rows) and in LDS; a row is 64 / LGV lanes wide, so the
+  // workgroup covers RA = 8 | 16 latitude rows per pass and the stage in two passes
+  constexpr int LA = 64 / LGV, RA = LG_THREADS / LA, LB = LG_BN / LGV, RB = LG_THREADS / LB;  // RB = 4 | 8 Fourier rows per pass, four passes
+  const int arow = tid / LA, ac = (tid % LA) * LGV;  // latitude rows arow and arow + RA of the stage
   const int ldk = g.ldk[m];
-  const real_t *pS = (const real_t *)g.PT + g.offTS[m] + (long long)arow * ldk + k0 + 2 * ac2;
-  const real_t *pA = (const real_t *)g.PT + g.offTA[m] + (long long)arow * ldk + k0 + 2 * ac2;
-  const long long stepA = 16LL * ldk, rowA8 = 8LL * ldk;
-  const int brow = tid >> 6, bc2 = tid & 63;  // latitude rows brow + 4 i, i = 0..3, of each stage
-  const real_t *FBc = FB + col0 + 2 * bc2;
-  real2 ra0, ra1, ra2, ra3;                      // P^T of stage s+1
-  real2 rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
+  const real_t *pS = (const real_t *)g.PT + g.offTS[m] + (long long)arow * ldk + k0 + ac;
+  const real_t *pA = (const real_t *)g.PT + g.offTA[m] + (long long)arow * ldk + k0 + ac;
+  const long long stepA = (long long)LG_LS * ldk, rowA8 = (long long)RA * ldk;
+  const int brow = tid / LB, bc = (tid % LB) * LGV;  // latitude rows brow + RB i, i = 0..3, of each stage
+  const real_t *FBc = FB + col0 + bc;
+  lgvec ra0, ra1, ra2, ra3;                      // P^T of stage s+1
+  lgvec rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
   // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
   // kernels), so each stage touches 32 far-apart rows, prefetched one stage (~2 x 2048 MFMA cycles
   // per SIMD) ahead.  Their row numbers (fbase[lat]+m) are staged once per tile in LDS, so that
   // looking them up is an LDS read (lgkmcnt) and never a vector-memory load that would order behind
   // the prefetches (vmcnt).
-  int *rowN = (int *)(Bs + 2 * 16 * LG_LDB);
-  int *rowS = rowN + 16 * nst;
-  for (int j = tid; j < 16 * nst; j += LG_THREADS) {
+  int *rowN = (int *)(Bs + 2 * LG_LS * LG_LDB);
+  int *rowS = rowN + LG_LS * nst;
+  for (int j = tid; j < LG_LS * nst; j += LG_THREADS) {
     // latitudes past the last one read row `zrow` of the buffer, a row of zeros behind the Fourier rows: no
     // branch, no select, and the row address is one 32 x 32 -> 64-bit multiply-add
     int rn_ = zrow, rs_ = zrow;
@@ -395,42 +413,42 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   EMI_SYNC();
 #define LEGDIR_LOADB(s_)                                                            \
   {                                                                                 \
-    const int j0_ = 16 * (s_) + brow;                                               \
-    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + 4], is1 = rowS[j0_ + 4];         \
-    const int in2 = rowN[j0_ + 8], is2 = rowS[j0_ + 8], in3 = rowN[j0_ + 12], is3 = rowS[j0_ + 12]; \
-    rn0 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in0 * (unsigned)ldf); \
-    rs0 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is0 * (unsigned)ldf); \
-    rn1 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in1 * (unsigned)ldf); \
-    rs1 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is1 * (unsigned)ldf); \
-    rn2 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in2 * (unsigned)ldf); \
-    rs2 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is2 * (unsigned)ldf); \
-    rn3 = *(const real2 *)(FBc + (unsigned long long)(unsigned)in3 * (unsigned)ldf); \
-    rs3 = *(const real2 *)(FBc + (unsigned long long)(unsigned)is3 * (unsigned)ldf); \
+    const int j0_ = LG_LS * (s_) + brow;                                            \
+    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + RB], is1 = rowS[j0_ + RB];         \
+    const int in2 = rowN[j0_ + 2 * RB], is2 = rowS[j0_ + 2 * RB], in3 = rowN[j0_ + 3 * RB], is3 = rowS[j0_ + 3 * RB]; \
+    rn0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in0 * (unsigned)ldf); \
+    rs0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is0 * (unsigned)ldf); \
+    rn1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in1 * (unsigned)ldf); \
+    rs1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is1 * (unsigned)ldf); \
+    rn2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in2 * (unsigned)ldf); \
+    rs2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is2 * (unsigned)ldf); \
+    rn3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in3 * (unsigned)ldf); \
+    rs3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is3 * (unsigned)ldf); \
   }
 #define LEGDIR_LOADA(s_)                                          \
   {                                                               \
-    ra0 = *(const real2 *)(pS + (s_) * stepA);                    \
-    ra1 = *(const real2 *)(pA + (s_) * stepA);                    \
-    ra2 = *(const real2 *)(pS + (s_) * stepA + rowA8);            \
-    ra3 = *(const real2 *)(pA + (s_) * stepA + rowA8);            \
+    ra0 = *(const lgvec *)(pS + (s_) * stepA);                    \
+    ra1 = *(const lgvec *)(pA + (s_) * stepA);                    \
+    ra2 = *(const lgvec *)(pS + (s_) * stepA + rowA8);            \
+    ra3 = *(const lgvec *)(pA + (s_) * stepA + rowA8);            \
   }
   LEGDIR_LOADB(0);
   LEGDIR_LOADA(0);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
     // As[par][latitude in stage][k index], Bs[par][latitude in stage][column]
-    *(real2 *)(As + (0 * 16 + arow) * LG_LDA + 2 * ac2) = ra0;
-    *(real2 *)(As + (1 * 16 + arow) * LG_LDA + 2 * ac2) = ra1;
-    *(real2 *)(As + (0 * 16 + arow + 8) * LG_LDA + 2 * ac2) = ra2;
-    *(real2 *)(As + (1 * 16 + arow + 8) * LG_LDA + 2 * ac2) = ra3;
-    *(real2 *)(Bs + (0 * 16 + brow) * LG_LDB + 2 * bc2) = cadd(rn0, rs0);  // symmetric part
-    *(real2 *)(Bs + (1 * 16 + brow) * LG_LDB + 2 * bc2) = csub(rn0, rs0);  // antisymmetric part
-    *(real2 *)(Bs + (0 * 16 + brow + 4) * LG_LDB + 2 * bc2) = cadd(rn1, rs1);
-    *(real2 *)(Bs + (1 * 16 + brow + 4) * LG_LDB + 2 * bc2) = csub(rn1, rs1);
-    *(real2 *)(Bs + (0 * 16 + brow + 8) * LG_LDB + 2 * bc2) = cadd(rn2, rs2);
-    *(real2 *)(Bs + (1 * 16 + brow + 8) * LG_LDB + 2 * bc2) = csub(rn2, rs2);
-    *(real2 *)(Bs + (0 * 16 + brow + 12) * LG_LDB + 2 * bc2) = cadd(rn3, rs3);
-    *(real2 *)(Bs + (1 * 16 + brow + 12) * LG_LDB + 2 * bc2) = csub(rn3, rs3);
+    *(lgvec *)(As + (0 * LG_LS + arow) * LG_LDA + ac) = ra0;
+    *(lgvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;
+    *(lgvec *)(As + (0 * LG_LS + arow + RA) * LG_LDA + ac) = ra2;
+    *(lgvec *)(As + (1 * LG_LS + arow + RA) * LG_LDA + ac) = ra3;
+    *(lgvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = lg_add(rn0, rs0);  // symmetric part
+    *(lgvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = lg_sub(rn0, rs0);  // antisymmetric part
+    *(lgvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = lg_add(rn1, rs1);
+    *(lgvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = lg_sub(rn1, rs1);
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = lg_add(rn2, rs2);
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = lg_sub(rn2, rs2);
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = lg_add(rn3, rs3);
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = lg_sub(rn3, rs3);
     EMI_SYNC();
     {
       // unconditional (the last stage requests its own rows again and drops them): with the loads inside an
@@ -441,13 +459,13 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
     }
     EMI_PRIO_HI();
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
+    for (int ks = 0; ks < LG_LS / 4; ks++) {
       const int kk = 4 * ks + (l >> 4);
       real_t a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[(par * 16 + kk) * LG_LDA + i * 16 + (l & 15)];
+      for (int i = 0; i < 4; i++) a[i] = As[(par * LG_LS + kk) * LG_LDA + i * 16 + (l & 15)];
 #pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[(par * 16 + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
+      for (int j = 0; j < 4; j++) b[j] = Bs[(par * LG_LS + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (FULL || i < ni) {  // the last k tile of a wavenumber: 16-row groups past the end are skipped

@@ -34,6 +34,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
   d2 ra0 = {1, 2}, ra1 = {3, 4}, rb0 = {5, 6}, rb1 = {7, 8}, rb2 = {9, 10}, rb3 = {11, 12};
   d2 qa0 = ra0, qa1 = ra1, qb0 = rb0, qb1 = rb1, qb2 = rb2, qb3 = rb3;
   double a0 = 1.0 + 1e-9 * l, b0 = 1.0 - 1e-9 * l;
+  // touch address: line (k, w, i) of a stage = load k (4 KB apart), wave w (1 KB), 128-byte line i
+  const int tt = tid < 192 ? tid : tid - 64;  // threads 192..255 repeat lines of the last loads
+  const double *gt = src + (long long)blockIdx.x * 4096 + (tt >> 5) * 512 + ((tt >> 3) & 3) * 128 + (tt & 7) * 16;
+  int tch = 0;
   for (int s = 0; s < nst; s++) {
     if (V >= 2 && s > 0) __syncthreads();
     if (V >= 3) {
@@ -46,6 +50,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
       *(d2 *)(Bs + (((brow + 12) & 1) * 8 + ((brow + 12) >> 1)) * LDB + 2 * bc2) = alt ? qb3 : rb3;
     }
     if (V >= 2) __syncthreads();
+    if (V == 23) {
+      // V23: V4 + "touch": behind the six loads of stage s+1 every thread below 192 reads ONE dword of one of the 192 lines of
+      // stage s+2 and drops it a stage later -- the line is then in L2 when the real loads of the next stage ask for it.  The
+      // touch is younger than the loads, so the waits on them (vmcnt(1) ... ) leave it outstanding; loads return in order.
+      asm volatile("" ::"v"(tch));  // the touch issued a stage ago has had a whole stage to arrive
+      const double *q = g + (long long)s * stride;
+      ra0 = *(const d2 *)q, ra1 = *(const d2 *)(q + 512), rb0 = *(const d2 *)(q + 1024), rb1 = *(const d2 *)(q + 1536);
+      rb2 = *(const d2 *)(q + 2048), rb3 = *(const d2 *)(q + 2560);
+      __builtin_amdgcn_sched_barrier(0);
+      tch = *(const int *)(gt + (long long)(s + 1) * stride);  // every thread (no branch: the compiler must be able to count it)
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (V == 4 || V == 6) {
       const double *q = g + (V == 6 ? 0 : (long long)s * stride);  // V6: the same lines every stage (cache hits)
       ra0 = *(const d2 *)q, ra1 = *(const d2 *)(q + 512), rb0 = *(const d2 *)(q + 1024), rb1 = *(const d2 *)(q + 1536);
@@ -83,7 +99,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
           for (int j = 0; j < 4; j++) acc[p][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[p][i][j], 0, 0, 0);
       }
   }
-  double sum = ra0.x + rb3.y + qa0.x + qb3.y;
+  double sum = ra0.x + rb3.y + qa0.x + qb3.y + tch;
   for (int p = 0; p < 2; p++)
     for (int i = 0; i < 2; i++)
       for (int j = 0; j < 4; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
@@ -305,6 +321,131 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
   out[(long long)blockIdx.x * 512 + threadIdx.x] = sum;
 }
 
+// V20-V22 "four waves per SIMD": the same 64 x 128 x two-parity tile and 8-row stages on a 512-thread workgroup (8 waves, wave
+// (wm, wn) owns 32 latitudes x 32 columns of both parities: 8 accumulator fragments = 64 registers), two workgroups per CU =
+// 16 waves, 128 registers each.  More waves to fill the matrix pipe while others sit in barriers / LDS phases; per MFMA one
+// ds_read_b64 instead of 0.75.  MODE 0: MFMAs only, 1: full loop with HBM-jumping loads, 2: full loop with cache hits.
+template <int MODE>
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(4, 4))) void probe_w4(double *out, const double *src, int nst, long long stride) {
+  extern __shared__ double lds[];
+  double *As = lds, *Bs = lds + 2 * 8 * LDA;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
+  for (int i = tid; i < 2 * 8 * LDA + 2 * 8 * LDB; i += 512) lds[i] = 1.0 + 1e-9 * i;
+  __syncthreads();
+  v4d acc[2][2][2];
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) acc[p][i][j] = (v4d){0, 0, 0, 0};
+  // loader: A = 2 parities x 8 k x 64 latitudes = 512 x 16 B (one per thread); B = 16 rows x 128 columns = 1024 x 16 B (two per thread)
+  const int apar = tid >> 8, arow = (tid >> 5) & 7, ac2 = tid & 31, brow = tid >> 6, bc2 = tid & 63;
+  const double *g = src + (long long)blockIdx.x * 4096 + tid * 2;
+  d2 ra0 = {1, 2}, rb0 = {5, 6}, rb1 = {7, 8};
+  double a0 = 1.0 + 1e-9 * l, b0 = 1.0 - 1e-9 * l;
+  for (int s = 0; s < nst; s++) {
+    if (MODE >= 1) {
+      if (s > 0) __syncthreads();
+      *(d2 *)(As + (apar * 8 + arow) * LDA + 2 * ac2) = ra0;
+      *(d2 *)(Bs + (((brow + 0) & 1) * 8 + ((brow + 0) >> 1)) * LDB + 2 * bc2) = rb0;
+      *(d2 *)(Bs + (((brow + 8) & 1) * 8 + ((brow + 8) >> 1)) * LDB + 2 * bc2) = rb1;
+      __syncthreads();
+      const double *q = g + (MODE == 2 ? 0 : (long long)s * stride);
+      ra0 = *(const d2 *)q, rb0 = *(const d2 *)(q + 1024), rb1 = *(const d2 *)(q + 2048);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int kk = 4 * ks + (l >> 4);
+        double a[2], b[2];
+        if (MODE >= 1) {
+#pragma unroll
+          for (int i = 0; i < 2; i++) a[i] = As[(p * 8 + kk) * LDA + wm * 32 + i * 16 + (l & 15)];
+#pragma unroll
+          for (int j = 0; j < 2; j++) b[j] = Bs[(p * 8 + kk) * LDB + wn * 32 + j * 16 + (l & 15)];
+        } else {
+          a[0] = a[1] = a0;
+          b[0] = b[1] = b0;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[p][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[p][i][j], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  double sum = ra0.x + rb0.y + rb1.x;
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
+  out[(long long)blockIdx.x * 512 + tid] = sum;
+}
+
+// V30-V35 "one big workgroup per CU": 256 threads = one wave per SIMD with the whole register file (256 arch + 256 accumulator
+// registers), tile 128 latitudes x 128 columns x two parities (wave (wm, wn): 64 x 64 of both parities = 32 accumulator fragments),
+// stages of 8 KS rows per parity = 64 KS MFMAs per wave between barriers.  16 flop per byte fetched instead of 10.9; nothing else
+// on the SIMD to cover a gap, so the loop itself has to be tight.  MODE 0: MFMAs only, 1: HBM-jumping loads, 2: cache hits.
+#define LDB2 144
+template <int MODE, int KS>
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 1))) void probe_big(double *out, const double *src, int nst, long long stride) {
+  extern __shared__ double lds[];
+  constexpr int KR = 8 * KS;  // rows per parity and stage
+  double *As = lds, *Bs = lds + 2 * KR * LDB2;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
+  for (int i = tid; i < 4 * KR * LDB2; i += 256) lds[i] = 1.0 + 1e-9 * i;
+  __syncthreads();
+  v4d acc[2][4][4];
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) acc[p][i][j] = (v4d){0, 0, 0, 0};
+  const int row = tid >> 6, c2 = tid & 63;  // loader: rows row + 4 i of A (2 KR rows of 128) and of B (2 KR rows of 128)
+  const double *g = src + (long long)blockIdx.x * 8192 + tid * 2;
+  d2 ra[4 * KS], rb[4 * KS];
+  for (int i = 0; i < 4 * KS; i++) ra[i] = (d2){1.0, 2.0}, rb[i] = (d2){3.0, 4.0};
+  double a0 = 1.0 + 1e-9 * l, b0 = 1.0 - 1e-9 * l;
+  for (int s = 0; s < nst; s++) {
+    if (MODE >= 1) {
+      if (s > 0) __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4 * KS; i++) {
+        *(d2 *)(As + (row + 4 * i) * LDB2 + 2 * c2) = ra[i];
+        *(d2 *)(Bs + (row + 4 * i) * LDB2 + 2 * c2) = rb[i];
+      }
+      __syncthreads();
+      const double *q = g + (MODE == 2 ? 0 : (long long)s * stride);
+#pragma unroll
+      for (int i = 0; i < 4 * KS; i++) ra[i] = *(const d2 *)(q + i * 512), rb[i] = *(const d2 *)(q + (4 * KS + i) * 512);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int ks = 0; ks < 2 * KS; ks++) {
+        const int kk = 4 * ks + (l >> 4);
+        double a[4], b[4];
+        if (MODE >= 1) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) a[i] = As[(p * KR + kk) * LDB2 + wm * 64 + i * 16 + (l & 15)];
+#pragma unroll
+          for (int j = 0; j < 4; j++) b[j] = Bs[(p * KR + kk) * LDB2 + wn * 64 + j * 16 + (l & 15)];
+        } else {
+          a[0] = a[1] = a[2] = a[3] = a0;
+          b[0] = b[1] = b[2] = b[3] = b0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[p][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[p][i][j], 0, 0, 0);
+      }
+  }
+  double sum = ra[0].x + rb[0].y;
+  for (int p = 0; p < 2; p++)
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
+  out[(long long)blockIdx.x * 256 + tid] = sum;
+}
+
 template <int V>
 static void run(double *out, const double *src, const char *what, int nst = 80) {
   const int nblk = 256 * 2 * 8;  // 16 tiles per CU-slot; nst = 80: K = 640 n-pairs
@@ -314,7 +455,13 @@ static void run(double *out, const double *src, const char *what, int nst = 80) 
   float best = 1e30f;
   for (int rep = 0; rep < 4; rep++) {
     hipEventRecord(e0, 0);
-    if (V >= 14 && V <= 17)
+    if (V >= 30 && V <= 35) {
+      // nblk / 2 workgroups of twice the tile; nst counts 8-row stages, so KS = 2 runs nst / 2 of them: the flop count below holds
+      constexpr int KS = V >= 33 ? 2 : 1;
+      hipLaunchKernelGGL((probe_big<(V - 30) % 3, KS>), dim3(nblk / 2), dim3(256), 4 * 8 * KS * LDB2 * 8, 0, out, src, nst / KS, (long long)8192 * (nblk / 2) / 64 * KS);
+    } else if (V >= 20 && V <= 22)
+      hipLaunchKernelGGL((probe_w4<V - 20>), dim3(nblk), dim3(512), (2 * 8 * LDA + 2 * 8 * LDB) * 8, 0, out, src, nst, (long long)4096 * nblk / 64);
+    else if (V >= 14 && V <= 17)
       hipLaunchKernelGGL((probe_pp<(V & 1), (V >= 16)>), dim3(nblk / 2), dim3(512), 2 * (2 * 8 * LDA + (V >= 16 ? 4 : 2) * 8 * LDB) * 8, 0, out, src, nst,
                          (long long)4096 * nblk / 64);
     else if (V == 8 || V == 9)
@@ -339,13 +486,30 @@ static void run(double *out, const double *src, const char *what, int nst = 80) 
 
 int main() {
   double *out, *src;
-  hipMalloc((void **)&out, (size_t)4096 * 256 * 8);
+  hipMalloc((void **)&out, (size_t)4096 * 512 * 8);
   hipMalloc((void **)&src, (size_t)1 << 30);
   hipMemset(src, 0, (size_t)1 << 30);
   if (getenv("PROBE_RANDOM")) {  // operand tiles with random mantissas: the matrix cores' power draw is data dependent
     int one = 1;
     hipMemcpyToSymbol(HIP_SYMBOL(g_random_operands), &one, sizeof(int));
     printf("random operand values in LDS (V1-V3 read them; V4+ overwrite them with the zero-filled source)\n");
+  }
+  if (getenv("PROBE_ONLY_W4")) {
+    run<0>(out, src, "MFMAs only");
+    run<4>(out, src, "+ global prefetch of the next stage");
+    run<6>(out, src, "V4 with the same lines every stage (hits)");
+    run<23>(out, src, "V4 + touch of stage s+2 behind the loads of s+1");
+    run<30>(out, src, "big tile, 1 wave/SIMD: MFMAs only");
+    run<31>(out, src, "big tile, 1 wave/SIMD: full loop, HBM-jumping loads");
+    run<32>(out, src, "big tile, 1 wave/SIMD: full loop, cache hits");
+    run<34>(out, src, "big tile, 16-row stages: HBM-jumping loads");
+    run<35>(out, src, "big tile, 16-row stages: cache hits");
+    run<20>(out, src, "four waves per SIMD: MFMAs only");
+    run<21>(out, src, "four waves per SIMD: full loop, HBM-jumping loads");
+    run<22>(out, src, "four waves per SIMD: full loop, cache hits");
+    run<4>(out, src, "V4 short tiles", 20);
+    run<21>(out, src, "V21 short tiles", 20);
+    return 0;
   }
   run<0>(out, src, "MFMAs only");
   run<1>(out, src, "+ LDS fragment reads");
