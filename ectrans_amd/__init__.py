@@ -127,6 +127,8 @@ def _bind(L):
     L.emi_last_phase_ms.argtypes = [dp]
     L.emi_set_max_batch.argtypes = [C.c_int]
     L.emi_specnorm_partial.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, dp]
+    L.emi_gpnorm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_int]
+    L.emi_vordiv_to_uv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.emi_specnorm_kvset.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, dp]
     L.emi_set_alltoallv.argtypes = [C.c_void_p, C.c_void_p]
     L.emi_set_profile.argtypes = [C.c_int]
@@ -499,6 +501,43 @@ def specnorm(kresol, pspec, kvset=None):
     from . import dist as _dist
     _chk(lib().emi_specnorm_partial(kresol, space[0], p, pspec.shape[1], pd(out)))
     return np.sqrt(_dist.all_reduce_sum(out, _DIST["group"], _DIST["device"]))  # every task gets the norms
+
+
+def gpnorm_trans(kresol, pgp, kfields=None, kproma=None, ldave_only=False, pmin=None, pmax=None):
+    """GPNORM_TRANS (gpnorm_trans.h:12): (PAVE, PMIN, PMAX) of the first `kfields` fields of pgp[ngpblks, nfld, nproma] -- the
+    area-weighted average over the sphere (Gaussian weights), minimum and maximum -- as numpy arrays, on every task (the
+    reference: task 1).  ldave_only: pmin / pmax are the caller's local extrema and are only reduced over the tasks."""
+    space = [None, real_dtype(kresol)]
+    p, keep = _ptr(pgp, space)
+    if pgp.ndim != 3:
+        raise TransError("PGP must have 3 dimensions (ngpblks, fields, nproma), got shape %s" % (tuple(pgp.shape),))
+    nf = int(pgp.shape[1]) if kfields is None else int(kfields)
+    nproma = int(kproma) if kproma else int(pgp.shape[2])
+    ave, mn, mx = np.zeros(nf), np.zeros(nf), np.zeros(nf)
+    if ldave_only:
+        mn[:], mx[:] = np.asarray(pmin, dtype=np.float64)[:nf], np.asarray(pmax, dtype=np.float64)[:nf]
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    _chk(lib().emi_gpnorm(kresol, space[0], p, int(pgp.shape[1]), nf, nproma, pd(ave), pd(mn), pd(mx), int(bool(ldave_only))))
+    return ave, mn, mx
+
+
+def vordiv_to_uv(pspvor, pspdiv, ksmax, pspu=None, pspv=None):
+    """VORDIV_TO_UV (vordiv_to_uv.h:12): spectral vorticity / divergence [nspec2, nfld] -> spectral (U, V) = (u, v) cos(theta), total
+    wavenumbers n <= ksmax, for the zonal wavenumbers of this task.  Needs setup_trans0 only; returns (pspu, pspv)."""
+    is64 = str(pspvor.dtype).endswith("float64")
+    space = [None, "float64" if is64 else "float32"]
+    pv_, k1 = _ptr(pspvor, space)
+    pd_, k2 = _ptr(pspdiv, space)
+    if pspu is None:
+        pspu = pspvor.clone() if _is_torch(pspvor) else np.zeros_like(pspvor)
+    if pspv is None:
+        pspv = pspvor.clone() if _is_torch(pspvor) else np.zeros_like(pspvor)
+    pu_, k3 = _ptr(pspu, space)
+    pw_, k4 = _ptr(pspv, space)
+    if not (tuple(pspvor.shape) == tuple(pspdiv.shape) == tuple(pspu.shape) == tuple(pspv.shape)) or pspvor.ndim != 2:
+        raise TransError("VORDIV_TO_UV: PSPVOR, PSPDIV, PSPU, PSPV must be [nspec2, nfld] arrays of one shape")
+    _chk(lib().emi_vordiv_to_uv(int(ksmax), 8 if is64 else 4, space[0], pv_, pd_, pu_, pw_, int(pspvor.shape[1])))
+    return pspu, pspv
 
 
 # ---------------------------------------------------------------------------------------------

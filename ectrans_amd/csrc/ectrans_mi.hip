@@ -2924,6 +2924,143 @@ extern "C" int emi_specnorm_partial(int kresol, int mem_space, const void *spec,
   return specnorm_sumsq(*Pp, mem_space, spec, nfld, sumsq);
 }
 
+// GPNORM_TRANS (cpu/external/gpnorm_trans.F90:11-96, cpu/internal/gpnorm_trans_ctl_mod.F90): area-weighted average, minimum and maximum of
+// `kfields` grid fields of PGP(nproma, gp_nfld, ngpblks).  Per latitude the sum over the longitudes in double times RW / NLOEN on the
+// task that holds the latitude (whole latitudes here, so the reference's TRGTOL is not needed); the per-latitude values of all tasks
+// are gathered and summed in latitude order on every task (the reference: on task 1), so the average does not depend on the
+// decomposition.  ave_only (LDAVE_ONLY): pmin / pmax come in as the caller's local extrema and are only reduced over the tasks.
+extern "C" int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld, int kfields, int kproma, double *ave, double *pmin, double *pmax,
+                          int ave_only) {
+  Plan *Pp = get_plan(kresol);
+  if (!Pp) EMI_FAIL(EMI_ERR_STATE, "GPNORM_TRANS: unknown resolution %d", kresol);
+  Plan &P = *Pp;
+  if (kfields <= 0 || !gp || !ave || !pmin || !pmax) EMI_FAIL(EMI_ERR_ARG, "GPNORM_TRANS: bad arguments");
+  if (gp_nfld < kfields) EMI_FAIL(EMI_ERR_ARG, "GPNORM_TRANS_CTL:SECOND DIMENSION OF PGP TOO SMALL (%d < %d)", gp_nfld, kfields);
+  if (G.nproc_all > 1 && !G.hc_gather) EMI_FAIL(EMI_ERR_STATE, "GPNORM_TRANS: several tasks and no host collectives (emi_set_host_collectives)");
+  const int j0 = P.vfirst(P.me, P.mev), j1 = P.vlast(P.me, P.mev), nl = j1 - j0;
+  std::vector<int> rowoff(nl + 1, 0);
+  for (int j = 0; j < nl; j++) rowoff[j + 1] = rowoff[j] + P.nloen[j0 + j];
+  const long long myp = rowoff[nl];
+  const int nproma = kproma > 0 ? kproma : (int)std::max<long long>(myp, 1);
+  const long long ngpblks = myp > 0 ? (myp - 1) / nproma + 1 : 0;
+  std::vector<double> loc((size_t)3 * kfields * std::max(nl, 1), 0.0);
+  if (nl > 0) {
+    HostStage hs(P.esz);
+    if (plan_begin(P, (emi_stream_t)0)) return EMI_ERR_RUNTIME;  // behind the transform that produced the fields
+    const void *d_gp = hs.in(gp, (size_t)nproma * gp_nfld * ngpblks, mem_space == EMI_MEM_HOST, 0);
+    int *d_off = nullptr;
+    void *d_out = nullptr;
+    if (hs.failed || upload(rowoff, &d_off) || emi_dev_malloc(&d_out, loc.size() * 8)) {
+      emi_dev_free(d_off);
+      EMI_FAIL(EMI_ERR_RUNTIME, "GPNORM_TRANS: no device memory (%s)", emi_last_error());
+    }
+    EMI_LAUNCH_P(P.esz, k_gpnorm, (long long)nl * kfields, 256, 3 * 256 * 8, (emi_stream_t)0, (const int *)d_off, nl, (const RT *)d_gp, gp_nfld, kfields, nproma,
+                 (double *)d_out);
+    emi_d2h(loc.data(), d_out, loc.size() * 8, 0);
+    emi_stream_sync(0);
+    emi_dev_free(d_off);
+    emi_dev_free(d_out);
+  }
+  // this task's block: [field][latitude] RW / NLOEN x row sums, then the field minima and maxima
+  const size_t nn = (size_t)kfields * nl;
+  std::vector<double> blk(nn + 2 * (size_t)kfields);
+  for (int f = 0; f < kfields; f++) {
+    double mn = ave_only ? pmin[f] : 0.0, mx = ave_only ? pmax[f] : 0.0;
+    for (int j = 0; j < nl; j++) {
+      const double rwj = P.esz == 4 ? (double)(float)P.rw[j0 + j] : P.rw[j0 + j];  // REAL(PW(IGL),JPRB), gpnorm_trans_ctl_mod.F90:206
+      blk[(size_t)f * nl + j] = loc[(size_t)f * nl + j] * rwj / (double)P.nloen[j0 + j];
+      if (!ave_only) {
+        const double a = loc[nn + (size_t)f * nl + j], b = loc[2 * nn + (size_t)f * nl + j];
+        mn = j == 0 ? a : std::min(mn, a), mx = j == 0 ? b : std::max(mx, b);
+      }
+    }
+    blk[nn + f] = mn, blk[nn + kfields + f] = mx;
+  }
+  const int NA = G.nproc_all;
+  std::vector<double> all;
+  std::vector<long long> cnt(NA, 0), dsp(NA, 0);
+  std::vector<int> nlat_of(NA, 0);
+  if (NA > 1) {
+    long long tot = 0;
+    for (int w = 0; w < P.nproc; w++)
+      for (int v = 0; v < P.nprv; v++) {
+        const int t = w * P.nprv + v;
+        nlat_of[t] = P.vlast(w, v) - P.vfirst(w, v);
+        cnt[t] = 8LL * ((long long)kfields * nlat_of[t] + 2 * kfields), dsp[t] = tot, tot += cnt[t];
+      }
+    all.resize((size_t)(tot / 8));
+    if (G.hc_gather(G.hc_user, blk.data(), cnt[G.myproc_all - 1], all.data(), cnt.data(), dsp.data(), NA)) EMI_FAIL(EMI_ERR_RUNTIME, "GPNORM_TRANS: all-gather-v failed");
+  } else {
+    nlat_of[0] = nl, cnt[0] = 8LL * (long long)blk.size();
+    all = blk;
+  }
+  for (int f = 0; f < kfields; f++) {  // latitude order = task order (bands and sub-bands ascend with the task number)
+    double a = 0.0, mn = 0.0, mx = 0.0;
+    bool first = true;
+    for (int t = 0; t < NA; t++) {
+      const double *b = all.data() + dsp[t] / 8;
+      const int nlt = nlat_of[t];
+      for (int j = 0; j < nlt; j++) a += b[(size_t)f * nlt + j];
+      if (nlt > 0 || ave_only) {
+        const double tmn = b[(size_t)kfields * nlt + f], tmx = b[(size_t)kfields * nlt + kfields + f];
+        mn = first ? tmn : std::min(mn, tmn), mx = first ? tmx : std::max(mx, tmx), first = false;
+      }
+    }
+    ave[f] = a, pmin[f] = mn, pmax[f] = mx;
+  }
+  return EMI_SUCCESS;
+}
+
+// VORDIV_TO_UV (cpu/external/vordiv_to_uv.F90:11-178): spectral vorticity / divergence -> spectral U = u cos(theta), V = v cos(theta), for the
+// wavenumbers of this task's W-set (suwavedi_mod.F90:118-137), n <= KSMAX.  Needs SETUP_TRANS0 only (the reference sets up and releases a
+// spectral-only resolution inside the call); precision: 8 or 4 bytes per real of the four arrays PSP*(nfld, nspec2).
+extern "C" int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const void *spvor, const void *spdiv, void *spu, void *spv, int nfld) {
+  if (!G.init) EMI_FAIL(EMI_ERR_STATE, "VORDIV_TO_UV: SETUP_TRANS0 has not been called");
+  if (ksmax < 0 || (precision != 8 && precision != 4)) EMI_FAIL(EMI_ERR_ARG, "VORDIV_TO_UV: bad arguments (KSMAX = %d, precision = %d)", ksmax, precision);
+  if (nfld <= 0) return EMI_SUCCESS;
+  if (!spvor || !spdiv || !spu || !spv) EMI_FAIL(EMI_ERR_ARG, "VORDIV_TO_UV : PSPVOR / PSPDIV / PSPU / PSPV MISSING");
+  const int N = ksmax, NP = G.nproc, me = G.myproc - 1;
+  std::vector<int> mval, nasm0, ebase, pairm;
+  std::vector<double> eps, lapin(N + 4, 0.0);
+  {
+    int ik = 0, ind = 1, ipos = 0;
+    for (int m = 0; m <= N; m++) {  // the zig-zag of SETUP_TRANS (suwavedi_mod.F90:118-137)
+      ik += ind;
+      if (ik > NP) ik = NP, ind = -1;
+      else if (ik < 1) ik = 1, ind = 1;
+      if (ik - 1 != me) continue;
+      const int ml = (int)mval.size();
+      mval.push_back(m), nasm0.push_back(ipos), ebase.push_back((int)eps.size());
+      for (int n = m; n <= N; n++) pairm.push_back(ml);
+      ipos += 2 * (N - m + 1);
+      for (int n = m; n <= N + 2; n++) eps.push_back(std::sqrt((double)(n * n - m * m) / (double)(4 * n * n - 1)));  // REPSNM (pre_suleg_mod.F90:55-63)
+    }
+  }
+  for (int n = 1; n <= N + 2; n++) lapin[n + 1] = -(G.ra * G.ra / (double)(n * (n + 1)));  // RLAPIN (pre_suleg_mod.F90:64-69)
+  const int nspec2 = 2 * (int)pairm.size();
+  if (nspec2 == 0) return EMI_SUCCESS;
+  HostStage hs(precision);
+  const bool host = mem_space == EMI_MEM_HOST;
+  const void *d_vor = hs.in(spvor, (size_t)nspec2 * nfld, host, 0), *d_div = hs.in(spdiv, (size_t)nspec2 * nfld, host, 0);
+  void *d_u = hs.out(spu, (size_t)nspec2 * nfld, host), *d_v = hs.out(spv, (size_t)nspec2 * nfld, host);
+  int *d_pairm = nullptr, *d_mval = nullptr, *d_nasm0 = nullptr, *d_ebase = nullptr;
+  double *d_eps = nullptr, *d_lapin = nullptr;
+  int rc = EMI_SUCCESS;
+  if (hs.failed || upload(pairm, &d_pairm) || upload(mval, &d_mval) || upload(nasm0, &d_nasm0) || upload(ebase, &d_ebase) || upload(eps, &d_eps) ||
+      upload(lapin, &d_lapin)) {
+    emi_set_error("VORDIV_TO_UV: no device memory");
+    rc = EMI_ERR_RUNTIME;
+  } else {
+    Vd2uvDev d{d_pairm, d_mval, d_nasm0, d_ebase, d_eps, d_lapin, N, nspec2, nfld, 1.0 / G.ra};
+    const long long nthr = (long long)(nspec2 / 2) * nfld;
+    EMI_LAUNCH_P(precision, k_vd2uv, (nthr + 255) / 256, 256, 0, (emi_stream_t)0, d, (const RT *)d_vor, (const RT *)d_div, (RT *)d_u, (RT *)d_v);
+    hs.flush(0);
+    emi_stream_sync(0);
+  }
+  for (void *q : {(void *)d_pairm, (void *)d_mval, (void *)d_nasm0, (void *)d_ebase, (void *)d_eps, (void *)d_lapin}) emi_dev_free(q);
+  return rc;
+}
+
 extern "C" int emi_work_model(int kresol, int nfields, double *leg, double *fft, double *fbytes) {
   Plan *Pp = get_plan(kresol);
   if (!Pp) EMI_FAIL(EMI_ERR_STATE, "emi_work_model: unknown resolution %d", kresol);

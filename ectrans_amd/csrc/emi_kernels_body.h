@@ -2242,5 +2242,72 @@ EMI_KERNEL_LB(256) void k_specnorm(EmiGeomDev g, long long nspec2, const real_t 
   if (EMI_TID == 0) out[f] = red[0];  // sum of squares; the host takes the root (after the task sum)
 }
 
+// ==========================================================================================
+// k_gpnorm: GPNORM_TRANS_CTL (cpu/internal/gpnorm_trans_ctl_mod.F90:170-210): for one (latitude, field) the sum over the longitudes
+// of the row, accumulated in double (the reference's ZAVE is JPRD), and the row's minimum and maximum.  One workgroup per
+// (latitude, field); a fixed reduction tree, so the result does not depend on the decomposition.  out: [3][nfld][nlat].
+// ==========================================================================================
+EMI_KERNEL_LB(256) void k_gpnorm(const int *rowoff /* [nlat + 1] first local point of every latitude */, int nlat, const real_t *gp, int nf_arr,
+                                 int nfld, int nproma, double *out) {
+  EMI_LDS_DECL;
+  double *red = (double *)EMI_LDS_PTR;
+  const int f = EMI_BID / nlat, j = EMI_BID - f * nlat;
+  const int p0 = rowoff[j], n = rowoff[j + 1] - p0;
+  double s = 0.0, mn = 0.0, mx = 0.0;
+  bool any = false;
+  for (int i = EMI_TID; i < n; i += EMI_NTHREADS) {
+    const long long p = (long long)p0 + i, blk = p / nproma;
+    const double v = (double)gp[(blk * nf_arr + f) * nproma + (p - blk * nproma)];
+    s += v;
+    mn = any ? (v < mn ? v : mn) : v;
+    mx = any ? (v > mx ? v : mx) : v;
+    any = true;
+  }
+  if (!any) mn = mx = (double)gp[((long long)(p0 / nproma) * nf_arr + f) * nproma + p0 % nproma];  // rows are never empty: the first point
+  const int T = EMI_NTHREADS;
+  red[EMI_TID] = s, red[T + EMI_TID] = mn, red[2 * T + EMI_TID] = mx;
+  EMI_SYNC();
+  for (int st = T / 2; st > 0; st >>= 1) {
+    if (EMI_TID < st) {
+      red[EMI_TID] += red[EMI_TID + st];
+      red[T + EMI_TID] = red[T + EMI_TID] < red[T + EMI_TID + st] ? red[T + EMI_TID] : red[T + EMI_TID + st];
+      red[2 * T + EMI_TID] = red[2 * T + EMI_TID] > red[2 * T + EMI_TID + st] ? red[2 * T + EMI_TID] : red[2 * T + EMI_TID + st];
+    }
+    EMI_SYNC();
+  }
+  if (EMI_TID == 0) {
+    const long long o = (long long)f * nlat + j, nn = (long long)nfld * nlat;
+    out[o] = red[0], out[nn + o] = red[T], out[2 * nn + o] = red[2 * T];
+  }
+}
+
+// ==========================================================================================
+// k_vd2uv: VORDIV_TO_UV (cpu/external/vordiv_to_uv.F90 -> cpu/internal/vd2uv_mod.F90:79-120 = PRFI1B + VDTUV, vdtuv_mod.F90:97-143):
+//   U_n = i m L_n D_n + (n-1) e_n L_(n-1) vor_(n-1) - (n+2) e_(n+1) L_(n+1) vor_(n+1)
+//   V_n = i m L_n vor_n - (n-1) e_n L_(n-1) D_(n-1) + (n+2) e_(n+1) L_(n+1) D_(n+1),   L_n = RLAPIN(n) = -a^2 / (n (n+1)),
+// coefficients n <= NSMAX, times 1 / a.  One thread per (spectral pair, field); no resolution handle is needed, only NSMAX and
+// the wavenumbers of the task (the reference sets up a spectral-only resolution for the call).
+// ==========================================================================================
+EMI_KERNEL_LB(256) void k_vd2uv(Vd2uvDev d, const real_t *vor, const real_t *div, real_t *pu, real_t *pv) {
+  const long long gi = (long long)EMI_BID * EMI_NTHREADS + EMI_TID;
+  const int ip = (int)(gi / d.nfld), f = (int)(gi - (long long)ip * d.nfld);
+  if (ip >= d.nspec2 / 2) return;
+  const int ml = d.pairm[ip], m = d.mval[ml], N = d.nsmax;
+  const long long isp = 2LL * ip;  // Re(m, n)
+  const int n = m + (int)((isp - d.nasm0[ml]) >> 1);
+  const double *eps = d.eps + d.ebase[ml] - m;
+  auto get = [&](const real_t *a, long long i) { return mk2(a[i * d.nfld + f], m == 0 ? (real_t)0.0 : a[(i + 1) * d.nfld + f]); };
+  const real_t zkm = (real_t)m, l_n = (real_t)d.lapin[n + 1], l_nm1 = (real_t)d.lapin[n], l_np1 = (real_t)d.lapin[n + 2];
+  const real_t c1 = (real_t)(n - 1) * (real_t)eps[n] * l_nm1, c2 = (real_t)(n + 2) * (real_t)eps[n + 1] * l_np1, ra = (real_t)d.rra;
+  const real2 z = mk2(0, 0);
+  const real2 vm = n - 1 >= m ? get(vor, isp - 2) : z, vp = n + 1 <= N ? get(vor, isp + 2) : z, v0 = get(vor, isp);
+  const real2 dm = n - 1 >= m ? get(div, isp - 2) : z, dp = n + 1 <= N ? get(div, isp + 2) : z, d0 = get(div, isp);
+  real2 u = mk2(-zkm * l_n * d0.y + (c1 * vm.x - c2 * vp.x), zkm * l_n * d0.x + (c1 * vm.y - c2 * vp.y));
+  real2 v = mk2(-zkm * l_n * v0.y - (c1 * dm.x - c2 * dp.x), zkm * l_n * v0.x - (c1 * dm.y - c2 * dp.y));
+  if (m == 0) u.y = 0.0, v.y = 0.0;
+  pu[isp * d.nfld + f] = u.x * ra, pu[(isp + 1) * d.nfld + f] = u.y * ra;
+  pv[isp * d.nfld + f] = v.x * ra, pv[(isp + 1) * d.nfld + f] = v.y * ra;
+}
+
 #undef FROW
 #undef emi_mfma_f64_16x16x4

@@ -38,6 +38,17 @@ struct EmiGeomDev {
   const double *specw;         // [nspec2 local] SPECNORM weight of every spectral entry (0, 1 or 2)
 };
 
+// k_vd2uv (VORDIV_TO_UV): spectral tables of one task, no resolution handle
+struct Vd2uvDev {
+  const int *pairm;     // [nspec2 / 2] local wavenumber number of every (Re, Im) pair
+  const int *mval;      // [nump]
+  const int *nasm0;     // [nump] 0-based
+  const int *ebase;     // [nump] index of eps(n = m) in eps[] (n = m .. N+2)
+  const double *eps, *lapin;  // REPSNM; RLAPIN(n) at [n + 1]
+  int nsmax, nspec2, nfld;
+  double rra;           // 1 / RA
+};
+
 struct LegPolDev {  // SETUP_TRANS on the device: inputs of k_legpol
   const double *mu;        // [ndgnh] Gaussian latitudes (sin) of the northern hemisphere, pole first
   const double *dcl, *ddl;  // [nump][nmax+1] recurrence coefficients of SUPOLF (supolf_mod.F90:79-83), index n

@@ -453,6 +453,23 @@ int trans_specnorm(struct SpecNorm_t *s) {
   return emi_specnorm(s->trans->handle, EMI_MEM_HOST, s->rspec, s->nfld, s->rnorm) ? TRANS_ERROR : TRANS_SUCCESS;
 }
 
+struct VorDivToUV_t new_vordiv_to_UV(void) {
+  struct VorDivToUV_t v;
+  memset(&v, 0, sizeof(v));
+  return v;
+}
+/* transi_module.F90:2663-2740: the same argument checks, then VORDIV_TO_UV(RSPVOR, RSPDIV, RSPU, RSPV, NSMAX) */
+int trans_vordiv_to_UV(struct VorDivToUV_t *v) {
+  if (v->count++ > 0) return TRANS_STALE_ARG;
+  if (v->ncoeff == 0 || v->nsmax == 0) return TRANS_MISSING_ARG;
+  if (!v->rspvor || !v->rspdiv || !v->rspu || !v->rspv) return TRANS_MISSING_ARG;
+  if (!g_init) {
+    const int rc = trans_init();
+    if (rc) return rc;
+  }
+  return emi_vordiv_to_uv(v->nsmax, 8, EMI_MEM_HOST, v->rspvor, v->rspdiv, v->rspu, v->rspv, v->nfld) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+
 int trans_delete(struct Trans_t *t) {
   int rc = TRANS_SUCCESS;
   if (t->handle) rc = emi_release(t->handle) ? TRANS_ERROR : TRANS_SUCCESS;

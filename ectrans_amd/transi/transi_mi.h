@@ -178,6 +178,16 @@ struct DistSpec_t new_distspec(struct Trans_t *);
 int trans_distspec(struct DistSpec_t *);
 struct GathSpec_t new_gathspec(struct Trans_t *);
 int trans_gathspec(struct GathSpec_t *);
+/* trans_vordiv_to_UV (src/transi/transi.h:620-648, 1189-1217): spectral vorticity / divergence -> spectral U, V (u cos, v cos), local
+ * arrays [ncoeff = nspec2][nfld]; no Trans_t handle, only the truncation */
+struct VorDivToUV_t {
+  const double *rspvor, *rspdiv;
+  double *rspu, *rspv;
+  int nfld, nsmax, ncoeff;
+  int count;
+};
+struct VorDivToUV_t new_vordiv_to_UV(void);
+int trans_vordiv_to_UV(struct VorDivToUV_t *);
 struct SpecNorm_t new_specnorm(struct Trans_t *);
 int trans_specnorm(struct SpecNorm_t *);
 int trans_delete(struct Trans_t *);

@@ -263,6 +263,20 @@ int emi_trim_cache(void);
 
 const char *emi_last_error(void);
 
+/* ---- GPNORM_TRANS (trans/include/ectrans/gpnorm_trans.h:12, cpu/internal/gpnorm_trans_ctl_mod.F90) ---------------------------
+ * Area-weighted average, minimum and maximum of the first `kfields` fields of PGP(nproma, gp_nfld, ngpblks) on this task's grid
+ * points: per latitude the sum over the longitudes (in double) x RW(lat) / NLOEN(lat), summed over ALL latitudes of the sphere
+ * in latitude order (every task gets the result; the reference fills it on task 1).  ave_only != 0 (LDAVE_ONLY): pmin / pmax hold
+ * the caller's local extrema on entry and are only reduced over the tasks.  kproma <= 0: NGPTOT.                              */
+int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld, int kfields, int kproma, double *ave, double *pmin, double *pmax,
+               int ave_only);
+
+/* ---- VORDIV_TO_UV (trans/include/ectrans/vordiv_to_uv.h:12, cpu/internal/vd2uv_mod.F90:79-120) --------------------------------
+ * Spectral vorticity / divergence PSPVOR / PSPDIV(nfld, nspec2) -> spectral U = u cos(theta), V = v cos(theta) in PSPU / PSPV, for
+ * the zonal wavenumbers of this task's W-set and total wavenumbers n <= ksmax.  Needs emi_init only (the reference builds and
+ * releases a spectral-only resolution inside the call); precision = bytes per real of the four arrays (8 or 4).               */
+int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const void *spvor, const void *spdiv, void *spu, void *spv, int nfld);
+
 /* ---- measurement hooks (no reference counterpart; used by bench.py / profiles) -------- */
 /* Algorithmic work of one call on this resolution: Legendre flops and Fourier/grid bytes
  * for `nfields` Fourier-space fields.                                      */

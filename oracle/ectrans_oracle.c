@@ -1132,6 +1132,57 @@ int orc_inv_trans(const orc_trans *t, int nuv, int nsc, const double *spvor, con
   return kf_fs;
 }
 
+/* VORDIV_TO_UV (cpu/external/vordiv_to_uv.F90:11-178 -> VD2UV_CTL -> VD2UV, cpu/internal/vd2uv_mod.F90:79-120): spectral vorticity /
+ * divergence -> spectral U = u cos(theta), V = v cos(theta), coefficients n <= NSMAX only, scaled by 1 / RA.                  */
+void orc_vordiv_to_uv(const orc_trans *t, int nuv, const double *spvor, const double *spdiv, double *spu, double *spv) {
+  if (nuv <= 0) return;
+  int ld = t->nlei1;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int km = 0; km <= t->nsmax; km++) {
+    double *zia = xcalloc((size_t)ld * 8 * nuv, 8), *zeps = xcalloc(t->ntmax + 3, 8);
+    prepsnm(t, km, zeps);
+    double *vor = zia, *div = zia + (size_t)ld * 2 * nuv, *pu = zia + (size_t)ld * 4 * nuv, *pv = zia + (size_t)ld * 6 * nuv;
+    prfi1b(t, km, vor, ld, spvor, nuv, nuv);
+    prfi1b(t, km, div, ld, spdiv, nuv, nuv);
+    vdtuv(t, km, nuv, zeps, vor, div, pu, pv, ld);
+    int ilcm = t->nsmax + 1 - km, ioff = t->nasm0[km];
+    double za_r = 1.0 / t->ra;
+    for (int j = 1; j <= ilcm; j++) { /* vd2uv_mod.F90:104-114 */
+      int inm = ioff + (ilcm - j) * 2;
+      for (int jfld = 1; jfld <= nuv; jfld++) {
+        int ir = 2 * (jfld - 1) + 1, ii = ir + 1;
+        spu[(size_t)(inm - 1) * nuv + (jfld - 1)] = A2(pu, ld, j + 2, ir) * za_r;
+        spu[(size_t)(inm) * nuv + (jfld - 1)] = A2(pu, ld, j + 2, ii) * za_r;
+        spv[(size_t)(inm - 1) * nuv + (jfld - 1)] = A2(pv, ld, j + 2, ir) * za_r;
+        spv[(size_t)(inm) * nuv + (jfld - 1)] = A2(pv, ld, j + 2, ii) * za_r;
+      }
+    }
+    free(zia), free(zeps);
+  }
+}
+
+/* GPNORM_TRANS (cpu/external/gpnorm_trans.F90:11-96 -> GPNORM_TRANS_CTL, cpu/internal/gpnorm_trans_ctl_mod.F90:170-210, 436-443)
+ * for one task: per latitude the sum over the longitudes in double, times RW(lat) / NLOEN(lat); the average is the sum of these over
+ * the latitudes in latitude order; minimum and maximum over all points.  gp[f*ngptot + p].                                       */
+void orc_gpnorm(const orc_trans *t, int nfld, const double *gp, double *ave, double *pmin, double *pmax) {
+  for (int jf = 0; jf < nfld; jf++) {
+    const double *f = gp + (size_t)jf * t->ngptot;
+    double a = 0.0, mn = f[0], mx = f[0];
+    for (int jgl = 1; jgl <= t->ndgl; jgl++) {
+      int n = t->nloen[jgl - 1];
+      const double *row = f + t->gpoff[jgl - 1];
+      double zave = 0.0;
+      for (int jl = 0; jl < n; jl++) {
+        zave += row[jl];
+        if (row[jl] < mn) mn = row[jl];
+        if (row[jl] > mx) mx = row[jl];
+      }
+      a += zave * t->rw[jgl - 1] / (double)n;
+    }
+    ave[jf] = a, pmin[jf] = mn, pmax[jf] = mx;
+  }
+}
+
 /* LTDIR (cpu/internal/ltdir_mod.F90:128-193): PRFI2B + LDFOU2 + LEDIR + UVTVD + UPDSP   */
 static void ltdir(const orc_trans *t, int km, int kf_fs, int kf_uv, int kf_scalars, const double *four,
                   double *spvor, double *spdiv, double *spsc) {

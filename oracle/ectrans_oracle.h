@@ -69,6 +69,12 @@ int orc_inv_trans(const orc_trans *t, int nuv, int nsc, const double *spvor,
 void orc_dir_trans(const orc_trans *t, int nuv, int nsc, const double *gp, double *spvor,
                    double *spdiv, double *spsc);
 
+/* VORDIV_TO_UV (vordiv_to_uv.F90, vd2uv_mod.F90:79-120): spectral vor / div -> spectral U, V (u cos, v cos; n <= NSMAX; times 1 / RA) */
+void orc_vordiv_to_uv(const orc_trans *t, int nuv, const double *spvor, const double *spdiv, double *spu, double *spv);
+
+/* GPNORM_TRANS (gpnorm_trans.F90, gpnorm_trans_ctl_mod.F90): area-weighted average, minimum and maximum of grid fields gp[f*ngptot+p] */
+void orc_gpnorm(const orc_trans *t, int nfld, const double *gp, double *ave, double *pmin, double *pmax);
+
 /* SPECNORM (spnormd_mod.F90:49-50 + spnormc_mod.F90): per-field L2 norm. */
 void orc_specnorm(const orc_trans *t, int nfld, const double *sp, double *norms);
 

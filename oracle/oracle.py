@@ -49,6 +49,8 @@ def lib():
                                     C.c_int, dp]
         L.orc_dir_trans.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp, dp]
         L.orc_specnorm.argtypes = [C.c_void_p, C.c_int, dp, dp]
+        L.orc_vordiv_to_uv.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp]
+        L.orc_gpnorm.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp]
         L.orc_legpol.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.orc_fft_r2c.argtypes = [C.c_int, dp, dp]
         L.orc_fft_c2r.argtypes = [C.c_int, dp, dp]
@@ -152,6 +154,21 @@ class Oracle:
     def set_sp_mode(self, on=True):
         """dir_trans computes LEDIR as libtrans_sp does: float operands, SGEMM, m = 0 in double (ledir_mod.F90:133-171)"""
         self.L.orc_set_sp_mode(self.h, int(on))
+
+    def vordiv_to_uv(self, spvor, spdiv):
+        """VORDIV_TO_UV: spectral (vor, div) -> spectral (U, V) = (u, v) cos(theta), n <= NSMAX"""
+        vor, div = (np.ascontiguousarray(a, dtype=np.float64) for a in (spvor, spdiv))
+        u, v = np.zeros_like(vor), np.zeros_like(vor)
+        self.L.orc_vordiv_to_uv(self.h, vor.shape[1], _dp(vor), _dp(div), _dp(u), _dp(v))
+        return u, v
+
+    def gpnorm(self, gp):
+        """GPNORM_TRANS: (average, minimum, maximum) of every grid field gp[f, point]"""
+        gp = np.ascontiguousarray(gp, dtype=np.float64)
+        nf = gp.shape[0]
+        ave, mn, mx = np.zeros(nf), np.zeros(nf), np.zeros(nf)
+        self.L.orc_gpnorm(self.h, nf, _dp(gp), _dp(ave), _dp(mn), _dp(mx))
+        return ave, mn, mx
 
     def specnorm(self, sp):
         sp = np.ascontiguousarray(sp, dtype=np.float64)

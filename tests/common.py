@@ -730,3 +730,47 @@ def closed_form_errors(inv, dirt, nsmax, nloen, rmu, nasm0, nspec2, ra=6371229.0
     v2, d2, s2 = dirt(gp[2:5])
     e_dir = [float(np.abs(x - y).max() / np.abs(y).max()) for x, y in ((v2, vor), (d2, div), (s2, sc))]
     return e_inv, e_dir
+
+
+def utility_case(et, oracle_cls, dev, nsmax=21, precision=8, nproma=37):
+    """VORDIV_TO_UV and GPNORM_TRANS of the product against the oracle (random dense fields) and against closed forms: solid-body
+    rotation (vor = 2U/(a sqrt 3) P_1^0 => U = u cos(theta) = 2U/3 P_0 - 2U/(3 sqrt 5) P_2, V = 0), a constant field and the
+    zonal harmonic P_2^0 (mean 0, maximum sqrt(5) P_2(mu_1) on the first Gaussian latitude).  Returns the relative errors."""
+    to, back = dev
+    dt = np.float64 if precision == 8 else np.float32
+    nloen = octahedral(nsmax)
+    o = oracle_cls(nsmax, nloen)
+    rng = np.random.default_rng(5)
+    vor = random_spectrum(rng, o.nasm0, nsmax, o.nspec2, 3, True)
+    div = random_spectrum(rng, o.nasm0, nsmax, o.nspec2, 3, True)
+    ur, vr = o.vordiv_to_uv(vor, div)
+    u, v = et.vordiv_to_uv(to(vor.astype(dt)), to(div.astype(dt)), nsmax)
+    e_uv = max(rel_err(back(u), ur), rel_err(back(v), vr))
+    U, a = 30.0, 6371229.0
+    sb = np.zeros((o.nspec2, 1))
+    sb[o.nasm0[0] - 1 + 2, 0] = 2 * U / (a * np.sqrt(3.0))
+    u, v = (back(x) for x in et.vordiv_to_uv(to(sb.astype(dt)), to(np.zeros_like(sb).astype(dt)), nsmax))
+    want = np.zeros_like(sb)
+    want[o.nasm0[0] - 1, 0], want[o.nasm0[0] - 1 + 4, 0] = 2 * U / 3, -2 * U / (3 * np.sqrt(5.0))
+    e_sb = max(np.abs(u - want).max(), np.abs(v).max()) / U
+    # grid-point norms
+    r = et.setup_trans(nsmax, len(nloen), nloen, precision=precision)
+    g = o.inv_trans(spvor=vor, spdiv=div)
+    sc = np.zeros((o.nspec2, 2))
+    sc[o.nasm0[0] - 1, 0], sc[o.nasm0[0] - 1 + 4, 1] = 3.5, 1.0
+    g = np.concatenate([g, o.inv_trans(spsc=sc)])
+    ar, mnr, mxr = o.gpnorm(g)
+    assert abs(ar[-2] - 3.5) < 1e-13 and abs(ar[-1]) < 1e-13 and abs(mxr[-1] - np.sqrt(5.0) * (3 * o.rmu[0] ** 2 - 1) / 2) < 1e-12  # the oracle itself
+    ng, nf = o.ngptot, g.shape[0]
+    nb = (ng - 1) // nproma + 1
+    pad = np.zeros((nf, nb * nproma))
+    pad[:, :ng] = g
+    pgp = np.ascontiguousarray(pad.reshape(nf, nb, nproma).transpose(1, 0, 2)).astype(dt)
+    a1, mn1, mx1 = et.gpnorm_trans(r, to(pgp), kproma=nproma)
+    scale = np.abs(g).max(axis=1)
+    e_gp = max((np.abs(a1 - ar) / scale).max(), (np.abs(mn1 - mnr) / scale).max(), (np.abs(mx1 - mxr) / scale).max())
+    # LDAVE_ONLY: the caller's extrema come back (one task), only the averages are computed; fewer fields than the array holds
+    a2, mn2, mx2 = et.gpnorm_trans(r, to(pgp), kfields=2, kproma=nproma, ldave_only=True, pmin=[-1.0, -2.0], pmax=[3.0, 4.0])
+    assert list(mn2) == [-1.0, -2.0] and list(mx2) == [3.0, 4.0] and np.abs(a2 - a1[:2]).max() == 0.0
+    et.trans_release(r)
+    return e_uv, e_sb, e_gp

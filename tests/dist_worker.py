@@ -65,8 +65,17 @@ def main():
     vr, dr, sr = o.dir_trans(gdir, nuv=nuv, nsc=nsc)
     e_dir = max(rel_err(back(a), b[gidx]) for a, b in ((v2, vr), (d2, dr), (s2, sr)))
     e_norm = np.abs(et.specnorm(r, to(loc(sc))) / o.specnorm(sc) - 1.0).max()
-    print("rank %d/%d: nump %d nlat %d e_inv %.2e e_dir %.2e e_norm %.2e" % (rank, world, len(myms), lat1 - lat0, e_inv, e_dir, e_norm),
-          flush=True)
+    # utility routines with several tasks: VORDIV_TO_UV on this task's wavenumbers, GPNORM_TRANS = the global norms on every task
+    ur, vr = o.vordiv_to_uv(vor, div)
+    u2, w2 = et.vordiv_to_uv(to(loc(vor)), to(loc(div)), N)
+    e_uv = max(rel_err(back(u2), ur[gidx]), rel_err(back(w2), vr[gidx]))
+    ave, gmn, gmx = et.gpnorm_trans(r, gp)
+    ar, mnr, mxr = o.gpnorm(gref)
+    gsc = np.abs(gref).max(axis=1)
+    e_gpn = max((np.abs(ave - ar) / gsc).max(), (np.abs(gmn - mnr) / gsc).max(), (np.abs(gmx - mxr) / gsc).max())
+    print("rank %d/%d: nump %d nlat %d e_inv %.2e e_dir %.2e e_norm %.2e e_uv %.2e e_gpnorm %.2e" % (
+        rank, world, len(myms), lat1 - lat0, e_inv, e_dir, e_norm, e_uv, e_gpn), flush=True)
+    assert e_uv < (1e-12 if PREC == 8 else 3e-6) and e_gpn < (1e-12 if PREC == 8 else 3e-5), (e_uv, e_gpn)
     tol = (1e-12, 1e-13) if PREC == 8 else (3e-5, 1e-5)  # fp32 library: as tests/test_gpu_parity.py
     assert e_inv < tol[0] and e_dir < tol[0] and e_norm < tol[1], (e_inv, e_dir, e_norm)
     if PREC != 8:  # the re-layout helpers below are precision independent; exact-equality checks in fp64 only

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
-from tests.common import adjoint_case, closed_form_errors, legpol_io_case, octahedral, run_case
+from tests.common import adjoint_case, closed_form_errors, legpol_io_case, octahedral, run_case, utility_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-12  # fp64: observed ~1e-15
@@ -480,3 +480,11 @@ def test_inquiry_of_the_initialisation(et):
     the library first abort on a different radius instead of computing with the transport's."""
     kmax, ra = et.inq_init()
     assert kmax >= 1 and ra == 6371229.0  # setup_trans0.F90:129 default
+
+
+@pytest.mark.parametrize("precision", [8, 4])
+def test_utility_routines_vordiv_to_uv_and_gpnorm(et, precision):
+    """VORDIV_TO_UV (k_vd2uv) and GPNORM_TRANS (k_gpnorm) against the oracle and closed forms (tests/common.py::utility_case)"""
+    e_uv, e_sb, e_gp = utility_case(et, Oracle, XP, 15, precision, 37)
+    tol = 1e-12 if precision == 8 else 3e-6
+    assert e_uv < tol and e_sb < tol and e_gp < tol, (e_uv, e_sb, e_gp)

@@ -823,3 +823,15 @@ def test_closed_form_winds_and_derivatives(et, dev, grid, precision):
         et.trans_release(r)
     tol = 1e-12 if precision == 8 else 2e-5
     assert max(e_inv) < tol and max(e_dir) < tol, (e_inv, e_dir)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [8, 4])
+def test_utility_routines_vordiv_to_uv_and_gpnorm(et, dev, precision):
+    """VORDIV_TO_UV (k_vd2uv: vd2uv_mod.F90:79-120) and GPNORM_TRANS (k_gpnorm: gpnorm_trans_ctl_mod.F90) on device arrays against the
+    oracle and closed forms (tests/common.py::utility_case), NPROMA blocks, both precisions"""
+    from oracle.oracle import Oracle as O
+    from tests.common import utility_case
+    e_uv, e_sb, e_gp = utility_case(et, O, dev, 63, precision, 1000)
+    tol = 1e-12 if precision == 8 else 3e-6
+    assert e_uv < tol and e_sb < tol and e_gp < tol, (e_uv, e_sb, e_gp)

@@ -135,3 +135,25 @@ def test_closed_form_winds_and_derivatives(grid):
     dirt = lambda g: o.dir_trans(g, nuv=1, nsc=1)
     e_inv, e_dir = closed_form_errors(inv, dirt, 21, nloen, o.rmu, o.nasm0, o.nspec2)
     assert max(e_inv) < 1e-12 and max(e_dir) < 1e-12, (e_inv, e_dir)
+
+
+def test_closed_form_vordiv_to_uv_and_gpnorm():
+    """VORDIV_TO_UV (vd2uv_mod.F90:79-120) and GPNORM_TRANS (gpnorm_trans_ctl_mod.F90) of the oracle against closed forms: solid-body
+    rotation gives U = u cos(theta) = U0 (1 - mu^2) = 2 U0 / 3 P_0 - 2 U0 / (3 sqrt 5) P_2 and V = 0 in the package's normalisation;
+    a constant field has average = minimum = maximum; the zonal harmonic P_2^0 has average 0 (Gaussian quadrature is exact) and its
+    maximum sqrt(5) P_2(mu) on the first latitude."""
+    N = 21
+    nloen = octahedral(N)
+    o = Oracle(N, nloen)
+    U, a = 30.0, 6371229.0
+    vor, div = np.zeros((o.nspec2, 1)), np.zeros((o.nspec2, 1))
+    vor[o.nasm0[0] - 1 + 2, 0] = 2 * U / (a * np.sqrt(3.0))
+    u, v = o.vordiv_to_uv(vor, div)
+    want = np.zeros_like(u)
+    want[o.nasm0[0] - 1, 0], want[o.nasm0[0] - 1 + 4, 0] = 2 * U / 3, -2 * U / (3 * np.sqrt(5.0))
+    assert np.abs(u - want).max() < 1e-13 * U and np.abs(v).max() < 1e-13 * U
+    sc = np.zeros((o.nspec2, 2))
+    sc[o.nasm0[0] - 1, 0], sc[o.nasm0[0] - 1 + 4, 1] = 3.5, 1.0
+    ave, mn, mx = o.gpnorm(o.inv_trans(spsc=sc))
+    assert abs(ave[0] - 3.5) < 1e-13 and abs(mn[0] - 3.5) < 1e-13 and abs(mx[0] - 3.5) < 1e-13
+    assert abs(ave[1]) < 1e-13 and abs(mx[1] - np.sqrt(5.0) * (3 * o.rmu[0] ** 2 - 1) / 2) < 1e-12 and mn[1] < -1.0

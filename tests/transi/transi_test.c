@@ -217,6 +217,26 @@ int main(void) {
     free(buffer), free(x), free(g0), free(g1);
     printf("legendre file / cache set-ups identical (%zu bytes)\n", size);
   }
+  { /* trans_vordiv_to_UV (transi.h:620-648): solid-body rotation, vor = 2 U / (a sqrt 3) P_1^0 => U = 2U/3 P_0 - 2U/(3 sqrt 5) P_2, V = 0
+       (transi's planet radius is 6371.22 km) */
+    const double U = 30.0, a = 6371.22e3;
+    double *vor = calloc((size_t)trans.nspec2, 8), *div = calloc((size_t)trans.nspec2, 8);
+    double *pu = malloc(sizeof(double) * trans.nspec2), *pv = malloc(sizeof(double) * trans.nspec2);
+    vor[trans.nasm0[0] - 1 + 2] = 2 * U / (a * sqrt(3.0));
+    struct VorDivToUV_t vd = new_vordiv_to_UV();
+    vd.rspvor = vor, vd.rspdiv = div, vd.rspu = pu, vd.rspv = pv, vd.nfld = 1, vd.ncoeff = trans.nspec2, vd.nsmax = nsmax;
+    CHECK(trans_vordiv_to_UV(&vd));
+    if (trans_vordiv_to_UV(&vd) != TRANS_STALE_ARG) return 30;
+    for (int i = 0; i < trans.nspec2; i++) {
+      const double want = i == trans.nasm0[0] - 1 ? 2 * U / 3 : (i == trans.nasm0[0] - 1 + 4 ? -2 * U / (3 * sqrt(5.0)) : 0.0);
+      if (fabs(pu[i] - want) > 1e-12 * U || fabs(pv[i]) > 1e-12 * U) {
+        fprintf(stderr, "vordiv_to_UV: coefficient %d: %g %g (want %g, 0)\n", i, pu[i], pv[i], want);
+        return 31;
+      }
+    }
+    free(vor), free(div), free(pu), free(pv);
+    printf("trans_vordiv_to_UV ok\n");
+  }
   CHECK(trans_delete(&trans));
   CHECK(trans_finalize());
   printf("TRANSI API OK\n");
