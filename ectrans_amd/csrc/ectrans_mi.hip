@@ -3112,6 +3112,16 @@ extern "C" int emi_set_host_collectives(emi_bcast_fn bcast, emi_allgatherv_fn al
   G.hc_user = user;
   return EMI_SUCCESS;
 }
+// broadcast of host bytes from task `root` (1-based) over the attached transport: what the drop-in layers above need where the
+// reference sends a small array from its master task (GPNORM_TRANSAD: gpnorm_trans_ctlad_mod.F90)
+extern "C" int emi_bcast_host(void *buf, long long bytes, int root) {
+  if (!G.init) EMI_FAIL(EMI_ERR_STATE, "emi_bcast_host: SETUP_TRANS0 has not been called");
+  if (root < 1 || root > G.nproc_all || bytes < 0 || (bytes > 0 && !buf)) EMI_FAIL(EMI_ERR_ARG, "emi_bcast_host: bad arguments");
+  if (G.nproc_all == 1 || bytes == 0) return EMI_SUCCESS;
+  if (!G.hc_bcast) EMI_FAIL(EMI_ERR_STATE, "emi_bcast_host: several tasks and no host collectives (emi_set_host_collectives)");
+  if (G.hc_bcast(G.hc_user, buf, bytes, root - 1)) EMI_FAIL(EMI_ERR_RUNTIME, "emi_bcast_host: broadcast failed");
+  return EMI_SUCCESS;
+}
 extern "C" int emi_inq_init(int *kmax_resol, double *prad) {
   if (!G.init) EMI_FAIL(EMI_ERR_STATE, "emi_inq_init: SETUP_TRANS0 has not been called");
   if (kmax_resol) *kmax_resol = G.max_resol;

@@ -277,6 +277,10 @@ int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld, int kfiel
  * releases a spectral-only resolution inside the call); precision = bytes per real of the four arrays (8 or 4).               */
 int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const void *spvor, const void *spdiv, void *spu, void *spv, int nfld);
 
+/* Broadcast of host bytes from task `root` (1-based) over the attached transport (emi_set_host_collectives): for the layers above,
+ * where the reference sends a small array from its master task (GPNORM_TRANSAD, gpnorm_trans_ctlad_mod.F90:108-113).  */
+int emi_bcast_host(void *buf, long long bytes, int root);
+
 /* ---- measurement hooks (no reference counterpart; used by bench.py / profiles) -------- */
 /* Algorithmic work of one call on this resolution: Legendre flops and Fourier/grid bytes
  * for `nfields` Fourier-space fields.                                      */
