@@ -446,6 +446,146 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
   out[(long long)blockIdx.x * 256 + tid] = sum;
 }
 
+// V40-V43 fp32: the fp32 library's loop on v_mfma_f32_16x16x4_f32 (half the cycles per instruction) with 16-row stages (round 4), and
+// the same flops on v_mfma_f32_32x32x2_f32 (half the instructions).  MODE 0: MFMAs only (16x16x4), 1: full loop with cache hits
+// (16x16x4), 2: MFMAs only (32x32x2), 3: MFMAs only 16x16x4 with four waves per SIMD is V20's business -- not repeated here.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(2, 2))) void probe_f32(float *out, const float *src, int nst, long long stride) {
+  extern __shared__ float ldsf[];
+  constexpr int KR = 16;
+  float *As = ldsf, *Bs = ldsf + 2 * KR * LDA;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, wm = w & 1, wn = w >> 1;
+  for (int i = tid; i < 2 * KR * LDA + 2 * KR * LDB; i += 256) ldsf[i] = 1.0f + 1e-5f * (i & 1023);
+  __syncthreads();
+  float sum = 0.f;
+  if (MODE == 4) {  // full loop (cache hits) on v_mfma_f32_32x32x2_f32: 32 instead of 64 MFMAs per stage, 64 cycles each
+    v16f acc[2][2];
+    for (int p = 0; p < 2; p++)
+      for (int j = 0; j < 2; j++)
+        for (int e = 0; e < 16; e++) acc[p][j][e] = 0.f;
+    const int arow = tid >> 4, ac = (tid & 15) * 4, brow = tid >> 5, bc = (tid & 31) * 4;
+    const float *g = src + (long long)blockIdx.x * 8192 + tid * 4;
+    v4f ra0 = {1, 2, 3, 4}, ra1 = ra0, rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
+    for (int s = 0; s < nst; s++) {
+      if (s > 0) __syncthreads();
+      *(v4f *)(As + (0 * KR + arow) * LDA + ac) = ra0;
+      *(v4f *)(As + (1 * KR + arow) * LDA + ac) = ra1;
+      *(v4f *)(Bs + (((brow + 0) & 1) * KR + ((brow + 0) >> 1)) * LDB + bc) = rb0;
+      *(v4f *)(Bs + (((brow + 8) & 1) * KR + ((brow + 8) >> 1)) * LDB + bc) = rb1;
+      *(v4f *)(Bs + (((brow + 16) & 1) * KR + ((brow + 16) >> 1)) * LDB + bc) = rb2;
+      *(v4f *)(Bs + (((brow + 24) & 1) * KR + ((brow + 24) >> 1)) * LDB + bc) = rb3;
+      __syncthreads();
+      ra0 = *(const v4f *)g, ra1 = *(const v4f *)(g + 1024), rb0 = *(const v4f *)(g + 2048), rb1 = *(const v4f *)(g + 3072);
+      rb2 = *(const v4f *)(g + 4096), rb3 = *(const v4f *)(g + 5120);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int ks = 0; ks < KR / 2; ks++) {
+          const int kk = 2 * ks + (l >> 5);
+          const float a = As[(p * KR + kk) * LDA + wm * 32 + (l & 31)];
+          float b[2];
+#pragma unroll
+          for (int j = 0; j < 2; j++) b[j] = Bs[(p * KR + kk) * LDB + wn * 64 + j * 32 + (l & 31)];
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[p][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    sum = ra0[0] + rb3[1];
+    for (int p = 0; p < 2; p++)
+      for (int j = 0; j < 2; j++) sum += acc[p][j][0] + acc[p][j][15];
+  } else if (MODE == 2) {
+    v16f acc[2][2];
+    for (int p = 0; p < 2; p++)
+      for (int j = 0; j < 2; j++)
+        for (int e = 0; e < 16; e++) acc[p][j][e] = 0.f;
+    float a0 = 1.0f + 1e-5f * l, b0 = 1.0f - 1e-5f * l;
+    for (int s = 0; s < nst; s++)
+#pragma unroll
+      for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int ks = 0; ks < KR / 2; ks++)  // k = 2 per instruction
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[p][j], 0, 0, 0);
+    for (int p = 0; p < 2; p++)
+      for (int j = 0; j < 2; j++) sum += acc[p][j][0] + acc[p][j][15];
+  } else {
+    v4f acc[2][2][4];
+    for (int p = 0; p < 2; p++)
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 4; j++) acc[p][i][j] = (v4f){0, 0, 0, 0};
+    const int arow = tid >> 4, ac = (tid & 15) * 4, brow = tid >> 5, bc = (tid & 31) * 4;
+    const float *g = src + (long long)blockIdx.x * 8192 + tid * 4;
+    v4f ra0 = {1, 2, 3, 4}, ra1 = ra0, rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
+    float a0 = 1.0f + 1e-5f * l, b0 = 1.0f - 1e-5f * l;
+    for (int s = 0; s < nst; s++) {
+      if (MODE == 1 || MODE == 3) {
+        if (s > 0) __syncthreads();
+        *(v4f *)(As + (0 * KR + arow) * LDA + ac) = ra0;
+        *(v4f *)(As + (1 * KR + arow) * LDA + ac) = ra1;
+        *(v4f *)(Bs + (((brow + 0) & 1) * KR + ((brow + 0) >> 1)) * LDB + bc) = rb0;
+        *(v4f *)(Bs + (((brow + 8) & 1) * KR + ((brow + 8) >> 1)) * LDB + bc) = rb1;
+        *(v4f *)(Bs + (((brow + 16) & 1) * KR + ((brow + 16) >> 1)) * LDB + bc) = rb2;
+        *(v4f *)(Bs + (((brow + 24) & 1) * KR + ((brow + 24) >> 1)) * LDB + bc) = rb3;
+        __syncthreads();
+        ra0 = *(const v4f *)g, ra1 = *(const v4f *)(g + 1024), rb0 = *(const v4f *)(g + 2048), rb1 = *(const v4f *)(g + 3072);
+        rb2 = *(const v4f *)(g + 4096), rb3 = *(const v4f *)(g + 5120);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int ks = 0; ks < KR / 4; ks++) {
+          const int kk = 4 * ks + (l >> 4);
+          float a[2], b[4];
+          if (MODE == 3) {
+            // two k-steps per LDS read: the operands of k-steps ks (even) and ks + 1 sit side by side (float2), so a stage needs half the
+            // ds_read instructions (the probe only measures the instruction mix: the values are whatever the image holds)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            if (ks & 1) continue;
+            f2v a2[2], b2[4];
+            const int kq = 2 * ks + (l >> 4);  // row of the pair image: KR / 2 rows of 2 x the width
+#pragma unroll
+            for (int i = 0; i < 2; i++) a2[i] = *(const f2v *)(As + (p * KR + kq) * LDA + 2 * (wm * 16 + i * 8) + 2 * (l & 7) + 32 * ((l >> 3) & 1));
+#pragma unroll
+            for (int j = 0; j < 4; j++) b2[j] = *(const f2v *)(Bs + (p * KR + kq) * LDB + 2 * (wn * 32 + j * 8) + 2 * (l & 7) + 64 * ((l >> 3) & 1));
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+              for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i][h], b2[j][h], acc[p][i][j], 0, 0, 0);
+            continue;
+          }
+          if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = As[(p * KR + kk) * LDA + wm * 32 + i * 16 + (l & 15)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = Bs[(p * KR + kk) * LDB + wn * 64 + j * 16 + (l & 15)];
+          } else {
+            a[0] = a[1] = a0;
+            b[0] = b[1] = b[2] = b[3] = b0;
+          }
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[p][i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    sum = ra0[0] + rb3[1];
+    for (int p = 0; p < 2; p++)
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 4; j++) sum += acc[p][i][j][0] + acc[p][i][j][3];
+  }
+  out[(long long)blockIdx.x * 256 + tid] = sum;
+}
+
 template <int V>
 static void run(double *out, const double *src, const char *what, int nst = 80) {
   const int nblk = 256 * 2 * 8;  // 16 tiles per CU-slot; nst = 80: K = 640 n-pairs
@@ -455,7 +595,10 @@ static void run(double *out, const double *src, const char *what, int nst = 80) 
   float best = 1e30f;
   for (int rep = 0; rep < 4; rep++) {
     hipEventRecord(e0, 0);
-    if (V >= 30 && V <= 35) {
+    if (V >= 40 && V <= 44) {
+      // fp32: nst counts 16-row stages of 64 MFMAs (16x16x4) = the flops of two fp64 stages: run nst / 2 of them, the flop count below holds
+      hipLaunchKernelGGL((probe_f32<V - 40>), dim3(nblk), dim3(256), (2 * 16 * LDA + 2 * 16 * LDB) * 4, 0, (float *)out, (const float *)src, nst / 2, (long long)0);
+    } else if (V >= 30 && V <= 35) {
       // nblk / 2 workgroups of twice the tile; nst counts 8-row stages, so KS = 2 runs nst / 2 of them: the flop count below holds
       constexpr int KS = V >= 33 ? 2 : 1;
       hipLaunchKernelGGL((probe_big<(V - 30) % 3, KS>), dim3(nblk / 2), dim3(256), 4 * 8 * KS * LDB2 * 8, 0, out, src, nst / KS, (long long)8192 * (nblk / 2) / 64 * KS);
@@ -481,7 +624,10 @@ static void run(double *out, const double *src, const char *what, int nst = 80) 
     if (ms < best) best = ms;
   }
   double flops = (double)nblk * 4 * nst * 32 * 2048.0;
-  printf("V%d nst %2d %-44s %6.1f TFLOP/s  (%.1f %% of 78.6)\n", V, nst, what, flops / best / 1e9, 100 * flops / best / 1e9 / 78.6);
+  if (V >= 40 && V <= 44)
+    printf("V%d nst %2d %-44s %6.1f TFLOP/s  (%.1f %% of 157.3, fp32)\n", V, nst, what, flops / best / 1e9, 100 * flops / best / 1e9 / 157.3);
+  else
+    printf("V%d nst %2d %-44s %6.1f TFLOP/s  (%.1f %% of 78.6)\n", V, nst, what, flops / best / 1e9, 100 * flops / best / 1e9 / 78.6);
 }
 
 int main() {
@@ -504,6 +650,11 @@ int main() {
     run<32>(out, src, "big tile, 1 wave/SIMD: full loop, cache hits");
     run<34>(out, src, "big tile, 16-row stages: HBM-jumping loads");
     run<35>(out, src, "big tile, 16-row stages: cache hits");
+    run<40>(out, src, "fp32 16x16x4: MFMAs only");
+    run<41>(out, src, "fp32 16x16x4: full loop, 16-row stages, cache hits");
+    run<42>(out, src, "fp32 32x32x2: MFMAs only");
+    run<43>(out, src, "fp32 16x16x4: full loop, two k-steps per LDS read");
+    run<44>(out, src, "fp32 32x32x2: full loop, 16-row stages, cache hits");
     run<20>(out, src, "four waves per SIMD: MFMAs only");
     run<21>(out, src, "four waves per SIMD: full loop, HBM-jumping loads");
     run<22>(out, src, "four waves per SIMD: full loop, cache hits");
