@@ -1059,6 +1059,29 @@ EMI_DEVFN void dit_last_to_grid_any(real2 *a, int nfl, int fs, int S, int lenp, 
 // k_fft_inv: FOURIER_IN (fourier_in_mod.F90:64-76) + FSC (fsc_mod.F90:138-187) + FTINV
 // (ftinv_mod.F90:65-84; FFTW c2r semantics, unnormalised) + TRLTOG local copy.
 // ==========================================================================================
+// FSC (fsc_mod.F90:138-187: x (a + i b k), a / b from the field mode; DIR_TRANSAD: times the weight) and the pairing of FOURIER_IN for one
+// pair (k, sz - k): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}) and Z_{sz-k} (w^{sz-k} = -conj w^k).  ONE expression tree for
+// the batched one-task paths and the row-table paths (several tasks) of the inverse kernels, so that both round alike and the gathered
+// fields of any decomposition stay bit-identical (tests/test_decomposition_invariance.py, the reference's own criterion).
+EMI_DEVFN void fin_factors(int mode, real_t racthe, real_t &fa, real_t &fb) {
+  fa = mode == GM_PLAIN ? (real_t)1.0 : (mode == GM_ACOS ? racthe : (real_t)0.0);
+  fb = mode == GM_EWDER ? racthe : (mode == GM_EWDER_UV ? racthe * racthe : (real_t)0.0);
+}
+EMI_DEVFN void fin_pair(real2 xa, real2 xb, unsigned k, unsigned k2, real_t fa, real_t fb, real_t fs, real2 wk, real2 ck, real2 ck2, real2 &zk, real2 &zk2) {
+  EMI_FP_STRICT();  // every operation rounds on its own: which multiply a fused multiply-add would absorb is the scheduler's choice, per call site
+  const real_t ba = fb * (real_t)k, bb = fb * (real_t)k2;
+  const real2 ya = mk2((xa.x * fa - xa.y * ba) * fs, (xa.y * fa + xa.x * ba) * fs);
+  const real2 yb = mk2((xb.x * fa - xb.y * bb) * fs, (xb.y * fa + xb.x * bb) * fs);
+  const real_t s1x = ya.x + yb.x, s1y = ya.y - yb.y, d1x = ya.x - yb.x, d1y = ya.y + yb.y;  // s = ya + conj yb, d = ya - conj yb
+  const real_t px = wk.x * d1x - wk.y * d1y, py = wk.x * d1y + wk.y * d1x;                   // w d
+  const real_t zx = s1x - py, zy = s1y + px;                                                   // s + i w d
+  zk = mk2(zx * ck.x + zy * ck.y, zy * ck.x - zx * ck.y);                                      // times conj(ck)
+  const real_t s2x = yb.x + ya.x, s2y = yb.y - ya.y, d2x = yb.x - ya.x, d2y = yb.y + ya.y;
+  const real_t qx = -wk.x * d2x - wk.y * d2y, qy = -wk.x * d2y + wk.y * d2x;                  // (-conj w) d
+  const real_t ux = s2x - qy, uy = s2y + qx;
+  zk2 = mk2(ux * ck2.x + uy * ck2.y, uy * ck2.x - ux * ck2.y);
+}
+EMI_DEVFN real2 fin_raw(const real_t *FB, int row, int ldf, int src) { return *(const real2 *)(FB + (unsigned long long)(unsigned)row * (unsigned)ldf + 2 * src); }
 // row < 2^31 and ldf > 0: the row offset is one 32 x 32 -> 64-bit multiply
 EMI_DEVFN real2 fsc_load(const real_t *FB, int row, int ldf, const GridFld &gf, int k, real_t racthe) {
   real2 x = *(const real2 *)(FB + (unsigned long long)(unsigned)row * (unsigned)ldf + 2 * gf.src);
@@ -1501,23 +1524,46 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
   const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
   // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times the chirp
-  for (int fl = 0; fl < nfl; fl++) {
-    const GridFld gf = flds[f0 + fl];
-    real2 *a = (real2 *)EMI_LDS_PTR + (long long)fl * fs;
+  // Branch-free, the Fourier-row loads of a field first (see k_fft_inv_r16: the plain loop cost four to five serialised memory round
+  // trips per pair).
+  {
+    constexpr int NT = hot_threads(PC), TRIPS = (H.S / 4 + 1 + NT - 1) / NT;
+    constexpr unsigned SZ2 = sizeof(real2);
+    const unsigned t = (unsigned)EMI_TID, rowb = (unsigned)ldf * (unsigned)sizeof(real_t);
     const int npair = sz / 2 + 1;
-    for (int k = EMI_TID; k < npair; k += EMI_NTHREADS) {
-      const int k2 = sz - k;
-      real2 xa = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
-      real2 xb = (k2 <= nmen) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
-      if (Lc.adj) xa = cscale(xa, adjw), xb = cscale(xb, adjw);
-      real2 wk = cconj(rtw[k]);
-      real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
-      real2 zk = cadd(s1, cmuli(cmul(wk, d1)));
-      a[FPAD(k)] = cmulc(zk, chirp[k]);
-      if (k2 != k && k2 < sz) {
-        real2 s2 = cadd(xb, cconj(xa)), d2_ = csub(xb, cconj(xa));
-        real2 zk2 = cadd(s2, cmuli(cmul(mk2(-wk.x, wk.y), d2_)));
-        a[FPAD(k2)] = cmulc(zk2, chirp[k2]);
+    const EmiBuf b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2), b_ch = emi_buf(chirp, (unsigned)sz * SZ2);
+    const real_t fsc = Lc.adj ? adjw : (real_t)1.0;
+    for (int fl = 0; fl < nfl; fl++) {
+      const GridFld gf = flds[f0 + fl];
+      real2 *a = (real2 *)EMI_LDS_PTR + (long long)fl * fs;
+      const EmiBuf b_fb = emi_buf(FB + (unsigned long long)(unsigned)fb0 * (unsigned)ldf + 2 * gf.src, (unsigned)nmen * rowb + SZ2);
+      real_t fa, fb;
+      fin_factors(gf.mode, racthe, fa, fb);
+      real2 xa[TRIPS], xb[TRIPS];
+#pragma unroll
+      for (int i = 0; i < TRIPS; i++) {
+        const unsigned k = t + (unsigned)NT * i, k2 = (unsigned)sz - k;
+        if (!frow) {  // (uniform) k > NMEN: zero (range check of the descriptor)
+          xa[i] = emi_buf_ld<real2>(b_fb, k * rowb, 0);
+          xb[i] = emi_buf_ld<real2>(b_fb, k2 * rowb, 0);
+        } else {
+          const unsigned ka = k < (unsigned)nmen ? k : (unsigned)nmen, kb = k2 < (unsigned)nmen ? k2 : (unsigned)nmen;
+          const real2 va = fin_raw(FB, frow[ka], ldf, gf.src), vb = fin_raw(FB, frow[kb], ldf, gf.src);
+          xa[i] = k <= (unsigned)nmen ? va : mk2(0, 0);
+          xb[i] = k2 <= (unsigned)nmen ? vb : mk2(0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TRIPS; i++) {
+        const unsigned k = t + (unsigned)NT * i, k2 = (unsigned)sz - k;
+        if (k < (unsigned)npair) {
+          const real2 wk = cconj(emi_buf_ld<real2>(b_rtw, k * SZ2, 0));
+          const real2 ck = emi_buf_ld<real2>(b_ch, k * SZ2, 0), ck2 = emi_buf_ld<real2>(b_ch, k2 * SZ2, 0);  // k2 = sz (k = 0): zero, slot unused
+          real2 zk, zk2;
+          fin_pair(xa[i], xb[i], k, k2, fa, fb, fsc, wk, ck, ck2, zk, zk2);
+          a[FPAD(k)] = zk;
+          a[FPAD(k2)] = zk2;
+        }
       }
     }
   }
@@ -2046,24 +2092,49 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + pl.bhat_off, (unsigned)S * SZ2);
   if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
-  // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times conj(chirp), to LDS
-  // (issuing all Fourier-row loads of a thread before the first use -- the loop unrolled over its at most five trips -- was
-  // measured 3 ms per pair SLOWER over the four work lengths: the other workgroups of the CU already cover that latency)
+  // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times conj(chirp), to LDS.
+  // Round 4: branch-free, all Fourier-row loads of the thread first.  A wave-0 clock attribution had put 39 % of a workgroup's life
+  // into this stage: the plain loop below compiles into four to five SERIALISED memory round trips per trip of the loop (row-table
+  // branch, X_k behind its `k <= nmen` branch, X_{sz-k} behind its own, the FSC mode branches, the tables), twenty per row -- which
+  // is also why round 3's "all loads first" experiments changed nothing: the waits sat at the ends of those branches.  With one task the
+  // Fourier rows of a latitude are consecutive, so ONE buffer descriptor over rows 0 .. NMEN of this field range-checks k <= NMEN in
+  // hardware (rows past NMEN read as zero), FSC is two uniform factors (x (a + i b k): a, b from the field mode), the tables come
+  // through descriptors as well, and the second store is unconditional (k = 0 writes the unused slot sz; k = sz - k writes the same
+  // value twice).  Rows addressed through the exchange-order table (several tasks) are looked up with a clamped index and selected.
   {
+    constexpr int TRIPS = R1 / 4 + 1;  // pairs k = t + NT a < sz / 2 + 1 <= S / 4 + 1
     const int npair = sz / 2 + 1;
-    for (int k = (int)t; k < npair; k += NT) {
-      const int k2 = sz - k;
-      real2 xa = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
-      real2 xb = (k2 <= nmen) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
-      if (Lc.adj) xa = cscale(xa, adjw), xb = cscale(xb, adjw);
-      const real2 wk = cconj(rtw[k]);
-      const real2 s1 = cadd(xa, cconj(xb)), d1 = csub(xa, cconj(xb));
-      const real2 zk = cadd(s1, cmuli(cmul(wk, d1)));
-      zbuf[k] = cmulc(zk, chirp[k]);
-      if (k2 != k && k2 < sz) {
-        const real2 s2 = cadd(xb, cconj(xa)), d2_ = csub(xb, cconj(xa));
-        const real2 zk2 = cadd(s2, cmuli(cmul(mk2(-wk.x, wk.y), d2_)));
-        zbuf[k2] = cmulc(zk2, chirp[k2]);
+    const unsigned rowb = (unsigned)ldf * (unsigned)sizeof(real_t);
+    const EmiBuf b_fb = emi_buf(FB + (unsigned long long)(unsigned)fb0 * (unsigned)ldf + 2 * gf.src, (unsigned)nmen * rowb + SZ2);
+    const EmiBuf b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
+    real_t fa, fb;
+    fin_factors(gf.mode, racthe, fa, fb);
+    const real_t fs = Lc.adj ? adjw : (real_t)1.0;
+    real2 xa[TRIPS], xb[TRIPS];
+#pragma unroll
+    for (int a = 0; a < TRIPS; a++) {
+      const unsigned k = t + (unsigned)NT * a, k2 = (unsigned)sz - k;
+      if (!frow) {  // (uniform) one descriptor: k > NMEN -- and the idle lanes k >= npair of the last trip, whose k2 wraps -- read zero
+        xa[a] = emi_buf_ld<real2>(b_fb, k * rowb, 0);
+        xb[a] = emi_buf_ld<real2>(b_fb, k2 * rowb, 0);
+      } else {      // rows through the exchange-order table: clamped look-up, then a select
+        const unsigned ka = k < (unsigned)nmen ? k : (unsigned)nmen, kb = k2 < (unsigned)nmen ? k2 : (unsigned)nmen;
+        const real2 va = fin_raw(FB, frow[ka], ldf, gf.src), vb = fin_raw(FB, frow[kb], ldf, gf.src);
+        xa[a] = k <= (unsigned)nmen ? va : mk2(0, 0);
+        xb[a] = k2 <= (unsigned)nmen ? vb : mk2(0, 0);
+      }
+    }
+    // ONE copy of the arithmetic for both ways of loading: the gathered fields of any decomposition stay bit-identical
+#pragma unroll
+    for (int a = 0; a < TRIPS; a++) {
+      const unsigned k = t + (unsigned)NT * a, k2 = (unsigned)sz - k;
+      if (k < (unsigned)npair) {
+        const real2 wk = cconj(emi_buf_ld<real2>(b_rtw, k * SZ2, 0));
+        const real2 ck = emi_buf_ld<real2>(b_ch, k * SZ2, 0), ck2 = emi_buf_ld<real2>(b_ch, k2 * SZ2, 0);  // k2 = sz (k = 0): zero, slot unused
+        real2 zk, zk2;
+        fin_pair(xa[a], xb[a], k, k2, fa, fb, fs, wk, ck, ck2, zk, zk2);
+        zbuf[k] = zk;
+        zbuf[k2] = zk2;
       }
     }
   }

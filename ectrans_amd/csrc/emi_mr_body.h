@@ -455,8 +455,50 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLa
     const unsigned mbc = mr_magic((unsigned)bc);
     const int npair = sz / 2 + 1, ntot = nfl * npair, NT = EMI_NTHREADS;
     const unsigned mnf = mr_magic((unsigned)nfl);
+    if (nfl == 1) {
+      // one field per workgroup (the long rows): branch-free, four pairs per thread with all their loads first (round 4, as
+      // k_fft_inv_r16: behind the `k <= nmen` / FSC-mode branches of the loop below every load waits alone).  One task: the Fourier rows
+      // through a buffer descriptor (k > NMEN reads zero); several tasks: clamped look-up in the exchange-order table and a select.  ONE
+      // copy of the arithmetic for both, so the results do not depend on the decomposition.
+      constexpr unsigned SZ2 = sizeof(real2);
+      const GridFld gf = flds[f0];
+      const unsigned rowb = (unsigned)ldf * (unsigned)sizeof(real_t);
+      const EmiBuf b_fb = emi_buf(FB + (unsigned long long)(unsigned)fb0 * (unsigned)ldf + 2 * gf.src, (unsigned)nmen * rowb + SZ2);
+      const EmiBuf b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
+      real_t fa, fb;
+      fin_factors(gf.mode, racthe, fa, fb);
+      const real_t fsc = Lc.adj ? adjw : (real_t)1.0;
+      for (unsigned g0 = (unsigned)EMI_TID; g0 < (unsigned)npair; g0 += 4u * (unsigned)NT) {
+        real2 xa[4], xb[4], w4[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const unsigned k = g0 + (unsigned)(e * NT), k2 = (unsigned)sz - k;  // k >= npair: loaded (or zero) and dropped
+          if (!frow) {
+            xa[e] = emi_buf_ld<real2>(b_fb, k * rowb, 0);
+            xb[e] = emi_buf_ld<real2>(b_fb, k2 * rowb, 0);
+          } else {
+            const unsigned ka = k < (unsigned)nmen ? k : (unsigned)nmen, kb = k2 < (unsigned)nmen ? k2 : (unsigned)nmen;
+            const real2 va = fin_raw(FB, frow[ka], ldf, gf.src), vb = fin_raw(FB, frow[kb], ldf, gf.src);
+            xa[e] = k <= (unsigned)nmen ? va : mk2(0, 0);
+            xb[e] = k2 <= (unsigned)nmen ? vb : mk2(0, 0);
+          }
+          w4[e] = emi_buf_ld<real2>(b_rtw, k * SZ2, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const unsigned k = g0 + (unsigned)(e * NT), k2 = (unsigned)sz - k;
+          if (k < (unsigned)npair) {
+            real2 zk, zk2;
+            fin_pair(xa[e], xb[e], k, k2, fa, fb, fsc, cconj(w4[e]), mk2((real_t)1.0, (real_t)0.0), mk2((real_t)1.0, (real_t)0.0), zk, zk2);
+            a[k + (pad ? mr_div(k, mbc) * (unsigned)pad : 0u)] = cconj(zk);
+            if (k2 != k && k2 < (unsigned)sz) a[k2 + (pad ? mr_div(k2, mbc) * (unsigned)pad : 0u)] = cconj(zk2);
+          }
+        }
+      }
+    } else
     for (int g0 = EMI_TID; g0 < ntot; g0 += 4 * NT) {
       real2 xa[4], xb[4], w4[4];
+      real_t fa4[4], fb4[4];
       int kk[4], ff[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -465,9 +507,10 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLa
           const int k = nfl > 1 ? (int)mr_div((unsigned)gi, mnf) : gi, fl = gi - k * nfl, k2 = sz - k;  // field fastest
           const GridFld gf = flds[f0 + fl];
           kk[e] = k, ff[e] = fl;
-          xa[e] = (k <= nmen) ? fsc_load(FB, FROW(k), ldf, gf, k, racthe) : mk2(0, 0);
-          xb[e] = (k2 <= nmen) ? fsc_load(FB, FROW(k2), ldf, gf, k2, racthe) : mk2(0, 0);
+          xa[e] = (k <= nmen) ? fin_raw(FB, FROW(k), ldf, gf.src) : mk2(0, 0);
+          xb[e] = (k2 <= nmen) ? fin_raw(FB, FROW(k2), ldf, gf.src) : mk2(0, 0);
           w4[e] = rtw[k];
+          fin_factors(gf.mode, racthe, fa4[e], fb4[e]);
         }
       }
 #pragma unroll
@@ -475,17 +518,10 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLa
         if (g0 + e * NT < ntot) {
           const int k = kk[e], k2 = sz - k;
           real2 *af = a + (long long)ff[e] * m.fs;
-          real2 ya = xa[e], yb = xb[e];
-          if (Lc.adj) ya = cscale(ya, adjw), yb = cscale(yb, adjw);
-          const real2 wk = cconj(w4[e]);
-          const real2 s1 = cadd(ya, cconj(yb)), d1 = csub(ya, cconj(yb));
-          const real2 zk = cadd(s1, cmuli(cmul(wk, d1)));
+          real2 zk, zk2;
+          fin_pair(xa[e], xb[e], (unsigned)k, (unsigned)k2, fa4[e], fb4[e], Lc.adj ? adjw : (real_t)1.0, cconj(w4[e]), mk2((real_t)1.0, (real_t)0.0), mk2((real_t)1.0, (real_t)0.0), zk, zk2);
           af[k + (pad ? (int)mr_div((unsigned)k, mbc) * pad : 0)] = cconj(zk);
-          if (k2 != k && k2 < sz) {
-            const real2 s2 = cadd(yb, cconj(ya)), d2_ = csub(yb, cconj(ya));
-            const real2 zk2 = cadd(s2, cmuli(cmul(mk2(-wk.x, wk.y), d2_)));
-            af[k2 + (pad ? (int)mr_div((unsigned)k2, mbc) * pad : 0)] = cconj(zk2);
-          }
+          if (k2 != k && k2 < sz) af[k2 + (pad ? (int)mr_div((unsigned)k2, mbc) * pad : 0)] = cconj(zk2);
         }
       }
     }

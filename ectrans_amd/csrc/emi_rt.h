@@ -49,6 +49,9 @@
 #define EMI_WAVE_FENCE() __asm__ volatile("" ::: "memory")
 // the instruction scheduler moves nothing across this point
 #define EMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// first statement of a function body whose floating-point operations must round one by one (no fused multiply-adds): code that is
+// instantiated in two places and has to give bit-identical results in both (fin_pair: decomposition invariance)
+#define EMI_FP_STRICT() _Pragma("clang fp contract(off)")
 
 // Buffer-descriptor access to tables and rows (k_fft_*_r16): one 32-bit lane offset, row / leg offsets in scalar registers,
 // no 64-bit vector address arithmetic; a read whose lane offset + immediate is past `bytes` returns zero and such a write is
@@ -145,6 +148,7 @@ static inline void emu_barrier() {
 #define EMI_LDS_SYNC() emu_barrier()
 #define EMI_WAVE_FENCE() emu_barrier()  // lanes are threads here: a real barrier (every thread of the workgroup reaches it)
 #define EMI_SCHED_FENCE() ((void)0)
+#define EMI_FP_STRICT()
 struct EmiBuf {
   const char *p;
   unsigned bytes;
