@@ -1990,6 +1990,18 @@ EMI_DEVFN void r16_conv(real2 *vio, const unsigned t, const EmiBuf &b_tw, const 
 #undef R16_UNPACK
 }
 
+// -DEMI_MR_STAMP (experiments only, as in emi_mr_body.h): thread 0 of every R1 = 16 workgroup adds the clock ticks between consecutive
+// R16_STAMP points to emi_mr_stamp[] (tools/r16_stamp.py reads them: `python tools/r16_stamp.py inv|dir` with the instrumented build in $EMI_LIB)
+#if defined(EMI_MR_STAMP) && !defined(EMI_CPU_EMU)
+#define R16_STAMP_BEGIN() unsigned long long r16_acc[6] = {0}; unsigned long long r16_prev = __builtin_readcyclecounter()
+#define R16_STAMP(i_) do { const unsigned long long n_ = __builtin_readcyclecounter(); r16_acc[i_] += n_ - r16_prev; r16_prev = n_; } while (0)
+#define R16_STAMP_END(n_) do { if (R1 == 16 && EMI_TID == 0) { for (int i_ = 0; i_ < (n_); i_++) atomicAdd(&emi_mr_stamp[i_], r16_acc[i_]); atomicAdd(&emi_mr_stamp[7], 1ull); } } while (0)
+#else
+#define R16_STAMP_BEGIN() ((void)0)
+#define R16_STAMP(i_) ((void)0)
+#define R16_STAMP_END(n_) ((void)0)
+#endif
+
 template <int R1>
 EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
                                                    int nproma) {
@@ -2012,6 +2024,7 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
   const EmiBuf b_ch = emi_buf((const real2 *)T.chirp + pl.chirp_off, (unsigned)sz * SZ2);
   const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + pl.ptw_off[0], 7u * 256u * SZ2);
   const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + pl.bhat_off, (unsigned)S * SZ2);
+  R16_STAMP_BEGIN();
   if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
   // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp; l = t + 256 a
@@ -2043,7 +2056,9 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
       }
     }
   }
+  R16_STAMP(0);
   r16_conv<R1, 0>(v, t, b_tw, b_bh, lds, tw2s);
+  R16_STAMP(1);
   // Z_i = conv_i chirp_i / S, i < sz, to LDS (complex, natural order: sz <= S/2 of them fit the plane)
   EMI_LDS_SYNC();  // every thread has read its last plane values
   if (edge) {
@@ -2054,6 +2069,7 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
     }
   }
   EMI_LDS_SYNC();
+  R16_STAMP(2);
   // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
   const real_t sc = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
   for (int k = (int)t; k <= nmen; k += NT) {
@@ -2063,6 +2079,8 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
     const real2 tt = cmuli(cmul(rtw[k], d1));
     *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * f0) = mk2((s1.x - tt.x) * sc, (s1.y - tt.y) * sc);
   }
+  R16_STAMP(3);
+  R16_STAMP_END(4);
 }
 
 template <int R1>
@@ -2090,6 +2108,7 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   const EmiBuf b_ch = emi_buf(chirp, (unsigned)sz * SZ2);
   const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + pl.ptw_off[0], 7u * 256u * SZ2);
   const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + pl.bhat_off, (unsigned)S * SZ2);
+  R16_STAMP_BEGIN();
   if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
   // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times conj(chirp), to LDS.
@@ -2138,6 +2157,7 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
       }
     }
   }
+  R16_STAMP(0);
   EMI_LDS_SYNC();
   real2 v[H];
   if (edge) {
@@ -2148,7 +2168,9 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
     }
   }
   EMI_LDS_SYNC();  // the plane is free for the exchanges
+  R16_STAMP(1);
   r16_conv<R1, 1>(v, t, b_tw, b_bh, lds, tw2s);
+  R16_STAMP(2);
   // stage 3 (TRLTOG local copy): z_i = conv_i conj(chirp_i) / S; x_{2i} = Re z_i, x_{2i+1} = Im z_i, straight from the registers
   if (edge) {
     const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
@@ -2176,6 +2198,8 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
       }
     }
   }
+  R16_STAMP(3);
+  R16_STAMP_END(4);
 }
 
 #include "emi_mr_body.h"
