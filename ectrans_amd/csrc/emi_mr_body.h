@@ -455,7 +455,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLa
     const unsigned mbc = mr_magic((unsigned)bc);
     const int npair = sz / 2 + 1, ntot = nfl * npair, NT = EMI_NTHREADS;
     const unsigned mnf = mr_magic((unsigned)nfl);
-    if (nfl == 1) {
+    if (pl.fbk == 1) {  // (a property of the row length, not of the chunk: the same code path in every decomposition)
       // one field per workgroup (the long rows): branch-free, four pairs per thread with all their loads first (round 4, as
       // k_fft_inv_r16: behind the `k <= nmen` / FSC-mode branches of the loop below every load waits alone).  One task: the Fourier rows
       // through a buffer descriptor (k > NMEN reads zero); several tasks: clamped look-up in the exchange-order table and a select.  ONE
