@@ -263,15 +263,22 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[p][i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
 
-  // global -> register prefetch pointers (advance by one stage per iteration): a panel row of the tile is 64 / LGV lanes wide, a
-  // packed spectral row 128 / LGV lanes
+  // global -> register prefetch (one stage ahead): a panel row of the tile is 64 / LGV lanes wide, a packed spectral row 128 / LGV
+  // lanes.  Every address is (base uniform over the wave) + (32-bit lane offset that never changes): the bases live in scalar
+  // registers and advance on the scalar unit, the loads are `global_load_dwordx4 v, v_off, s[base]` -- the stage loop has no vector
+  // address arithmetic (it had six 64-bit adds, which cost the matrix pipe what 0.6 matrix instructions do; emi_rt.h)
   constexpr int LA = 64 / LGV, LB = LG_BN / LGV, RPP = LG_THREADS / LB;  // RPP: W rows per pass of the workgroup (4 | 8)
+  constexpr int WRA = 64 / LA, WRB = 64 / LB;                            // panel rows | W rows that one wave loads per instruction
+  const int wv = emi_uniform(w);
   const int arow = tid / LA, ac = (tid % LA) * LGV;
-  const real_t *pS = (const real_t *)g.P + g.offS[m] + (long long)arow * ld + lat0 + ac;
-  const real_t *pA = (const real_t *)g.P + g.offA[m] + (long long)arow * ld + lat0 + ac;
+  unsigned voA = (unsigned)(((l / LA) * ld + ac) * (int)sizeof(real_t));
+  const char *uS = emi_uniform_ptr((const real_t *)g.P + g.offS[m] + (long long)(wv * WRA) * ld + lat0);
+  const char *uA = emi_uniform_ptr((const real_t *)g.P + g.offA[m] + (long long)(wv * WRA) * ld + lat0);
   const int brow = tid / LB, bc = (tid % LB) * LGV;  // rows brow + RPP i, i = 0..3, of the stage
-  const real_t *pW = W + ((long long)g.wbase[m] + brow) * ldw + col0 + bc;
-  const long long stepA = (long long)LG_KR * ld, stepW = 2LL * LG_KR * ldw, rowW4 = (long long)RPP * ldw;
+  unsigned voB = (unsigned)(((l / LB) * ldw + bc) * (int)sizeof(real_t));
+  const char *uW = emi_uniform_ptr(W + ((long long)g.wbase[m] + wv * WRB) * ldw + col0);
+  const long long stepA = (long long)LG_KR * ld * (long long)sizeof(real_t), stepW = 2LL * LG_KR * ldw * (long long)sizeof(real_t);
+  const long long rowW4 = (long long)RPP * ldw * (long long)sizeof(real_t);
   real_t *sA0 = As + (0 * LG_KR + arow) * LG_LDA + ac;
   real_t *sA1 = As + (1 * LG_KR + arow) * LG_LDA + ac;
   // W row r of the stage -> parity r&1, k = r>>1 ; r = brow + RPP*i
@@ -279,8 +286,21 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
   real_t *sB1 = Bs + (((brow + 1 * RPP) & 1) * LG_KR + ((brow + 1 * RPP) >> 1)) * LG_LDB + bc;
   real_t *sB2 = Bs + (((brow + 2 * RPP) & 1) * LG_KR + ((brow + 2 * RPP) >> 1)) * LG_LDB + bc;
   real_t *sB3 = Bs + (((brow + 3 * RPP) & 1) * LG_KR + ((brow + 3 * RPP) >> 1)) * LG_LDB + bc;
-  lgvec ra0 = *(const lgvec *)pS, ra1 = *(const lgvec *)pA;
-  lgvec rb0 = *(const lgvec *)pW, rb1 = *(const lgvec *)(pW + rowW4), rb2 = *(const lgvec *)(pW + 2 * rowW4), rb3 = *(const lgvec *)(pW + 3 * rowW4);
+  // fragment positions, one register per (parity, k step): the paired LDS reads of a step then reach their operands through the
+  // 8-bit offsets of the instruction and the stage loop has no address adds (the compiler, given one base, re-derives the others
+  // by nine vector adds per stage)
+  int fa[2][LG_KR / 4], fb[2][LG_KR / 4];
+#pragma unroll
+  for (int p = 0; p < 2; p++)
+#pragma unroll
+    for (int ks = 0; ks < LG_KR / 4; ks++) {
+      fa[p][ks] = (p * LG_KR + 4 * ks + (l >> 4)) * LG_LDA + wm * 32 + (l & 15);
+      fb[p][ks] = (p * LG_KR + 4 * ks + (l >> 4)) * LG_LDB + wn * 64 + (l & 15);
+      EMI_OPAQUE(fa[p][ks]);
+      EMI_OPAQUE(fb[p][ks]);
+    }
+  lgvec ra0 = emi_ld_sv<lgvec>(uS, voA), ra1 = emi_ld_sv<lgvec>(uA, voA);
+  lgvec rb0 = emi_ld_sv<lgvec>(uW, voB), rb1 = emi_ld_sv<lgvec>(uW + rowW4, voB), rb2 = emi_ld_sv<lgvec>(uW + 2 * rowW4, voB), rb3 = emi_ld_sv<lgvec>(uW + 3 * rowW4, voB);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
     *(lgvec *)sA0 = ra0;
@@ -291,27 +311,28 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
     *(lgvec *)sB3 = rb3;
     EMI_SYNC();
     if (s + 1 < nst) {
-      pS += stepA;
-      pA += stepA;
-      pW += stepW;
-      ra0 = *(const lgvec *)pS;
-      ra1 = *(const lgvec *)pA;
-      rb0 = *(const lgvec *)pW;
-      rb1 = *(const lgvec *)(pW + rowW4);
-      rb2 = *(const lgvec *)(pW + 2 * rowW4);
-      rb3 = *(const lgvec *)(pW + 3 * rowW4);
+      uS += stepA;
+      uA += stepA;
+      uW += stepW;
+      EMI_OPAQUE(voA);  // the zero-extension of the lane offset has to sit in this block for the scalar-base form to be selected
+      EMI_OPAQUE(voB);
+      ra0 = emi_ld_sv<lgvec>(uS, voA);
+      ra1 = emi_ld_sv<lgvec>(uA, voA);
+      rb0 = emi_ld_sv<lgvec>(uW, voB);
+      rb1 = emi_ld_sv<lgvec>(uW + rowW4, voB);
+      rb2 = emi_ld_sv<lgvec>(uW + 2 * rowW4, voB);
+      rb3 = emi_ld_sv<lgvec>(uW + 3 * rowW4, voB);
     }
     EMI_PRIO_HI();
 #pragma unroll
     for (int p = 0; p < 2; p++)
 #pragma unroll
       for (int ks = 0; ks < LG_KR / 4; ks++) {
-        const int kk = 4 * ks + (l >> 4);
         real_t a[2], b[4];
 #pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = As[(p * LG_KR + kk) * LG_LDA + wm * 32 + i * 16 + (l & 15)];
+        for (int i = 0; i < 2; i++) a[i] = As[fa[p][ks] + i * 16];
 #pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = Bs[(p * LG_KR + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
+        for (int j = 0; j < 4; j++) b[j] = Bs[fb[p][ks] + j * 16];
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -383,36 +404,77 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   // P^T tile: LG_LS latitudes x 64 k per parity, k contiguous in HBM (coalesced rows) and in LDS; a row is 64 / LGV lanes wide, so the
   // workgroup covers RA = 8 | 16 latitude rows per pass and the stage in two passes
   constexpr int LA = 64 / LGV, RA = LG_THREADS / LA, LB = LG_BN / LGV, RB = LG_THREADS / LB;  // RB = 4 | 8 Fourier rows per pass, four passes
+  constexpr int WRA = 64 / LA;                       // panel rows that one wave loads per instruction
+  constexpr bool SROWS = (LB == 64);                 // a wave loads ONE Fourier row per instruction (fp64): row addresses are scalar
+  const int wv = emi_uniform(w);
   const int arow = tid / LA, ac = (tid % LA) * LGV;  // latitude rows arow and arow + RA of the stage
   const int ldk = g.ldk[m];
-  const real_t *pS = (const real_t *)g.PT + g.offTS[m] + (long long)arow * ldk + k0 + ac;
-  const real_t *pA = (const real_t *)g.PT + g.offTA[m] + (long long)arow * ldk + k0 + ac;
-  const long long stepA = (long long)LG_LS * ldk, rowA8 = (long long)RA * ldk;
+  // as in leg_inv_tile: uniform bases in scalar registers + constant 32-bit lane offsets, no vector address arithmetic per stage
+  unsigned voA = (unsigned)(((l / LA) * ldk + ac) * (int)sizeof(real_t));
+  const char *uS = emi_uniform_ptr((const real_t *)g.PT + g.offTS[m] + (long long)(wv * WRA) * ldk + k0);
+  const char *uA = emi_uniform_ptr((const real_t *)g.PT + g.offTA[m] + (long long)(wv * WRA) * ldk + k0);
+  const long long stepA = (long long)LG_LS * ldk * (long long)sizeof(real_t), rowA8 = (long long)RA * ldk * (long long)sizeof(real_t);
   const int brow = tid / LB, bc = (tid % LB) * LGV;  // latitude rows brow + RB i, i = 0..3, of each stage
   const real_t *FBc = FB + col0 + bc;
+  unsigned voB = (unsigned)(bc * (int)sizeof(real_t));
+  const char *uFB = emi_uniform_ptr(FB + col0);
   lgvec ra0, ra1, ra2, ra3;                      // P^T of stage s+1
   lgvec rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
-  // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT
-  // kernels), so each stage touches 32 far-apart rows, prefetched one stage (~2 x 2048 MFMA cycles
-  // per SIMD) ahead.  Their row numbers (fbase[lat]+m) are staged once per tile in LDS, so that
-  // looking them up is an LDS read (lgkmcnt) and never a vector-memory load that would order behind
-  // the prefetches (vmcnt).
+  // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT kernels), so each stage touches 32
+  // far-apart rows, prefetched one stage (~2 x 4096 MFMA cycles per SIMD) ahead.  fp64 (SROWS): a wave loads one whole row piece per
+  // instruction, so its row numbers (fbase[lat]+m) are SCALAR loads from the latitude tables, fetched a further stage ahead, and the
+  // row address is scalar arithmetic (before: eight LDS look-ups, eight 32 x 32 -> 64-bit vector multiply-adds and eight 64-bit vector
+  // adds per stage, which together took the matrix pipe for as long as two matrix instructions).  Latitudes past the last one read
+  // row `zrow` of the buffer, a row of zeros behind the Fourier rows: no branch around the loads.
+  // fp32: a wave loads two rows per instruction; their numbers are staged once per tile in LDS, so that looking them up is an LDS
+  // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
   int *rowN = (int *)(Bs + 2 * LG_LS * LG_LDB);
   int *rowS = rowN + LG_LS * nst;
-  for (int j = tid; j < LG_LS * nst; j += LG_THREADS) {
-    // latitudes past the last one read row `zrow` of the buffer, a row of zeros behind the Fourier rows: no
-    // branch, no select, and the row address is one 32 x 32 -> 64-bit multiply-add
-    int rn_ = zrow, rs_ = zrow;
-    if (j < ndglu) {
-      rn_ = g.legN[lb + j];
-      rs_ = g.legS[lb + j];
+  if constexpr (!SROWS) {
+    for (int j = tid; j < LG_LS * nst; j += LG_THREADS) {
+      int rn_ = zrow, rs_ = zrow;
+      if (j < ndglu) {
+        rn_ = g.legN[lb + j];
+        rs_ = g.legS[lb + j];
+      }
+      rowN[j] = rn_;
+      rowS[j] = rs_;
     }
-    rowN[j] = rn_;
-    rowS[j] = rs_;
+    EMI_SYNC();
   }
-  EMI_SYNC();
+  int qn[4], qs[4];  // SROWS: row numbers of the stage that is requested next
+#define LEGDIR_ROWS(s_)                                    \
+  if constexpr (SROWS) {                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
+      const int j_ = LG_LS * (s_) + wv + RB * i_;          \
+      const int jc_ = j_ < ndglu ? j_ : ndglu - 1;         \
+      qn[i_] = emi_ld_const(g.legN, lb + jc_);             \
+      qs[i_] = emi_ld_const(g.legS, lb + jc_);             \
+    }                                                      \
+  }
+  unsigned qrn[4], qrs[4];  // SROWS: the rows that LEGDIR_LOADB requests
+  // the selects sit a stage after the scalar loads were issued (nothing waits for them) and BEFORE the next ones overwrite qn / qs
+#define LEGDIR_SEL(s_)                                     \
+  if constexpr (SROWS) {                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
+      const bool live_ = LG_LS * (s_) + wv + RB * i_ < ndglu; \
+      qrn[i_] = live_ ? qn[i_] : zrow;                     \
+      qrs[i_] = live_ ? qs[i_] : zrow;                     \
+    }                                                      \
+  }
 #define LEGDIR_LOADB(s_)                                                            \
-  {                                                                                 \
+  if constexpr (SROWS) {                                                            \
+    const unsigned long long ldfb_ = (unsigned long long)(unsigned)ldf * sizeof(real_t); \
+    EMI_OPAQUE(voB);                                                                \
+    rn0 = emi_ld_sv<lgvec>(uFB + qrn[0] * ldfb_, voB);                                 \
+    rs0 = emi_ld_sv<lgvec>(uFB + qrs[0] * ldfb_, voB);                                 \
+    rn1 = emi_ld_sv<lgvec>(uFB + qrn[1] * ldfb_, voB);                                 \
+    rs1 = emi_ld_sv<lgvec>(uFB + qrs[1] * ldfb_, voB);                                 \
+    rn2 = emi_ld_sv<lgvec>(uFB + qrn[2] * ldfb_, voB);                                 \
+    rs2 = emi_ld_sv<lgvec>(uFB + qrs[2] * ldfb_, voB);                                 \
+    rn3 = emi_ld_sv<lgvec>(uFB + qrn[3] * ldfb_, voB);                                 \
+    rs3 = emi_ld_sv<lgvec>(uFB + qrs[3] * ldfb_, voB);                                 \
+  } else {                                                                          \
     const int j0_ = LG_LS * (s_) + brow;                                            \
     const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + RB], is1 = rowS[j0_ + RB];         \
     const int in2 = rowN[j0_ + 2 * RB], is2 = rowS[j0_ + 2 * RB], in3 = rowN[j0_ + 3 * RB], is3 = rowS[j0_ + 3 * RB]; \
@@ -427,15 +489,38 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   }
 #define LEGDIR_LOADA(s_)                                          \
   {                                                               \
-    ra0 = *(const lgvec *)(pS + (s_) * stepA);                    \
-    ra1 = *(const lgvec *)(pA + (s_) * stepA);                    \
-    ra2 = *(const lgvec *)(pS + (s_) * stepA + rowA8);            \
-    ra3 = *(const lgvec *)(pA + (s_) * stepA + rowA8);            \
+    const char *us_ = uS + (s_) * stepA, *ua_ = uA + (s_) * stepA; \
+    EMI_OPAQUE(voA);                                              \
+    ra0 = emi_ld_sv<lgvec>(us_, voA);                             \
+    ra1 = emi_ld_sv<lgvec>(ua_, voA);                             \
+    ra2 = emi_ld_sv<lgvec>(us_ + rowA8, voA);                     \
+    ra3 = emi_ld_sv<lgvec>(ua_ + rowA8, voA);                     \
   }
+  // fragment positions, one register per k step (leg_inv_tile)
+  int fa[LG_LS / 4], fb[LG_LS / 4];
+#pragma unroll
+  for (int ks = 0; ks < LG_LS / 4; ks++) {
+    fa[ks] = (par * LG_LS + 4 * ks + (l >> 4)) * LG_LDA + (l & 15);
+    fb[ks] = (par * LG_LS + 4 * ks + (l >> 4)) * LG_LDB + wn * 64 + (l & 15);
+    EMI_OPAQUE(fa[ks]);
+    EMI_OPAQUE(fb[ks]);
+  }
+  LEGDIR_ROWS(0);
+  LEGDIR_SEL(0);
   LEGDIR_LOADB(0);
   LEGDIR_LOADA(0);
+  LEGDIR_ROWS(nst > 1 ? 1 : 0);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
+    const int sn = (s + 1 < nst) ? s + 1 : s;
+    {
+      // row numbers: those of stage s+1 (requested a stage ago) are consumed, those of stage s+2 requested -- here, ahead of the LDS
+      // writes and the second barrier, so that the matrix phase's first fragment reads never wait on a scalar load
+      LEGDIR_SEL(sn);
+      const int sn2 = (s + 2 < nst) ? s + 2 : sn;
+      LEGDIR_ROWS(sn2);
+      EMI_SCHED_FENCE();  // left to itself the scheduler sinks the scalar loads to the wait in front of the second barrier
+    }
     // As[par][latitude in stage][k index], Bs[par][latitude in stage][column]
     *(lgvec *)(As + (0 * LG_LS + arow) * LG_LDA + ac) = ra0;
     *(lgvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;
@@ -453,19 +538,17 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
     {
       // unconditional (the last stage requests its own rows again and drops them): with the loads inside an
       // `if (s + 1 < nst)` the compiler copies all twelve prefetch registers at the loop back edge, 44 moves per stage
-      const int sn = (s + 1 < nst) ? s + 1 : s;
       LEGDIR_LOADB(sn);
       LEGDIR_LOADA(sn);
     }
     EMI_PRIO_HI();
 #pragma unroll
     for (int ks = 0; ks < LG_LS / 4; ks++) {
-      const int kk = 4 * ks + (l >> 4);
       real_t a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[(par * LG_LS + kk) * LG_LDA + i * 16 + (l & 15)];
+      for (int i = 0; i < 4; i++) a[i] = As[fa[ks] + i * 16];
 #pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[(par * LG_LS + kk) * LG_LDB + wn * 64 + j * 16 + (l & 15)];
+      for (int j = 0; j < 4; j++) b[j] = Bs[fb[ks] + j * 16];
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (FULL || i < ni) {  // the last k tile of a wavenumber: 16-row groups past the end are skipped
@@ -475,6 +558,8 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
     }
     EMI_PRIO_LO();
   }
+#undef LEGDIR_ROWS
+#undef LEGDIR_SEL
 #undef LEGDIR_LOADA
 #undef LEGDIR_LOADB
   // Epilogue.  Fields whose spectral output is a plain copy (UPDSP, updsp_mod.F90:100-161: every scalar) go

@@ -82,6 +82,25 @@ EMI_DEVFN void emi_buf_st(const EmiBuf &b, unsigned voff, unsigned soff, V v) {
   else
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(emi_v2i, v), b.r, voff, soff, 0);
 }
+// Scalar addressing of loads whose base is uniform over the wave (Legendre stage loops): `emi_uniform*` move a value that IS the same in
+// every lane into scalar registers (v_readfirstlane), and a load from uniform base + 32-bit lane offset is one
+// `global_load_dwordx4 v, v_off, s[base:base+1]` -- the per-stage pointer arithmetic then runs on the scalar unit.  On gfx950 every
+// vector instruction, 32-bit moves included, takes issue time from the pipe the fp64 matrix instructions run on
+// (tools/dp_pipe_probe.hip: 2.5 - 5 cycles of a matrix instruction's 64 per 32-bit instruction, 5 - 8 per 64-bit one).
+EMI_DEVFN int emi_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+EMI_DEVFN const char *emi_uniform_ptr(const void *p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (const char *)(((unsigned long long)hi << 32) | lo);
+}
+template <class V>
+EMI_DEVFN V emi_ld_sv(const char *ubase, unsigned voff) {
+  return *(const EMI_GLOBAL_AS V *)((const EMI_GLOBAL_AS char *)ubase + voff);
+}
+// element `idx` (uniform) of a table that nothing writes while kernels run: read through the constant address space, which makes it a
+// scalar load (s_load_dword) wherever it stands -- behind a workgroup barrier a plain load is a vector load + v_readfirstlane whose
+// s_waitcnt vmcnt also waits for every operand prefetch issued before it
+EMI_DEVFN int emi_ld_const(const int *tab, int idx) { return ((const __attribute__((address_space(4))) int *)tab)[idx]; }
 // Wave priority around the MFMA block of the Legendre stage loops: the two waves of a SIMD are in
 // different phases (one issues MFMAs, the other address arithmetic, LDS writes and loads for its next
 // stage); with the MFMA wave at the higher priority its next MFMA never queues behind the other wave's
@@ -164,6 +183,15 @@ inline V emi_buf_ld(const EmiBuf &b, unsigned voff, unsigned soff) {
 template <class V>
 inline void emi_buf_st(const EmiBuf &b, unsigned voff, unsigned soff, V v) {
   if ((size_t)voff + sizeof(V) <= b.bytes) memcpy((char *)b.p + voff + soff, &v, sizeof(V));
+}
+inline int emi_uniform(int x) { return x; }
+inline const char *emi_uniform_ptr(const void *p) { return (const char *)p; }
+inline int emi_ld_const(const int *tab, int idx) { return tab[idx]; }
+template <class V>
+inline V emi_ld_sv(const char *ubase, unsigned voff) {
+  V v;
+  memcpy(&v, ubase + voff, sizeof(V));
+  return v;
 }
 #define EMI_GLOBAL_AS
 #define EMI_LDS_DECL
