@@ -2488,7 +2488,7 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
       g_pt.stop(iv, sA);
       iv = g_pt.start(1, sA);
       LegMaps *lmaps = bmaps[ib];
-      EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
+      EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES + 512, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
       g_pt.stop(iv, sA);
     }
     if (piped) g_pipe.signal(3 * ib, sA);
@@ -2785,7 +2785,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
     emi_dev_memset(FBl + (size_t)lrows_call * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
     const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
     LegMaps *lmaps = bmaps[ib];
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 8 * roundup(P.ndgnh + 1, P.esz == 4 ? 32 : 16) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 1024 + 8 * roundup(P.ndgnh + 1, P.esz == 4 ? 32 : 16) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);

@@ -213,6 +213,31 @@ EMI_KERNEL_LB(256) void k_postpack_dir(EmiGeomDev g, const SpecDst *flds, int nf
 // epilogue -- the reference's single-precision library computes the mean wavenumber this way ("DGEM for the mean to
 // improve mass conservation", cpu/internal/ledir_mod.F90:133-171; its GPU back-end also in the inverse transform,
 // gpu/internal/leinv_mod.F90:273).  The two instructions share the A / B lane maps; the accumulator rows differ.
+// -DEMI_MR_STAMP -DEMI_LEG_STAMP=1|2 (experiments only; tools/leg_stamp.py): wave 0 of every k_leg_inv (1) / k_leg_dir (2) workgroup adds the
+// clock ticks between the LEG_STAMP points of its stage loop to emi_mr_stamp[]: 0 end of the matrix phase -> first barrier passed, 1 operand
+// waits (vmcnt) + LDS writes issued, 2 next stage's loads issued, 3 LDS writes done + second barrier passed, 4 matrix phase issued (k_leg_dir:
+// + the sums and differences of the next stage's rows); [6] counts stages, [7] tiles.  s_memtime itself returns through lgkmcnt, so the points
+// sit outside the matrix phase.
+#if defined(EMI_MR_STAMP) && defined(EMI_LEG_STAMP) && !defined(EMI_CPU_EMU)
+#define LEG_STAMP_BEGIN(k_) unsigned long long lst_acc[5] = {0}; unsigned long long lst_prev = __builtin_readcyclecounter(); const bool lst_on = (EMI_LEG_STAMP == (k_))
+#define LEG_STAMP(i_) do { if (lst_on) { const unsigned long long n_ = __builtin_readcyclecounter(); lst_acc[i_] += n_ - lst_prev; lst_prev = n_; } } while (0)
+#define LEG_STAMP_END(nst_) do { if (lst_on && EMI_TID == 0) { for (int i_ = 0; i_ < 5; i_++) atomicAdd(&emi_mr_stamp[i_], lst_acc[i_]); atomicAdd(&emi_mr_stamp[6], (unsigned long long)(nst_)); atomicAdd(&emi_mr_stamp[7], 1ull); } } while (0)
+// tile start-up (kernel entry -> stage loop, [5]) and drain (stage loop -> last store issued [8] -> stores acknowledged [9])
+#define LEG_STAMP_T0() const unsigned long long lst_t0 = __builtin_readcyclecounter()
+#define LEG_STAMP_PRO(k_) do { if (EMI_LEG_STAMP == (k_) && EMI_TID == 0) atomicAdd(&emi_mr_stamp[5], __builtin_readcyclecounter() - lst_t0); } while (0)
+#define LEG_STAMP_EPI0() const unsigned long long lst_e0 = __builtin_readcyclecounter()
+#define LEG_STAMP_EPI(k_) do { if (EMI_LEG_STAMP == (k_)) { const unsigned long long e1_ = __builtin_readcyclecounter(); __builtin_amdgcn_s_waitcnt(0); \
+    const unsigned long long e2_ = __builtin_readcyclecounter(); if (EMI_TID == 0) { atomicAdd(&emi_mr_stamp[8], e1_ - lst_e0); atomicAdd(&emi_mr_stamp[9], e2_ - lst_e0); } } } while (0)
+#else
+#define LEG_STAMP_BEGIN(k_) ((void)0)
+#define LEG_STAMP(i_) ((void)0)
+#define LEG_STAMP_END(nst_) ((void)0)
+#define LEG_STAMP_T0() ((void)0)
+#define LEG_STAMP_PRO(k_) ((void)0)
+#define LEG_STAMP_EPI0() ((void)0)
+#define LEG_STAMP_EPI(k_) ((void)0)
+#endif
+
 template <bool WIDE>
 struct LegAcc {
   typedef acc4 type;
@@ -246,6 +271,7 @@ EMI_DEVFN v4f lg_sub(v4f a, v4f b) { return a - b; }
 template <bool WIDE>
 EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, const int ct, const real_t *W, int ldw, real_t *FB, int ldf) {
   typedef typename LegAcc<WIDE>::type acc_t;
+  LEG_STAMP_T0();
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
   real_t *Bs = As + 2 * LG_KR * LG_LDA;
@@ -301,15 +327,31 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
     }
   lgvec ra0 = emi_ld_sv<lgvec>(uS, voA), ra1 = emi_ld_sv<lgvec>(uA, voA);
   lgvec rb0 = emi_ld_sv<lgvec>(uW, voB), rb1 = emi_ld_sv<lgvec>(uW + rowW4, voB), rb2 = emi_ld_sv<lgvec>(uW + 2 * rowW4, voB), rb3 = emi_ld_sv<lgvec>(uW + 3 * rowW4, voB);
+  // Fourier rows of the tile's 64 latitudes (north | south; -1 past the last latitude), staged in LDS now and read back by the epilogue:
+  // looked up there, each of its eight row groups waited for two dependent index loads behind a divergent branch -- 17.5 k of a
+  // tile's 211 k clocks (wave-0 stamps, tools/leg_stamp.py)
+  int *erow = (int *)((char *)As + LG_LDS_BYTES);
+  const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
+  if (tid < 128) {
+    const int jj = lat0 + (tid & 63);
+    int r_ = -1;
+    if (jj < ndglu) r_ = (tid < 64 ? g.legN : g.legS)[lb + jj];
+    erow[tid] = r_;
+  }
+  LEG_STAMP_PRO(1);
+  LEG_STAMP_BEGIN(1);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
+    LEG_STAMP(0);
     *(lgvec *)sA0 = ra0;
     *(lgvec *)sA1 = ra1;
     *(lgvec *)sB0 = rb0;
     *(lgvec *)sB1 = rb1;
     *(lgvec *)sB2 = rb2;
     *(lgvec *)sB3 = rb3;
-    EMI_SYNC();
+    LEG_STAMP(1);
+    // the next stage is requested BEFORE the second barrier (the LDS writes have read their registers): issuing six loads took 320 clocks
+    // of every stage between that barrier and the first matrix instruction
     if (s + 1 < nst) {
       uS += stepA;
       uA += stepA;
@@ -323,6 +365,9 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
       rb2 = emi_ld_sv<lgvec>(uW + 2 * rowW4, voB);
       rb3 = emi_ld_sv<lgvec>(uW + 3 * rowW4, voB);
     }
+    LEG_STAMP(2);
+    EMI_SYNC();
+    LEG_STAMP(3);
     EMI_PRIO_HI();
 #pragma unroll
     for (int p = 0; p < 2; p++)
@@ -339,17 +384,27 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
           for (int j = 0; j < 4; j++) acc[p][i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[p][i][j]);
       }
     EMI_PRIO_LO();
+    LEG_STAMP(4);
   }
+  LEG_STAMP_END(nst);
+  LEG_STAMP_EPI0();
   // epilogue (ASRE1B): rows = latitudes
-  const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
+  int ern[2][4], ers[2][4];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      int j = lat0 + wm * 32 + i * 16 + LegAcc<WIDE>::row(l, q);
-      if (j < ndglu) {
-        real_t *pn = FB + (long long)g.legN[lb + j] * ldf + col0 + wn * 64 + (l & 15);
-        real_t *ps = FB + (long long)g.legS[lb + j] * ldf + col0 + wn * 64 + (l & 15);
+      const int jl = wm * 32 + i * 16 + LegAcc<WIDE>::row(l, q);
+      ern[i][q] = erow[jl];
+      ers[i][q] = erow[64 + jl];
+    }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (ern[i][q] >= 0) {
+        real_t *pn = FB + (long long)ern[i][q] * ldf + col0 + wn * 64 + (l & 15);
+        real_t *ps = FB + (long long)ers[i][q] * ldf + col0 + wn * 64 + (l & 15);
 #pragma unroll
         for (int jn = 0; jn < 4; jn++) {
           const auto sv = acc[0][i][jn][q], av = acc[1][i][jn][q];  // WIDE: the sum and difference in double too
@@ -358,6 +413,7 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
         }
       }
     }
+  LEG_STAMP_EPI(1);
 }
 EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const real_t *W, int ldw, real_t *FB, int ldf) {
   // host-built tile map (leg_tilemap): block -> (local wavenumber, latitude tile, column tile),
@@ -384,6 +440,7 @@ template <bool FULL, bool WIDE>
 EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, const int ct, const int ni, const real_t *FB, const int zrow, int ldf,
                             real_t *W, int ldw, const FuseDst *fd) {
   typedef typename LegAcc<WIDE>::type acc_t;
+  LEG_STAMP_T0();
   EMI_LDS_DECL;
   real_t *As = (real_t *)EMI_LDS_PTR;
   real_t *Bs = As + 2 * LG_LS * LG_LDA;
@@ -428,7 +485,20 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   // row `zrow` of the buffer, a row of zeros behind the Fourier rows: no branch around the loads.
   // fp32: a wave loads two rows per instruction; their numbers are staged once per tile in LDS, so that looking them up is an LDS
   // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
-  int *rowN = (int *)(Bs + 2 * LG_LS * LG_LDB);
+  // destinations of the tile's 64 fields (fused epilogue), staged in LDS now: fetched in the epilogue they cost eight serialised memory
+  // round trips (descriptor, then index / stride / NASM0 behind a divergent branch, per 16-column group) -- about 20 k of the 35 k clocks
+  // a tile spent between its last matrix instruction and its last store (tools/leg_stamp.py)
+  FuseDst *efd = (FuseDst *)(Bs + 2 * LG_LS * LG_LDB);
+  if (tid < 64) {
+    FuseDst d_;
+    d_.dst = nullptr;
+    d_.stride = 0;
+    d_.idx = 0;
+    if (fd) d_ = fd[(col0 >> 1) + tid];
+    efd[tid] = d_;
+  }
+  const int nasm0_m = emi_ld_const(g.nasm0, m), mval_m = emi_ld_const(g.mval, m);
+  int *rowN = (int *)(efd + 64);
   int *rowS = rowN + LG_LS * nst;
   if constexpr (!SROWS) {
     for (int j = tid; j < LG_LS * nst; j += LG_THREADS) {
@@ -505,13 +575,30 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
     EMI_OPAQUE(fa[ks]);
     EMI_OPAQUE(fb[ks]);
   }
+  // PRFI2B: (north, south) -> (symmetric, antisymmetric), in place, as soon as the rows of the next stage have arrived
+#define LEGDIR_SUMDIFF()                                   \
+  {                                                        \
+    lgvec t_;                                              \
+    t_ = lg_sub(rn0, rs0), rn0 = lg_add(rn0, rs0), rs0 = t_; \
+    t_ = lg_sub(rn1, rs1), rn1 = lg_add(rn1, rs1), rs1 = t_; \
+    t_ = lg_sub(rn2, rs2), rn2 = lg_add(rn2, rs2), rs2 = t_; \
+    t_ = lg_sub(rn3, rs3), rn3 = lg_add(rn3, rs3), rs3 = t_; \
+  }
   LEGDIR_ROWS(0);
   LEGDIR_SEL(0);
   LEGDIR_LOADB(0);
   LEGDIR_LOADA(0);
+  LEGDIR_SUMDIFF();
+  // Order of a stage: barrier, LDS writes (no arithmetic), loads of the next stage, barrier, matrix phase, sums and differences of the rows
+  // that arrived meanwhile.  The sixteen fp64 adds used to sit in front of the LDS writes, where the wave runs at low priority beside the
+  // other workgroup's matrix phase and every add waited for a gap between matrix instructions (2.3 k of a stage's 9 k clocks); at the end
+  // of the wave's own matrix phase they issue back to back.
   LEGDIR_ROWS(nst > 1 ? 1 : 0);
+  LEG_STAMP_PRO(2);
+  LEG_STAMP_BEGIN(2);
   for (int s = 0; s < nst; s++) {
     if (s > 0) EMI_SYNC();
+    LEG_STAMP(0);
     const int sn = (s + 1 < nst) ? s + 1 : s;
     {
       // row numbers: those of stage s+1 (requested a stage ago) are consumed, those of stage s+2 requested -- here, ahead of the LDS
@@ -526,21 +613,24 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
     *(lgvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;
     *(lgvec *)(As + (0 * LG_LS + arow + RA) * LG_LDA + ac) = ra2;
     *(lgvec *)(As + (1 * LG_LS + arow + RA) * LG_LDA + ac) = ra3;
-    *(lgvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = lg_add(rn0, rs0);  // symmetric part
-    *(lgvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = lg_sub(rn0, rs0);  // antisymmetric part
-    *(lgvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = lg_add(rn1, rs1);
-    *(lgvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = lg_sub(rn1, rs1);
-    *(lgvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = lg_add(rn2, rs2);
-    *(lgvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = lg_sub(rn2, rs2);
-    *(lgvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = lg_add(rn3, rs3);
-    *(lgvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = lg_sub(rn3, rs3);
-    EMI_SYNC();
+    *(lgvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = rn0;  // symmetric part
+    *(lgvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = rs0;  // antisymmetric part
+    *(lgvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = rn1;
+    *(lgvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = rs1;
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rn2;
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rs2;
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rn3;
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rs3;
+    LEG_STAMP(1);
     {
       // unconditional (the last stage requests its own rows again and drops them): with the loads inside an
       // `if (s + 1 < nst)` the compiler copies all twelve prefetch registers at the loop back edge, 44 moves per stage
       LEGDIR_LOADB(sn);
       LEGDIR_LOADA(sn);
     }
+    LEG_STAMP(2);
+    EMI_SYNC();
+    LEG_STAMP(3);
     EMI_PRIO_HI();
 #pragma unroll
     for (int ks = 0; ks < LG_LS / 4; ks++) {
@@ -556,10 +646,15 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
           for (int j = 0; j < 4; j++) acc[i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[i][j]);
         }
     }
+    LEGDIR_SUMDIFF();
     EMI_PRIO_LO();
+    LEG_STAMP(4);
   }
+  LEG_STAMP_END(nst);
+  LEG_STAMP_EPI0();
 #undef LEGDIR_ROWS
 #undef LEGDIR_SEL
+#undef LEGDIR_SUMDIFF
 #undef LEGDIR_LOADA
 #undef LEGDIR_LOADB
   // Epilogue.  Fields whose spectral output is a plain copy (UPDSP, updsp_mod.F90:100-161: every scalar) go
@@ -574,16 +669,14 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   for (int jn = 0; jn < 4; jn++) {
     ud[jn] = nullptr;
     us[jn] = 0;
-    if (fd) {
-      const FuseDst d = fd[(col0 + wn * 64 + jn * 16 + (l & 15)) >> 1];
-      if (d.dst) {
-        ud[jn] = (real_t *)d.dst + d.idx + (long long)(g.nasm0[m] + cpar) * d.stride;
-        us[jn] = 2LL * d.stride;
-      }
+    const FuseDst d = efd[wn * 32 + jn * 8 + ((l & 15) >> 1)];
+    if (d.dst) {
+      ud[jn] = (real_t *)d.dst + d.idx + (long long)(nasm0_m + cpar) * d.stride;
+      us[jn] = 2LL * d.stride;
     }
   }
-  const int rmax = g.nsmax - g.mval[m];  // rows r = n - m <= rmax carry a coefficient
-  const bool zero_im = (g.mval[m] == 0) && cpar;
+  const int rmax = g.nsmax - mval_m;  // rows r = n - m <= rmax carry a coefficient
+  const bool zero_im = (mval_m == 0) && cpar;
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -602,6 +695,7 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
         }
       }
     }
+  LEG_STAMP_EPI(2);
 }
 EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const int zrow, int ldf, real_t *W, int ldw,
                                       const FuseDst *fd) {
@@ -2077,7 +2171,7 @@ EMI_DEVFN void r16_conv(real2 *vio, const unsigned t, const EmiBuf &b_tw, const 
 
 // -DEMI_MR_STAMP (experiments only, as in emi_mr_body.h): thread 0 of every R1 = 16 workgroup adds the clock ticks between consecutive
 // R16_STAMP points to emi_mr_stamp[] (tools/r16_stamp.py reads them: `python tools/r16_stamp.py inv|dir` with the instrumented build in $EMI_LIB)
-#if defined(EMI_MR_STAMP) && !defined(EMI_CPU_EMU)
+#if defined(EMI_MR_STAMP) && !defined(EMI_LEG_STAMP) && !defined(EMI_CPU_EMU)
 #define R16_STAMP_BEGIN() unsigned long long r16_acc[6] = {0}; unsigned long long r16_prev = __builtin_readcyclecounter()
 #define R16_STAMP(i_) do { const unsigned long long n_ = __builtin_readcyclecounter(); r16_acc[i_] += n_ - r16_prev; r16_prev = n_; } while (0)
 #define R16_STAMP_END(n_) do { if (R1 == 16 && EMI_TID == 0) { for (int i_ = 0; i_ < (n_); i_++) atomicAdd(&emi_mr_stamp[i_], r16_acc[i_]); atomicAdd(&emi_mr_stamp[7], 1ull); } } while (0)

@@ -29,7 +29,7 @@
 
 // -DEMI_MR_STAMP (experiments only): wave 0 of every workgroup adds the clock ticks it spent between consecutive MR_STAMP points to
 // emi_mr_stamp[] (read with emi_debug_mr_stamps)
-#if defined(EMI_MR_STAMP) && !defined(EMI_CPU_EMU)
+#if defined(EMI_MR_STAMP) && !defined(EMI_LEG_STAMP) && !defined(EMI_CPU_EMU)
 #define MR_STAMP_BEGIN()                  \
   unsigned long long st_acc[10] = {0};    \
   unsigned long long st_prev = __builtin_readcyclecounter()
@@ -408,7 +408,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_mr(EmiGeomDev g, FftTabDev T, FftLa
           za[e] = af[pos(k)], zb[e] = af[pos(k == 0 ? 0 : sz - k)];
         }
       }
-#if defined(EMI_MR_STAMP) && !defined(EMI_CPU_EMU)
+#if defined(EMI_MR_STAMP) && !defined(EMI_LEG_STAMP) && !defined(EMI_CPU_EMU)
       if (w4[0].x + za[0].x + zb[0].x + sc[0] == (real_t)1.2345e300) kk[0] = 0;  // wait for the loads here
       MR_STAMP(7);
 #endif

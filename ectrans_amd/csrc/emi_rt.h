@@ -104,7 +104,8 @@ EMI_DEVFN int emi_ld_const(const int *tab, int idx) { return ((const __attribute
 // Wave priority around the MFMA block of the Legendre stage loops: the two waves of a SIMD are in
 // different phases (one issues MFMAs, the other address arithmetic, LDS writes and loads for its next
 // stage); with the MFMA wave at the higher priority its next MFMA never queues behind the other wave's
-// vector instructions.  Measured +2.5 % on both Legendre kernels (priority 1 and 3 alike).
+// vector instructions.  Measured +2.5 % on both Legendre kernels (priority 1 and 3 alike) in round 1; since the stage loops lost their
+// vector address arithmetic (round 4) the kernels run the same with and without it (87.7 / 98.1 against 88.2 / 98.1 ms).
 #define EMI_PRIO_HI() __builtin_amdgcn_s_setprio(1)
 #define EMI_PRIO_LO() __builtin_amdgcn_s_setprio(0)
 // the value of a per-lane integer becomes opaque to the optimiser at this point: index arithmetic that depends on it

@@ -1,6 +1,10 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
+# A/B of library builds on ONE box: bash tools/ab_libs.sh [suffix ...]   (ectrans_amd/libectrans_mi.so.<suffix>; "" = the product build)
+cd ${GRAFT_REPO_ROOT:-$PWD}
+libs=("$@"); [ ${#libs[@]} -eq 0 ] && libs=(base "")
 for rep in 1 2; do
-  echo "== base"; EMI_LIB=$PWD/ectrans_amd/libectrans_mi.so.base python tools/gpu_perf.py 1279 137 10 4 2>&1 | grep -v amdgpu.ids | tail -3
-  echo "== new"; python tools/gpu_perf.py 1279 137 10 4 2>&1 | grep -v amdgpu.ids | tail -3
+  for sfx in "${libs[@]}"; do
+    lib=$PWD/ectrans_amd/libectrans_mi.so${sfx:+.$sfx}
+    echo "== ${sfx:-product}"; EMI_LIB=$lib python tools/gpu_perf.py 1279 137 10 4 2>&1 | grep -v amdgpu.ids | tail -2 | head -1
+  done
 done
