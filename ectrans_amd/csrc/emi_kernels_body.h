@@ -596,60 +596,59 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int kt, cons
   LEGDIR_ROWS(nst > 1 ? 1 : 0);
   LEG_STAMP_PRO(2);
   LEG_STAMP_BEGIN(2);
-  for (int s = 0; s < nst; s++) {
-    if (s > 0) EMI_SYNC();
-    LEG_STAMP(0);
-    const int sn = (s + 1 < nst) ? s + 1 : s;
-    {
-      // row numbers: those of stage s+1 (requested a stage ago) are consumed, those of stage s+2 requested -- here, ahead of the LDS
-      // writes and the second barrier, so that the matrix phase's first fragment reads never wait on a scalar load
-      LEGDIR_SEL(sn);
-      const int sn2 = (s + 2 < nst) ? s + 2 : sn;
-      LEGDIR_ROWS(sn2);
-      EMI_SCHED_FENCE();  // left to itself the scheduler sinks the scalar loads to the wait in front of the second barrier
-    }
-    // As[par][latitude in stage][k index], Bs[par][latitude in stage][column]
-    *(lgvec *)(As + (0 * LG_LS + arow) * LG_LDA + ac) = ra0;
-    *(lgvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;
-    *(lgvec *)(As + (0 * LG_LS + arow + RA) * LG_LDA + ac) = ra2;
-    *(lgvec *)(As + (1 * LG_LS + arow + RA) * LG_LDA + ac) = ra3;
-    *(lgvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = rn0;  // symmetric part
-    *(lgvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = rs0;  // antisymmetric part
-    *(lgvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = rn1;
-    *(lgvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = rs1;
-    *(lgvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rn2;
-    *(lgvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rs2;
-    *(lgvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rn3;
-    *(lgvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rs3;
-    LEG_STAMP(1);
-    {
-      // unconditional (the last stage requests its own rows again and drops them): with the loads inside an
-      // `if (s + 1 < nst)` the compiler copies all twelve prefetch registers at the loop back edge, 44 moves per stage
-      LEGDIR_LOADB(sn);
-      LEGDIR_LOADA(sn);
-    }
-    LEG_STAMP(2);
-    EMI_SYNC();
-    LEG_STAMP(3);
-    EMI_PRIO_HI();
-#pragma unroll
-    for (int ks = 0; ks < LG_LS / 4; ks++) {
-      real_t a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[fa[ks] + i * 16];
-#pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[fb[ks] + j * 16];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (FULL || i < ni) {  // the last k tile of a wavenumber: 16-row groups past the end are skipped
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[i][j]);
-        }
-    }
-    LEGDIR_SUMDIFF();
-    EMI_PRIO_LO();
-    LEG_STAMP(4);
+  // One stage; LAST_: the last stage of the tile requests nothing (the loop is peeled rather than guarded: with the loads inside an
+  // `if (s + 1 < nst)` the compiler copies all twelve prefetch registers at the loop back edge, 44 moves per stage; and a last stage that
+  // re-requested its own rows, as it did until round 4, made the epilogue wait a memory round trip for data nobody reads)
+#define LEGDIR_STAGE(s, LAST_)                                                                                            \
+  {                                                                                                                       \
+    if ((s) > 0) EMI_SYNC();                                                                                              \
+    LEG_STAMP(0);                                                                                                         \
+    if constexpr (!(LAST_)) {                                                                                             \
+      /* row numbers: those of stage s+1 (requested a stage ago) are consumed, those of stage s+2 requested -- here, ahead of the LDS */ \
+      /* writes and the second barrier, so that the matrix phase's first fragment reads never wait on a scalar load */     \
+      LEGDIR_SEL((s) + 1);                                                                                                \
+      const int sn2 = ((s) + 2 < nst) ? (s) + 2 : (s) + 1;                                                                \
+      LEGDIR_ROWS(sn2);                                                                                                   \
+      EMI_SCHED_FENCE(); /* left to itself the scheduler sinks the scalar loads to the wait in front of the second barrier */ \
+    }                                                                                                                     \
+    /* As[par][latitude in stage][k index], Bs[par][latitude in stage][column] */                                         \
+    *(lgvec *)(As + (0 * LG_LS + arow) * LG_LDA + ac) = ra0;                                                              \
+    *(lgvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;                                                              \
+    *(lgvec *)(As + (0 * LG_LS + arow + RA) * LG_LDA + ac) = ra2;                                                         \
+    *(lgvec *)(As + (1 * LG_LS + arow + RA) * LG_LDA + ac) = ra3;                                                         \
+    *(lgvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = rn0; /* symmetric part */                                         \
+    *(lgvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = rs0; /* antisymmetric part */                                     \
+    *(lgvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = rn1;                                                         \
+    *(lgvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = rs1;                                                         \
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rn2;                                                     \
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rs2;                                                     \
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rn3;                                                     \
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rs3;                                                     \
+    LEG_STAMP(1);                                                                                                         \
+    if constexpr (!(LAST_)) {                                                                                             \
+      LEGDIR_LOADB((s) + 1);                                                                                              \
+      LEGDIR_LOADA((s) + 1);                                                                                              \
+    }                                                                                                                     \
+    LEG_STAMP(2);                                                                                                         \
+    EMI_SYNC();                                                                                                           \
+    LEG_STAMP(3);                                                                                                         \
+    EMI_PRIO_HI();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < LG_LS / 4; ks++) {                                                            \
+      real_t a[4], b[4];                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 4; i++) a[i] = As[fa[ks] + i * 16];                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) b[j] = Bs[fb[ks] + j * 16];                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                       \
+        if (FULL || i < ni) { /* the last k tile of a wavenumber: 16-row groups past the end are skipped */               \
+          _Pragma("unroll") for (int j = 0; j < 4; j++) acc[i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[i][j]);             \
+        }                                                                                                                 \
+    }                                                                                                                     \
+    if constexpr (!(LAST_)) LEGDIR_SUMDIFF();                                                                             \
+    EMI_PRIO_LO();                                                                                                        \
+    LEG_STAMP(4);                                                                                                         \
   }
+  for (int s = 0; s < nst - 1; s++) LEGDIR_STAGE(s, false);
+  LEGDIR_STAGE(nst - 1, true);
+#undef LEGDIR_STAGE
   LEG_STAMP_END(nst);
   LEG_STAMP_EPI0();
 #undef LEGDIR_ROWS
