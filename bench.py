@@ -118,20 +118,19 @@ def cpu_baseline(nsmax, kf_full, budget_s=20.0, gpu=None):
     return base, dense, blas
 
 
-def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=64):
+def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=256):
     """A second CPU baseline on LIBRARY BLAS + FFT -- the closest stand-in for the reference's FFTW + BLAS path that may travel
-    (north_star; ledir_mod.F90:130,204 / leinv_mod.F90:133,166 call DGEMM, tpm_fftw.F90:294-316 FFTW): the Legendre transforms as
-    torch.matmul (MKL) on the ORACLE's panels, the Fourier transforms as scipy.fft (pocketfft) per latitude on a thread pool,
-    scalar fields only (the wind stencils are not where the time goes).  The first columns are the oracle's own sample and
-    must reproduce its results; pairs/s scaled linearly in the field count, as cpu_baseline."""
+    (north_star; ledir_mod.F90:130,204 / leinv_mod.F90:133,166 call DGEMM, tpm_fftw.F90:294-316 FFTW) -- parallelised the way the
+    reference parallelises it: a pool of threads over the zonal wavenumbers with a SEQUENTIAL BLAS call per thread
+    (ltdir_ctl_mod.F90:90-98, ltinv_ctl_mod.F90:118-138: !$OMP PARALLEL DO SCHEDULE(DYNAMIC,1) over m) and over the latitudes for the
+    Fourier transforms (ftdir_ctl_mod.F90:182-190), on ALL host cores, with >= 512 columns per panel product (256 fields x re / im).
+    Legendre transforms = torch.matmul (MKL, one thread per call) on the ORACLE's panels, Fourier transforms = scipy.fft (pocketfft)
+    per latitude; scalar fields only (the wind stencils are not where the time goes).  The first columns are the oracle's own sample
+    and must reproduce its results; pairs/s scaled linearly in the field count, as cpu_baseline."""
     import scipy.fft
     import torch
     from concurrent.futures import ThreadPoolExecutor
-    # 32 threads at most: with one MKL thread per core of the 256-core GPU box the ~5000 panel products of a pair took 0.25 s EACH
-    # (161 s for 640 of them at TCo639; 0.09 s with 32 threads -- tools/blas_diag.py), and 8-16 pool workers are the best the
-    # GIL-bound row loop of the Fourier transforms gets; `cores` of the record = the threads really used
-    cores = min(cores, 32)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(1)  # every worker thread runs its products on one BLAS thread, as the reference's OpenMP threads do
     nloen = octahedral(nsmax)
     ndgl, H = len(nloen), len(nloen) // 2
     nasm0, nmen, ndglu, rw = o.nasm0, o.nmen, o.ndglu, o.rw
@@ -140,61 +139,86 @@ def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=6
     rng = np.random.default_rng(7)
     nf = max(nf_total, nref)
     sc = np.concatenate([sc_ref, random_spectrum(rng, nasm0, nsmax, o.nspec2, nf - nref, False)], axis=1) if nf > nref else sc_ref
+    pool = ThreadPoolExecutor(max_workers=cores)
     # the panels as the BLAS operands (set-up, not timed: the reference keeps RPNMA / RPNMS in memory too)
-    Ps, Pa = [], []
-    for m in range(nsmax + 1):
+    def panels(m):
         ps, pa = o.rpnm(m, True), o.rpnm(m, False)  # [column: n descending][latitude]
         # [k][lat], n = m + 2 k (+ 1); the panels also hold the row n = N + 1 the wind stencils use: dropped here (scalars only)
-        Ps.append(torch.from_numpy(ps[::-1][:(nsmax - m) // 2 + 1].copy()))
-        Pa.append(torch.from_numpy(pa[::-1][:(nsmax - m + 1) // 2].copy()))
-    pool = ThreadPoolExecutor(max_workers=min(cores, 16))
+        return torch.from_numpy(ps[::-1][:(nsmax - m) // 2 + 1].copy()), torch.from_numpy(pa[::-1][:(nsmax - m + 1) // 2].copy())
+
+    PP = list(pool.map(panels, range(nsmax + 1)))
+    Ps, Pa = [p[0] for p in PP], [p[1] for p in PP]
 
     def coeffs(spec, m):
         i0 = nasm0[m] - 1
         z = spec[i0:i0 + 2 * (nsmax - m + 1)].reshape(nsmax - m + 1, 2, -1)  # [n - m][re | im][field]
         return torch.from_numpy(np.ascontiguousarray(z[0::2].reshape(-1, 2 * z.shape[2]))), torch.from_numpy(np.ascontiguousarray(z[1::2].reshape(-1, 2 * z.shape[2])))
 
+    tm = {}
+
+    # work arrays that persist between calls, as the reference's with LDALLOPERM = .TRUE. (what its benchmark sets,
+    # ectrans-benchmark.F90:378-381): allocated and touched once, outside the timed pair
+    buf = {}
+
+    def work(name, shape):
+        a = buf.get(name)
+        if a is None or a.shape != shape:
+            a = buf[name] = np.zeros(shape)
+        return a
+
     def inverse(spec):
         nfl = spec.shape[1]
-        FN, FS = np.zeros((H, nsmax + 1, 2 * nfl)), np.zeros((H, nsmax + 1, 2 * nfl))
-        for m in range(nsmax + 1):
+        FN, FS = work("FN", (H, nsmax + 1, 2 * nfl)), work("FS", (H, nsmax + 1, 2 * nfl))
+
+        def wave(m):
             K = int(min(H, ndglu[m]))
             if K <= 0:
-                continue
+                return
             xs, xa = coeffs(spec, m)
             S = (Ps[m].T @ xs).numpy()  # LEINV: (K x ILS) (ILS x 2 KF)
             A = (Pa[m].T @ xa).numpy() if xa.shape[0] else 0.0
             FN[H - K:, m], FS[H - K:, m] = S + A, S - A  # ASRE1B
-        grid = np.zeros((nfl, int(off[-1])))
+
+        t0 = time.time()
+        list(pool.map(wave, range(nsmax + 1)))
+        tm["inverse_legendre"] = time.time() - t0
+        # grid-point fields with the FIELD index fastest, as the reference's ZGTF(KF, NLENGTF) (ftinv_ctl_mod.F90:145-156): a latitude row
+        # is one contiguous block and the transform runs along its first axis -- no strided Python-side copies around the library call
+        grid = work("grid", (int(off[-1]), nfl))
 
         def row(j):
             n, jn = int(nloen[j]), (j if j < H else ndgl - 1 - j)
             M = int(min(nmen[j], n // 2))
-            X = np.zeros((nfl, n // 2 + 1), dtype=np.complex128)
-            F = (FN if j < H else FS)[jn, :M + 1]  # [m][re | im][field]
-            F = F.reshape(M + 1, 2, nfl)
-            X[:, :M + 1] = (F[:, 0] + 1j * F[:, 1]).T
-            grid[:, off[j]:off[j + 1]] = scipy.fft.irfft(X, n, axis=1) * n  # FTINV: c2r, unscaled
+            F = (FN if j < H else FS)[jn, :M + 1].reshape(M + 1, 2, nfl)  # [m][re | im][field]
+            X = np.zeros((n // 2 + 1, nfl), dtype=np.complex128)
+            X[:M + 1].real, X[:M + 1].imag = F[:, 0], F[:, 1]
+            grid[off[j]:off[j + 1]] = scipy.fft.irfft(X, n, axis=0) * n  # FTINV: c2r, unscaled
 
+        t0 = time.time()
         list(pool.map(row, range(ndgl)))
+        tm["inverse_fourier"] = time.time() - t0
         return grid
 
     def direct(grid):
-        nfl = grid.shape[0]
-        FN, FS = np.zeros((H, nsmax + 1, 2 * nfl)), np.zeros((H, nsmax + 1, 2 * nfl))
+        nfl = grid.shape[1]
+        FN, FS = work("FN", (H, nsmax + 1, 2 * nfl)), work("FS", (H, nsmax + 1, 2 * nfl))
 
         def row(j):
             n, jn = int(nloen[j]), (j if j < H else ndgl - 1 - j)
             M = int(min(nmen[j], n // 2))
-            X = scipy.fft.rfft(grid[:, off[j]:off[j + 1]], axis=1)[:, :M + 1] * (rw[j] / n)  # FTDIR scaled 1 / NLOEN, times the Gaussian weight
-            (FN if j < H else FS)[jn, :M + 1] = np.stack([X.real.T, X.imag.T], axis=1).reshape(M + 1, 2 * nfl)
+            X = scipy.fft.rfft(grid[off[j]:off[j + 1]], axis=0)[:M + 1] * (rw[j] / n)  # FTDIR scaled 1 / NLOEN, times the Gaussian weight
+            Fd = (FN if j < H else FS)[jn, :M + 1].reshape(M + 1, 2, nfl)
+            Fd[:, 0], Fd[:, 1] = X.real, X.imag
 
+        t0 = time.time()
         list(pool.map(row, range(ndgl)))
-        spec = np.zeros((o.nspec2, nfl))
-        for m in range(nsmax + 1):
+        tm["direct_fourier"] = time.time() - t0
+        spec = work("spec", (o.nspec2, nfl))
+
+        def wave(m):
             K = int(min(H, ndglu[m]))
             if K <= 0:
-                continue
+                return
             fn, fs = torch.from_numpy(FN[H - K:, m]), torch.from_numpy(FS[H - K:, m])
             xs = (Ps[m] @ (fn + fs)).numpy().reshape(-1, 2, nfl)  # LEDIR: (ILS x K) (K x 2 KF)
             xa = (Pa[m] @ (fn - fs)).numpy().reshape(-1, 2, nfl)
@@ -203,26 +227,36 @@ def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=6
             z[0::2], z[1::2] = xs, xa
             if m == 0:
                 z[:, 1] = 0.0
+
+        t0 = time.time()
+        list(pool.map(wave, range(nsmax + 1)))
+        tm["direct_legendre"] = time.time() - t0
         return spec
 
-    # guard: the leg must stay a bounded sample whatever the host's BLAS threading does -- a probe of 32 panel products first
+    # guard: the leg must stay a bounded sample whatever the host's BLAS threading does -- a probe of `cores` panel products first
     t = time.time()
-    for m in range(0, nsmax + 1, max(1, (nsmax + 1) // 32)):
-        _ = Ps[m].T @ coeffs(sc, m)[0]
+    list(pool.map(lambda m: Ps[m].T @ coeffs(sc, m)[0], range(0, min(cores, nsmax + 1))))
     t_probe = time.time() - t
-    if t_probe * (2 * (nsmax + 1) / 32.0) * 2 > 120.0:
+    if t_probe * (4.0 * (nsmax + 1) / max(1, min(cores, nsmax + 1))) > 240.0:
         pool.shutdown()
-        return {"error": "skipped: 32 panel products took %.1f s with %d BLAS threads on this host" % (t_probe, cores)}
+        return {"error": "skipped: %d concurrent panel products took %.1f s on this host" % (min(cores, nsmax + 1), t_probe)}
+    # one untimed pair first, as the reference harness's warm-up iterations (ectrans-benchmark.F90:47-50): the FFT plans of every
+    # row length, the BLAS threads' buffers and the first touch of the work arrays are set-up, not transform time
+    direct(inverse(sc))
     t = time.time()
     g = inverse(sc)
+    t_inv = time.time() - t
     s2 = direct(g)
     dt = time.time() - t
     rel = lambda a, b: float((np.abs(a - b).max(axis=-1) / np.abs(b).max(axis=-1)).max())
-    e_inv, e_dir = rel(g[:nref], g_ref), rel(s2[:, :nref].T, s_ref.T)
+    e_inv, e_dir = rel(g[:, :nref].T, g_ref), rel(s2[:, :nref].T, s_ref.T)
     pool.shutdown()
     return {"value": (1.0 / dt) * nf / kf_full, "unit": "pairs/s", "cores": cores, "kind": "library BLAS + FFT on the oracle's panels",
-            "libraries": "torch.matmul (MKL, %d threads) for LEINV / LEDIR, scipy.fft (pocketfft) per latitude on a thread pool" % cores,
-            "sample": "same grid+truncation, dense spectrum, %d scalar fields of %d Fourier fields, scaled linearly in KF; panels and thread pool set up outside the timed pair" % (nf, kf_full),
+            "libraries": "torch.matmul (MKL, sequential) for LEINV / LEDIR on a pool of %d threads over the zonal wavenumbers (the reference: OpenMP over m, "
+                         "sequential DGEMM per thread), scipy.fft (pocketfft) per latitude on the same pool" % cores,
+            "sample": "same grid+truncation, dense spectrum, %d scalar fields (%d columns per panel product) of %d Fourier fields, scaled linearly in KF; "
+                      "panels and thread pool set up outside the timed pair" % (nf, 2 * nf, kf_full),
+            "seconds_at_sample": dict(tm, inverse=t_inv, direct=dt - t_inv),
             "inv_max_rel_err_vs_oracle": e_inv, "dir_max_rel_err_vs_oracle": e_dir}
 
 
@@ -263,6 +297,32 @@ def api_level(et, r, N, kf_full, esz, nf=128, pairs=2):
             "harmonic_check": chk,
             "pageable": {"ms_per_pair_at_kf": tp * 1e3, "effective_GBps": moved / 1e9 / tp, "harmonic_check": chkp,
                          "memory": "pageable host (numpy), EMI_MEM_HOST"}}
+
+
+def fortran_device_resident(N, nlev, nfld, steps, warmup, ms_step_python):
+    """The SAME pair driven from Fortran: ectrans_amd/fortran/emi_bench_host.F90 -- the reference harness's timed loop
+    (ectrans-benchmark.F90:619-769) over the drop-in shim's INV_TRANS / DIR_TRANS (libectrans_mi_f.so, the reference's keyword
+    interfaces) on call-mode-2 arrays that live in device memory (hipMalloc + C_F_POINTER; the shim passes EMI_MEM_AUTO and the
+    library uses them in place).  A child process: it initialises the library and allocates its own fields.  Wall time per pair
+    measured in Fortran with SYSTEM_CLOCK around calls that return when the fields are there."""
+    import subprocess
+    exe = os.path.join(ROOT, "ectrans_amd", "fortran", "emi_bench_host")
+    if not os.path.exists(exe):
+        return {"error": "ectrans_amd/fortran/emi_bench_host is not built (__graft_entry__.build())"}
+    try:
+        p = subprocess.run([exe, str(N), str(nlev), str(nfld), str(steps), str(warmup)], capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "emi_bench_host timed out"}
+    line = [l for l in p.stdout.splitlines() if l.startswith("EMI_BENCH_HOST")]
+    if p.returncode != 0 or not line:
+        return {"error": "emi_bench_host failed (rc %d): %s" % (p.returncode, (p.stdout + p.stderr)[-400:])}
+    import re
+    kv = dict(re.findall(r"(\w+)=\s*([-+0-9.eE]+)", line[0]))
+    avg = float(kv["ms_per_pair_avg"])
+    return {"host": "Fortran (flang) -> libectrans_mi_f.so (shim, reference dummy-argument lists) -> libectrans_mi.so; arrays: hipMalloc + C_F_POINTER, EMI_MEM_AUTO",
+            "pairs_per_s": 1e3 / avg, "ms_per_pair": avg, "ms_per_pair_median": float(kv["ms_per_pair_median"]), "ms_per_pair_min": float(kv["ms_min"]),
+            "ms_per_pair_max": float(kv["ms_max"]), "steps": steps, "warmup": warmup, "kf": int(kv["kf"]), "spectral_norm_rel_error": float(kv["norm_err"]),
+            "setup_s": float(kv["setup_s"]), "vs_python_host_ms_per_step": avg / ms_step_python}
 
 
 def recorded_fft_bound(N, nlev, nfld, esz, world, source_hash):
@@ -320,6 +380,8 @@ def main():
                     help="8: fp64 library (headline metric); 4: fp32 library (BASELINE configs[4]'s arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs: cpu_baseline and the dense sub-record")
     ap.add_argument("--no-api-level", action="store_true", help="skip the host-array (PCIe-inclusive) measurement")
+    ap.add_argument("--no-dense-timing", action="store_true", help="skip the second timed loop on the dense spectrum")
+    ap.add_argument("--no-fortran", action="store_true", help="skip the Fortran host leg (fortran_device_resident)")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--nprtrv", type=int, default=int(os.environ.get("EMI_BENCH_NPRTRV", "1")),
                     help="V-sets (N > 1 only): NPRTRW = N / NPRTRV; levels dealt to the V-sets as ectrans-benchmark.F90:329-344, 440-447")
@@ -470,28 +532,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_loop(steps):
+        """exactly `steps` pairs, bracketed by barrier + synchronize; HIP-event phase timers run inside and are only resolved after
+        the region (accumulating mode): no host synchronisation between the calls.  One event per step boundary on the stream the
+        calls are queued on (the null stream = torch's default stream) gives the per-step times for the median the reference
+        reports (ectrans-benchmark.F90:906-917)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        et.set_profile(2)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i].record()
+            et.inv_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
+            et.dir_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
+        ev[steps].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        sm = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        med = sm[len(sm) // 2] if len(sm) % 2 else 0.5 * (sm[len(sm) // 2 - 1] + sm[len(sm) // 2])
+        phases = et.last_phase_ms()
+        launches = et.last_phase_launches()[1]
+        et.set_profile(0)
+        return dt, sm, med, phases, launches
+
     for _ in range(args.warmup):
         step()
-    # ---- timed region: exactly K steps; HIP-event phase timers run inside and are only resolved after the
-    # region (accumulating mode): no host synchronisation between the calls.  One event per step boundary on the
-    # stream the calls are queued on (the null stream = torch's default stream) gives the per-step times for the
-    # median the reference reports (ectrans-benchmark.F90:906-917).
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    et.set_profile(2)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i].record()
-        et.inv_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
-        et.dir_trans(r, pspvor=spvor, pspdiv=spdiv, pspsc3a=spsc3a, pspsc2=spsc2, pgpuv=gpuv, pgp3a=gp3a, pgp2=gp2, **kv)
-    ev[args.steps].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
-    med_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
-    pack_ms, leg_ms, fft_ms = et.last_phase_ms()
-    leg_launches = et.last_phase_launches()[1]
-    et.set_profile(0)
+    # ---- timed region: the reference harness's input (one harmonic), exactly K steps
+    dt, step_ms, med_ms, (pack_ms, leg_ms, fft_ms), leg_launches = timed_loop(args.steps)
+    n1 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
+
+    # ---- the same loop on a DENSE spectrum (SURVEY 8d; VERDICT r4 #4): every coefficient of every field ~ U(-0.5, 0.5) / (n + 1) from
+    # a seed-20251114 generator, every field distinct, imag(m = 0) = 0, (0, 0) of vor / div = 0 -- filled on the device into the same
+    # arrays.  99.9 % of the harmonic loop's Legendre products multiply zeros; this one shows whether the kernels (and the chip's
+    # clock) care.  `value` stays the harmonic loop, the reference's metric (ectrans-benchmark.F90:1390-1415).
+    dense_t = None
+    if not args.no_dense_timing:
+        nasm0_l = et.trans_inq(r, "nasm0")
+        inv_np1 = np.zeros(nspec2)
+        i00 = None
+        for m in range(N + 1):
+            if nasm0_l[m] > 0:
+                i0 = int(nasm0_l[m]) - 1
+                inv_np1[i0:i0 + 2 * (N - m + 1)] = 1.0 / (np.repeat(np.arange(m, N + 1), 2) + 1.0)
+                if m == 0:
+                    inv_np1[i0 + 1:i0 + 2 * (N + 1):2] = 0.0  # imag(m = 0)
+                    i00 = i0
+        prof = torch.from_numpy(inv_np1).to(device=dev, dtype=spvor.dtype)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(20251114 + rank)
+
+        def fill(a, spec_axis, zero00):
+            shape = [1] * a.dim()
+            shape[spec_axis] = nspec2
+            for lo in range(0, a.shape[-1], 8):  # in slices of the last axis: no second full-size temporary
+                v = a[..., lo:lo + 8]
+                v.copy_((torch.rand(v.shape, generator=gen, device=dev, dtype=a.dtype) - 0.5) * prof.view(shape))
+            if zero00 and i00 is not None:
+                a.select(spec_axis, i00).zero_()
+
+        fill(spvor, 0, True), fill(spdiv, 0, True), fill(spsc3a, 1, False), fill(spsc2, 0, False)
+        nd0 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
+        step()
+        d_dt, d_sm, d_med, (d_pack, d_leg, d_fft), d_launch = timed_loop(args.steps)
+        nd1 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
+        dense_t = {"dt": d_dt, "med": d_med, "pack": d_pack, "leg": d_leg, "fft": d_fft, "launches": d_launch, "drift": abs(nd0 / nd1 - 1.0)}
     kf_l = 2 * nlevl + nfld * nlevl + nsc2l  # Legendre / Fourier-space fields of this rank (= kf without V-sets)
     wm = et.work_model(r, kf_l)
     # algorithmic HBM bytes of this rank (SURVEY 8d: each array touched once per phase it belongs to, both directions)
@@ -516,7 +620,10 @@ def main():
         wm["legendre_flops"], wm["fourier_bytes"], ngptot = float(red[0]), float(red[1]), int(red[2].item())
         alg_leg_bytes, alg_pair_bytes = float(red[3]), float(red[4])
         leg_ms, fft_ms, pack_ms = (float(x) for x in mx)
-    n1 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
+        if dense_t is not None:
+            mxd = torch.tensor([dense_t[k] for k in ("dt", "med", "pack", "leg", "fft")], dtype=torch.float64, device=rdev)
+            dist.all_reduce(mxd, op=dist.ReduceOp.MAX)
+            dense_t.update(zip(("dt", "med", "pack", "leg", "fft"), (float(x) for x in mxd)))
 
     if rank == 0:
         # per launch: algorithmic flops of the launch (all ranks) / average launch duration (slowest rank)
@@ -563,6 +670,18 @@ def main():
                         "peak_GBps": 8000.0 * world},
             "fft_bound": recorded_fft_bound(N, nlev, nfld, esz, world, et.source_hash()),
         }
+        if dense_t is not None:
+            d_ms = dense_t["dt"] / args.steps * 1e3
+            d_ach = wm["legendre_flops"] * 2 * args.steps / max(dense_t["leg"] * 1e-3, 1e-12) / 1e12
+            out["dense_timing"] = {
+                "input": "every coefficient of every field ~ U(-0.5, 0.5) / (n + 1), seed 20251114 (device generator), imag(m=0) = 0, "
+                         "vor/div (0,0) = 0; same arrays, same steps as the harmonic loop above",
+                "ms_per_step": d_ms, "ms_per_step_median": dense_t["med"], "pairs_per_s": args.steps / dense_t["dt"],
+                "phase_ms_per_step": {"spectral_pack_unpack": dense_t["pack"] / args.steps, "legendre_mfma": dense_t["leg"] / args.steps,
+                                      "fft": dense_t["fft"] / args.steps},
+                "roofline_frac": d_ach / (peak * world), "roofline_achieved_TFLOPs": d_ach,
+                "vs_harmonic_ms_per_step": d_ms / ms_step,
+                "spectral_norm_rel_error_round_trip": dense_t["drift"]}
         if world == 1 and not args.no_api_level:
             # free the device-resident benchmark arrays first: the staging buffers of the host calls need the room
             del spvor, spdiv, spsc3a, spsc2, gpuv, gp3a, gp2
@@ -571,6 +690,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             out["cpu_baseline"], out["dense"], out["cpu_baseline_blas"] = cpu_baseline(N, kf, gpu=(et, r, dev) if esz == 8 else None)
+        if world == 1 and esz == 8 and not args.no_fortran:
+            # last leg: this process gives the GPU back (the Fortran host allocates the same 200 GB itself)
+            try:
+                del spvor, spdiv, spsc3a, spsc2, gpuv, gp3a, gp2
+            except NameError:
+                pass
+            et.trans_end()
+            torch.cuda.empty_cache()
+            try:
+                out["fortran_device_resident"] = fortran_device_resident(N, nlev, nfld, args.steps, args.warmup, ms_step)
+            except Exception as e:  # noqa: BLE001 -- a side record must never cost the bench line
+                out["fortran_device_resident"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

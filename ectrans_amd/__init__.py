@@ -26,7 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "libectrans_mi.so")
 _L = None
 
-EMI_MEM_HOST, EMI_MEM_DEVICE = 0, 1
+EMI_MEM_HOST, EMI_MEM_DEVICE, EMI_MEM_AUTO = 0, 1, 2
 
 
 class TransError(RuntimeError):
@@ -128,7 +128,9 @@ def _bind(L):
     L.emi_set_max_batch.argtypes = [C.c_int]
     L.emi_specnorm_partial.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, dp]
     L.emi_gpnorm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_int]
-    L.emi_vordiv_to_uv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.emi_vordiv_to_uv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.emi_ptr_space.argtypes = [C.c_void_p]
+    L.emi_wait.argtypes = [C.c_int]
     L.emi_specnorm_kvset.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, dp]
     L.emi_set_alltoallv.argtypes = [C.c_void_p, C.c_void_p]
     L.emi_set_profile.argtypes = [C.c_int]
@@ -536,7 +538,7 @@ def vordiv_to_uv(pspvor, pspdiv, ksmax, pspu=None, pspv=None):
     pw_, k4 = _ptr(pspv, space)
     if not (tuple(pspvor.shape) == tuple(pspdiv.shape) == tuple(pspu.shape) == tuple(pspv.shape)) or pspvor.ndim != 2:
         raise TransError("VORDIV_TO_UV: PSPVOR, PSPDIV, PSPU, PSPV must be [nspec2, nfld] arrays of one shape")
-    _chk(lib().emi_vordiv_to_uv(int(ksmax), 8 if is64 else 4, space[0], pv_, pd_, pu_, pw_, int(pspvor.shape[1])))
+    _chk(lib().emi_vordiv_to_uv(int(ksmax), 8 if is64 else 4, space[0], pv_, pd_, pu_, pw_, int(pspvor.shape[1]), int(pspvor.shape[0])))
     return pspu, pspv
 
 

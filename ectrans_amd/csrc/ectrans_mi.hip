@@ -161,6 +161,40 @@ int emi_mem_info(size_t *f, size_t *t) {
 static const bool g_oom_hook_set = (g_oom_hook = emi_stage::trim, true);
 #endif
 
+// ---- EMI_MEM_AUTO: where do the caller's arrays live?  The reference GPU back-end treats its caller's arrays as present-or-copyin
+// (gpu/internal/trltog_mod.F90:501-523, trgtol_mod.F90:444-448, ltinv_mod.F90:334-338, updsp_mod.F90:96-97): arrays already on the
+// device are used in place, host arrays are copied.  Device and managed allocations of any visible GPU count as device memory;
+// pageable, pinned and registered host memory is staged (kernels reading rows over PCIe piece by piece would be far slower).
+extern "C" int emi_ptr_space(const void *p) {
+#ifdef EMI_CPU_EMU
+  (void)p;
+  return EMI_MEM_HOST;  // the emulator's "device" memory is host memory: staging is a memcpy
+#else
+  if (!p) return EMI_MEM_HOST;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {  // older runtimes: "invalid value" for memory HIP has never seen
+    (void)hipGetLastError();
+    return EMI_MEM_HOST;
+  }
+  return (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeArray) ? EMI_MEM_DEVICE : EMI_MEM_HOST;
+#endif
+}
+// mem_space of a call -> EMI_MEM_HOST or EMI_MEM_DEVICE; AUTO classifies every array that is present
+static int resolve_space(const char *who, int mem_space, std::initializer_list<const void *> arrays, int *out) {
+  if (mem_space == EMI_MEM_HOST || mem_space == EMI_MEM_DEVICE) {
+    *out = mem_space;
+    return 0;
+  }
+  if (mem_space != EMI_MEM_AUTO) EMI_FAIL(EMI_ERR_ARG, "%s: mem_space = %d (EMI_MEM_HOST, EMI_MEM_DEVICE or EMI_MEM_AUTO)", who, mem_space);
+  int ndev = 0, nhost = 0;
+  for (const void *q : arrays)
+    if (q) (emi_ptr_space(q) == EMI_MEM_DEVICE ? ndev : nhost)++;
+  if (ndev && nhost)
+    EMI_FAIL(EMI_ERR_ARG, "%s: %d ARRAYS OF THE CALL ARE IN DEVICE MEMORY AND %d IN HOST MEMORY (all of them must live in one place)", who, ndev, nhost);
+  *out = ndev ? EMI_MEM_DEVICE : EMI_MEM_HOST;
+  return 0;
+}
+
 template <class T>
 static int upload(const std::vector<T> &h, T **d) {
   void *p = nullptr;
@@ -2805,6 +2839,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
 }
 
 static int specnorm_sumsq(Plan &P, int mem_space, const void *spec, int nfld, double *sumsq) {
+  if (resolve_space("SPECNORM", mem_space, {spec}, &mem_space)) return EMI_ERR_ARG;
   HostStage hs(P.esz);
   // SPECNORM has no stream argument: it runs on the null stream behind the last transform of this resolution
   // (which may have been queued on a non-blocking stream, e.g. the DIR_TRANS that produced `spec`)
@@ -2858,7 +2893,10 @@ extern "C" int emi_specnorm(int kresol, int mem_space, const void *spec, int nfl
   if (nfld < 0 || (nfld > 0 && (!spec || !norms)) || (nfld == 0 && Pp->nprv == 1)) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: bad arguments");
   if (Pp->nproc > 1 && Pp->nprv == 1 && !G.hc_gather)
     EMI_FAIL(EMI_ERR_STATE, "SPECNORM: several tasks and no host collectives (emi_set_host_collectives): use emi_specnorm_partial and sum over tasks");
-  if (nfld > 0 && specnorm_sumsq(*Pp, mem_space, spec, nfld, norms)) return EMI_ERR_RUNTIME;
+  if (nfld > 0) {
+    const int rc = specnorm_sumsq(*Pp, mem_space, spec, nfld, norms);
+    if (rc) return rc;
+  }
   if (Pp->nproc > 1 && Pp->nprv == 1) {  // spnormc_mod.F90:49-85 gathers the partial sums on the master; here every task gets the norms
     const int NP = Pp->nproc;
     std::vector<double> all((size_t)NP * nfld);
@@ -2894,7 +2932,10 @@ extern "C" int emi_specnorm_kvset(int kresol, int mem_space, const void *spec, i
   if (mine != nfld) EMI_FAIL(EMI_ERR_ARG, "SPECNORM: %d fields of KVSET belong to this V-set, PSPEC holds %d", mine, nfld);
   if (P.nprv == 1) return emi_specnorm(kresol, mem_space, spec, nfld, norms_g);
   std::vector<double> part((size_t)nfld + 1, 0.0);
-  if (nfld > 0 && specnorm_sumsq(P, mem_space, spec, nfld, part.data())) return EMI_ERR_RUNTIME;
+  if (nfld > 0) {
+    const int rc = specnorm_sumsq(P, mem_space, spec, nfld, part.data());
+    if (rc) return rc;
+  }
   std::vector<std::vector<double>> byv;
   if (specnorm_vsets(P, part.data(), nfld, byv)) return EMI_ERR_RUNTIME;
   std::vector<int> k(P.nprv, 0);
@@ -2937,6 +2978,7 @@ extern "C" int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld
   if (kfields <= 0 || !gp || !ave || !pmin || !pmax) EMI_FAIL(EMI_ERR_ARG, "GPNORM_TRANS: bad arguments");
   if (gp_nfld < kfields) EMI_FAIL(EMI_ERR_ARG, "GPNORM_TRANS_CTL:SECOND DIMENSION OF PGP TOO SMALL (%d < %d)", gp_nfld, kfields);
   if (G.nproc_all > 1 && !G.hc_gather) EMI_FAIL(EMI_ERR_STATE, "GPNORM_TRANS: several tasks and no host collectives (emi_set_host_collectives)");
+  if (resolve_space("GPNORM_TRANS", mem_space, {gp}, &mem_space)) return EMI_ERR_ARG;
   const int j0 = P.vfirst(P.me, P.mev), j1 = P.vlast(P.me, P.mev), nl = j1 - j0;
   std::vector<int> rowoff(nl + 1, 0);
   for (int j = 0; j < nl; j++) rowoff[j + 1] = rowoff[j] + P.nloen[j0 + j];
@@ -3014,7 +3056,7 @@ extern "C" int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld
 // VORDIV_TO_UV (cpu/external/vordiv_to_uv.F90:11-178): spectral vorticity / divergence -> spectral U = u cos(theta), V = v cos(theta), for the
 // wavenumbers of this task's W-set (suwavedi_mod.F90:118-137), n <= KSMAX.  Needs SETUP_TRANS0 only (the reference sets up and releases a
 // spectral-only resolution inside the call); precision: 8 or 4 bytes per real of the four arrays PSP*(nfld, nspec2).
-extern "C" int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const void *spvor, const void *spdiv, void *spu, void *spv, int nfld) {
+extern "C" int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const void *spvor, const void *spdiv, void *spu, void *spv, int nfld, int nspec2_ext) {
   if (!G.init) EMI_FAIL(EMI_ERR_STATE, "VORDIV_TO_UV: SETUP_TRANS0 has not been called");
   if (ksmax < 0 || (precision != 8 && precision != 4)) EMI_FAIL(EMI_ERR_ARG, "VORDIV_TO_UV: bad arguments (KSMAX = %d, precision = %d)", ksmax, precision);
   if (nfld <= 0) return EMI_SUCCESS;
@@ -3039,6 +3081,10 @@ extern "C" int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const v
   for (int n = 1; n <= N + 2; n++) lapin[n + 1] = -(G.ra * G.ra / (double)(n * (n + 1)));  // RLAPIN (pre_suleg_mod.F90:64-69)
   const int nspec2 = 2 * (int)pairm.size();
   if (nspec2 == 0) return EMI_SUCCESS;
+  if (nspec2_ext < nspec2)
+    EMI_FAIL(EMI_ERR_ARG, "VORDIV_TO_UV:SECOND DIMENSION OF PSPVOR / PSPDIV / PSPU / PSPV TOO SMALL (%d < %d spectral coefficients at KSMAX = %d)", nspec2_ext, nspec2,
+             ksmax);
+  if (resolve_space("VORDIV_TO_UV", mem_space, {spvor, spdiv, spu, spv}, &mem_space)) return EMI_ERR_ARG;
   HostStage hs(precision);
   const bool host = mem_space == EMI_MEM_HOST;
   const void *d_vor = hs.in(spvor, (size_t)nspec2 * nfld, host, 0), *d_div = hs.in(spdiv, (size_t)nspec2 * nfld, host, 0);
@@ -3687,21 +3733,46 @@ static int dir_trans_vsets(int kresol, const emi_dirtrans_t *ap, bool adj, const
   return rcode;
 }
 
+// EMI_MEM_AUTO of a transform call: every array of the argument block is classified (emi_ptr_space); the call then runs as
+// EMI_MEM_DEVICE (arrays used in place) or EMI_MEM_HOST (staged) -- or is refused when the arrays are in both places
+template <class A>
+static int resolve_call(const char *who, const A *ap, A &a) {
+  if (!ap) EMI_FAIL(EMI_ERR_ARG, "%s: null argument block", who);
+  a = *ap;
+  return resolve_space(who, ap->mem_space, {ap->spvor, ap->spdiv, ap->spscalar, ap->spsc3a, ap->spsc3b, ap->spsc2, ap->gp, ap->gpuv, ap->gp3a, ap->gp3b, ap->gp2},
+                       &a.mem_space);
+}
 extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *args) {
   EmiRange rg(EMI_LBL_INV);  // GSTATS 4
-  if (G.nprtrv > 1) return inv_trans_vsets(kresol, args, false);
-  return inv_trans_impl(kresol, args, false);
+  emi_invtrans_t a;
+  if (resolve_call("INV_TRANS", args, a)) return EMI_ERR_ARG;
+  if (G.nprtrv > 1) return inv_trans_vsets(kresol, &a, false);
+  return inv_trans_impl(kresol, &a, false);
 }
 extern "C" int emi_dir_trans(int kresol, const emi_dirtrans_t *args) {
   EmiRange rg(EMI_LBL_DIR);  // GSTATS 5
-  if (G.nprtrv > 1) return dir_trans_vsets(kresol, args, false, nullptr);
-  return dir_trans_impl(kresol, args, false);
+  emi_dirtrans_t a;
+  if (resolve_call("DIR_TRANS", args, a)) return EMI_ERR_ARG;
+  if (G.nprtrv > 1) return dir_trans_vsets(kresol, &a, false, nullptr);
+  return dir_trans_impl(kresol, &a, false);
+}
+extern "C" int emi_wait(int kresol) {
+  if (!G.init) EMI_FAIL(EMI_ERR_STATE, "emi_wait: SETUP_TRANS0 has not been called");
+  if (kresol > 0) {
+    Plan *Pp = get_plan(kresol);
+    if (!Pp) EMI_FAIL(EMI_ERR_STATE, "emi_wait: unknown resolution %d", kresol);
+    plan_quiesce(*Pp);
+    return EMI_SUCCESS;
+  }
+  for (Plan *Pp : G.plans)
+    if (Pp && Pp->active) plan_quiesce(*Pp);
+  return EMI_SUCCESS;
 }
 
 // INV_TRANSAD (include/ectrans/inv_transad.h): arguments of INV_TRANS with the intents swapped
 extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {
-  if (!ap) EMI_FAIL(EMI_ERR_ARG, "INV_TRANSAD: null argument block");
-  const emi_invtrans_t &a = *ap;
+  emi_invtrans_t a;
+  if (resolve_call("INV_TRANSAD", ap, a)) return EMI_ERR_ARG;
   emi_dirtrans_t d{};
   d.mem_space = a.mem_space;
   d.spvor = (void *)a.spvor, d.spdiv = (void *)a.spdiv, d.nf_uv = a.nf_uv;
@@ -3723,8 +3794,8 @@ extern "C" int emi_inv_transad(int kresol, const emi_invtrans_t *ap) {
 }
 // DIR_TRANSAD (include/ectrans/dir_transad.h): arguments of DIR_TRANS with the intents swapped
 extern "C" int emi_dir_transad(int kresol, const emi_dirtrans_t *ap) {
-  if (!ap) EMI_FAIL(EMI_ERR_ARG, "DIR_TRANSAD: null argument block");
-  const emi_dirtrans_t &d = *ap;
+  emi_dirtrans_t d;
+  if (resolve_call("DIR_TRANSAD", ap, d)) return EMI_ERR_ARG;
   emi_invtrans_t a{};
   a.mem_space = d.mem_space;
   a.spvor = d.spvor, a.spdiv = d.spdiv, a.nf_uv = d.nf_uv;

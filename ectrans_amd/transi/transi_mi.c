@@ -225,6 +225,13 @@ static int check_global(const struct Trans_t *t, int lglobal) {
   return TRANS_SUCCESS;
 }
 
+/* A transi call returns when its results are there (transi has no stream argument): calls on device-resident arrays are queued
+ * asynchronously by the library, so wait for the resolution's last call here.  Host-array calls have already synchronised. */
+static int run_and_wait(int rc, int handle) {
+  if (rc) return TRANS_ERROR;
+  return emi_wait(handle) ? TRANS_ERROR : TRANS_SUCCESS;
+}
+
 struct DirTrans_t new_dirtrans(struct Trans_t *t) {
   struct DirTrans_t d;
   memset(&d, 0, sizeof(d));
@@ -240,7 +247,7 @@ int trans_dirtrans(struct DirTrans_t *d) {
   if (d->rmeanu || d->rmeanv) return TRANS_NOTIMPL; /* LAM only */
   emi_dirtrans_t a;
   memset(&a, 0, sizeof(a));
-  a.mem_space = EMI_MEM_HOST;
+  a.mem_space = EMI_MEM_AUTO; /* rgp / rsp* in device memory are used in place, host arrays are staged (emi_ptr_space) */
   if (d->nvordiv > 0) {
     a.spvor = d->rspvor;
     a.spdiv = d->rspdiv;
@@ -256,7 +263,7 @@ int trans_dirtrans(struct DirTrans_t *d) {
   a.kproma = (d->nproma > 0 && !d->lglobal) ? d->nproma : d->trans->ngptot;
   a.gp = d->rgp;
   a.gp_nfld = 2 * d->nvordiv + d->nscalar;
-  return emi_dir_trans(d->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+  return run_and_wait(emi_dir_trans(d->trans->handle, &a), d->trans->handle);
 }
 
 struct InvTrans_t new_invtrans(struct Trans_t *t) {
@@ -274,7 +281,7 @@ int trans_invtrans(struct InvTrans_t *v) {
   if (v->rmeanu || v->rmeanv) return TRANS_NOTIMPL; /* LAM only */
   emi_invtrans_t a;
   memset(&a, 0, sizeof(a));
-  a.mem_space = EMI_MEM_HOST;
+  a.mem_space = EMI_MEM_AUTO; /* rgp / rsp* in device memory are used in place, host arrays are staged (emi_ptr_space) */
   if (v->nvordiv > 0) {
     a.spvor = v->rspvor;
     a.spdiv = v->rspdiv;
@@ -292,7 +299,7 @@ int trans_invtrans(struct InvTrans_t *v) {
   a.gp = v->rgp;
   a.gp_nfld = 2 * v->nvordiv + v->nscalar + (v->lscalarders ? 2 * v->nscalar : 0) + (v->lvordivgp ? 2 * v->nvordiv : 0) +
               (v->luvder_EW ? 2 * v->nvordiv : 0);
-  return emi_inv_trans(v->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+  return run_and_wait(emi_inv_trans(v->trans->handle, &a), v->trans->handle);
 }
 
 /* ---- adjoints ---- */
@@ -310,14 +317,14 @@ int trans_dirtrans_adj(struct DirTransAdj_t *d) {
   if (d->rmeanu || d->rmeanv) return TRANS_NOTIMPL;
   emi_dirtrans_t a;
   memset(&a, 0, sizeof(a));
-  a.mem_space = EMI_MEM_HOST;
+  a.mem_space = EMI_MEM_AUTO; /* rgp / rsp* in device memory are used in place, host arrays are staged (emi_ptr_space) */
   if (d->nvordiv > 0) a.spvor = d->rspvor, a.spdiv = d->rspdiv, a.nf_uv = d->nvordiv;
   if (d->nscalar > 0) a.spscalar = d->rspscalar, a.nf_scalar = d->nscalar;
   if (check_global(d->trans, d->lglobal)) return TRANS_ERROR;
   a.kproma = (d->nproma > 0 && !d->lglobal) ? d->nproma : d->trans->ngptot;
   a.gp = d->rgp; /* written */
   a.gp_nfld = 2 * d->nvordiv + d->nscalar;
-  return emi_dir_transad(d->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+  return run_and_wait(emi_dir_transad(d->trans->handle, &a), d->trans->handle);
 }
 struct InvTransAdj_t new_invtrans_adj(struct Trans_t *t) {
   struct InvTransAdj_t v;
@@ -334,7 +341,7 @@ int trans_invtrans_adj(struct InvTransAdj_t *v) {
   if (check_global(v->trans, v->lglobal)) return TRANS_ERROR;
   emi_invtrans_t a;
   memset(&a, 0, sizeof(a));
-  a.mem_space = EMI_MEM_HOST;
+  a.mem_space = EMI_MEM_AUTO; /* rgp / rsp* in device memory are used in place, host arrays are staged (emi_ptr_space) */
   if (v->nvordiv > 0) a.spvor = v->rspvor, a.spdiv = v->rspdiv, a.nf_uv = v->nvordiv; /* written */
   if (v->nscalar > 0) a.spscalar = v->rspscalar, a.nf_scalar = v->nscalar;
   a.ldscders = v->lscalarders; /* the extra grid fields are further inputs (inv_transad.h) */
@@ -344,7 +351,7 @@ int trans_invtrans_adj(struct InvTransAdj_t *v) {
   a.gp = v->rgp;
   a.gp_nfld = 2 * v->nvordiv + v->nscalar + (v->lscalarders ? 2 * v->nscalar : 0) + (v->lvordivgp ? 2 * v->nvordiv : 0) +
               (v->luvder_EW ? 2 * v->nvordiv : 0);
-  return emi_inv_transad(v->trans->handle, &a) ? TRANS_ERROR : TRANS_SUCCESS;
+  return run_and_wait(emi_inv_transad(v->trans->handle, &a), v->trans->handle);
 }
 
 /* ---- global <-> distributed arrays: DIST_GRID / GATH_GRID / DIST_SPEC / GATH_SPEC of the C-ABI, any task count
@@ -450,7 +457,7 @@ int trans_specnorm(struct SpecNorm_t *s) {
   if (s->count++ > 0) return TRANS_STALE_ARG;
   if (!s->trans || !s->rspec || !s->rnorm || s->nfld <= 0) return TRANS_MISSING_ARG;
   if (s->rmet) return TRANS_NOTIMPL;
-  return emi_specnorm(s->trans->handle, EMI_MEM_HOST, s->rspec, s->nfld, s->rnorm) ? TRANS_ERROR : TRANS_SUCCESS;
+  return emi_specnorm(s->trans->handle, EMI_MEM_AUTO, s->rspec, s->nfld, s->rnorm) ? TRANS_ERROR : TRANS_SUCCESS;
 }
 
 struct VorDivToUV_t new_vordiv_to_UV(void) {
@@ -467,7 +474,7 @@ int trans_vordiv_to_UV(struct VorDivToUV_t *v) {
     const int rc = trans_init();
     if (rc) return rc;
   }
-  return emi_vordiv_to_uv(v->nsmax, 8, EMI_MEM_HOST, v->rspvor, v->rspdiv, v->rspu, v->rspv, v->nfld) ? TRANS_ERROR : TRANS_SUCCESS;
+  return emi_vordiv_to_uv(v->nsmax, 8, EMI_MEM_AUTO, v->rspvor, v->rspdiv, v->rspu, v->rspv, v->nfld, v->ncoeff) ? TRANS_ERROR : TRANS_SUCCESS;
 }
 
 int trans_delete(struct Trans_t *t) {

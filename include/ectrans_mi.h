@@ -17,9 +17,14 @@
  *      3-D spec  PSPSC3A(nlev, nspec2, nvar)       -> p[(v*nspec2 + ispec)*nlev + l]
  *      grid      PGP(nproma, nfld, ngpblks)        -> p[(blk*nfld + f)*nproma + i]
  *      grid 4-D  PGPUV(nproma, nlev, nvar, ngpblks)-> p[((blk*nvar + v)*nlev + l)*nproma + i]
- *  - pointers are HOST pointers when mem_space == EMI_MEM_HOST (staged over PCIe, the
- *    behaviour a Fortran/C caller of the reference expects) and DEVICE (HBM) pointers when
- *    mem_space == EMI_MEM_DEVICE (zero-copy; what bench.py times).
+ *  - pointers are HOST pointers when mem_space == EMI_MEM_HOST (staged over PCIe) and DEVICE (HBM)
+ *    pointers when mem_space == EMI_MEM_DEVICE (used in place, zero-copy; what bench.py times).
+ *    mem_space == EMI_MEM_AUTO: the library classifies every array of the call (hipPointerGetAttributes):
+ *    all in device memory -> used in place, all in host memory -> staged, a mixture -> EMI_ERR_ARG.  This is
+ *    what the Fortran shim and the transi layer pass, i.e. the reference GPU back-end's present-or-copyin
+ *    treatment of its caller's arrays (trans/gpu/internal/trltog_mod.F90:501-523, trgtol_mod.F90:444-448,
+ *    ltinv_mod.F90:334-338, updsp_mod.F90:96-97): a Fortran / C caller whose fields already live on the
+ *    device (hipMalloc + C_F_POINTER, OpenMP use_device_addr, OpenACC host_data) gets the device-resident rate.
  *  - not thread-safe / not re-entrant, exactly like the reference (module-global state,
  *    trans/cpu/internal/tpm_trans.F90:28-56).
  */
@@ -34,6 +39,14 @@ extern "C" {
 
 #define EMI_MEM_HOST 0
 #define EMI_MEM_DEVICE 1
+#define EMI_MEM_AUTO 2
+/* Where p lives: EMI_MEM_DEVICE for device (or managed) memory of any visible GPU, EMI_MEM_HOST for everything else (pageable,
+ * pinned or registered host memory: it is staged).  The classification behind EMI_MEM_AUTO.                           */
+int emi_ptr_space(const void *p);
+/* Blocks the host until every call queued so far on resolution kresol has finished on the device (kresol <= 0: on every
+ * resolution).  Calls with device-resident arrays return without waiting for their kernels (stream semantics); a host that has
+ * no stream to synchronise -- the Fortran shim, the transi layer -- calls this before it returns to its caller.        */
+int emi_wait(int kresol);
 
 #define EMI_SUCCESS 0
 #define EMI_ERR_ARG (-1)      /* what ABORT_TRANS would have reported about the arguments */
@@ -274,8 +287,10 @@ int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld, int kfiel
 /* ---- VORDIV_TO_UV (trans/include/ectrans/vordiv_to_uv.h:12, cpu/internal/vd2uv_mod.F90:79-120) --------------------------------
  * Spectral vorticity / divergence PSPVOR / PSPDIV(nfld, nspec2) -> spectral U = u cos(theta), V = v cos(theta) in PSPU / PSPV, for
  * the zonal wavenumbers of this task's W-set and total wavenumbers n <= ksmax.  Needs emi_init only (the reference builds and
- * releases a spectral-only resolution inside the call); precision = bytes per real of the four arrays (8 or 4).               */
-int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const void *spvor, const void *spdiv, void *spu, void *spv, int nfld);
+ * releases a spectral-only resolution inside the call); precision = bytes per real of the four arrays (8 or 4).
+ * nspec2 = second extent of the four arrays (UBOUND(PSPVOR,2), transi's ncoeff): the call needs (and touches) the spectral
+ * coefficients of this task's wavenumbers at truncation ksmax and fails with EMI_ERR_ARG when the arrays are shorter.        */
+int emi_vordiv_to_uv(int ksmax, int precision, int mem_space, const void *spvor, const void *spdiv, void *spu, void *spv, int nfld, int nspec2);
 
 /* Broadcast of host bytes from task `root` (1-based) over the attached transport (emi_set_host_collectives): for the layers above,
  * where the reference sends a small array from its master task (GPNORM_TRANSAD, gpnorm_trans_ctlad_mod.F90:108-113).  */

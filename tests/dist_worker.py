@@ -24,7 +24,17 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     on_gpu = os.environ.get("EMI_TEST_DEVICE", "cpu") == "cuda"
-    if on_gpu:  # all ranks share cuda:0; the hook stages the exchange through gloo (ectrans_amd/dist.py)
+    if os.environ.get("EMI_TEST_DEVICE", "cpu") == "cuda_per_rank":
+        # one GPU per task and the NATIVE RCCL transport (ectrans_amd/rccl: grouped ncclSend / ncclRecv over xGMI) -- the configuration of
+        # `bench.py --gpus N`; gloo only carries the 128-byte unique id and SPECNORM's partial sums
+        import torch
+        on_gpu = True
+        dev_ = "cuda:%d" % rank
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=DT)).to(dev_)
+        back = lambda t: t.cpu().numpy().astype(np.float64)
+        torch.cuda.set_device(rank)
+        et.setup_trans0(kmax_resol=2, kprtrw=world, myproc=rank + 1, device=rank, transport=os.environ.get("EMI_TEST_TRANSPORT", "rccl"))
+    elif on_gpu:  # all ranks share cuda:0; the hook stages the exchange through gloo (ectrans_amd/dist.py)
         import torch
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=DT)).to("cuda:0")
         back = lambda t: t.cpu().numpy().astype(np.float64)
