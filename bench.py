@@ -341,7 +341,8 @@ def recorded_fft_bound(N, nlev, nfld, esz, world, source_hash):
             continue
         if js.get("source_hash") == source_hash:
             return {"bound": "SIMD instruction issue (fp64 vector ALU + LDS + other), chip clock lowered under this load",
-                    "simd_issue_share": js["simd_issue_share"], "wave_life_share": js["wave_life_share"], "fft_ms_per_pair_under_profiler": js["fft_ms_per_pair"],
+                    "simd_issue_share": js["simd_issue_share"], "wave_life_share": js["wave_life_share"],
+                    "nonfp_valu_share": js.get("nonfp_valu_share"), "nonfp_valu_share_six_heaviest": js.get("nonfp_valu_share_six_heaviest"), "fft_ms_per_pair_under_profiler": js["fft_ms_per_pair"],
                     "source": os.path.basename(f)}
     return {"bound": None, "source": "no profiles/*_pmc_fft.json for this build (source hash %s): re-run tools/pmc_fft.sh" % source_hash}
 

@@ -1505,10 +1505,15 @@ EMI_DEVFN constexpr int hot_lenp(int pc, int ip) {  // stride of factor ip = pro
   return l;
 }
 
-// one butterfly q of the field at byte offset fo: fft_bfly_at with the stride and the work length known at compile time
-template <int R, int LENP, int S, int DIF, int MASK, int TW, int NOUT, int NZ>
-EMI_DEVFN void hot_bfly_at(int fo, int q, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
+// one butterfly q of the field at byte offset fo: fft_bfly_at with the stride and the work length known at compile time.
+// Round 5: the twiddle table of the pass comes through a buffer descriptor -- the lane offset j is one 32-bit register for all legs and
+// the leg offsets (t - 1) LENP are scalar operands of the load, where the flat loads needed a 64-bit add (two vector instructions)
+// per leg beyond the 4 KiB reach of their immediate offsets (SQ counters, profiles/r5a_pmc_fft.txt: 29 - 31 % of the vector
+// instructions of these kernels were not floating point).
+template <int R, int LENP, int S, int DIF, int TW, int NOUT, int NZ>
+EMI_DEVFN void hot_bfly_at(int fo, int q, const EmiBuf &bt, int sgn) {
   constexpr int len = LENP * R;
+  constexpr unsigned SZ2 = sizeof(real2);
   int blk = 0, j = q;
   if constexpr (len != S) {  // the last pass spans the whole array: block 0
     blk = (int)((unsigned)q / (unsigned)LENP);
@@ -1518,7 +1523,7 @@ EMI_DEVFN void hot_bfly_at(int fo, int q, const real2 *tw, const real2 *ptw, int
   real2 w[R];
   if (TW) {
 #pragma unroll
-    for (int t = 1; t < R; t++) w[t] = (ptw + (t - 1) * LENP)[(unsigned)j];
+    for (int t = 1; t < R; t++) w[t] = emi_buf_ld<real2>(bt, (unsigned)j * SZ2, (unsigned)((t - 1) * LENP) * SZ2);
   }
   const HotLegs<R, LENP> L(fo, base);
   real2 v[R];
@@ -1526,8 +1531,6 @@ EMI_DEVFN void hot_bfly_at(int fo, int q, const real2 *tw, const real2 *ptw, int
   for (int t = 0; t < R; t++) {
     if (t >= NZ)
       v[t] = mk2(0.0, 0.0);
-    else if (MASK)
-      v[t] = (base + t * LENP < nvalid) ? hot_ld(L.at(t)) : mk2(0.0, 0.0);
     else
       v[t] = hot_ld(L.at(t));
   }
@@ -1544,7 +1547,7 @@ EMI_DEVFN void hot_bfly_at(int fo, int q, const real2 *tw, const real2 *ptw, int
   if constexpr (NZ < R && NZ == R / 2 && (R == 8 || R == 4))
     butterfly_hz<R>(v, sgn);
   else
-    butterfly<R>(v, tw, S, sgn);
+    butterfly<R>(v, nullptr, S, sgn);  // the specialised plans hold no radix that needs the root table (2, 3, 4, 5, 8, 6, 9, 10)
   if (TW && DIF) {
 #pragma unroll
     for (int t = 1; t < R; t++) v[t] = cmul(v[t], w[t]);
@@ -1555,13 +1558,14 @@ EMI_DEVFN void hot_bfly_at(int fo, int q, const real2 *tw, const real2 *ptw, int
 // FLAT as fft_pass_body; fsb: bytes between the fields of the workgroup
 // NT: threads of the workgroup (a compile-time property of the plan, hot_threads): with one field per workgroup the
 // butterfly loop has a compile-time trip count and disappears
-template <int NT, int R, int LENP, int S, int DIF, int MASK, int TW, int FLAT, int NOUT = R, int NZ = R>
-EMI_DEVFN void hot_pass_body(int nfl, int fsb, const real2 *tw, const real2 *ptw, int sgn, int nvalid) {
+template <int NT, int R, int LENP, int S, int DIF, int TW, int FLAT, int NOUT = R, int NZ = R>
+EMI_DEVFN void hot_pass_body(int nfl, int fsb, const real2 *ptw, int sgn) {
   constexpr int nb = S / R;
+  const EmiBuf bt = emi_buf_all(ptw);
   if (FLAT) {
     for (int idx = EMI_TID; idx < nfl * nb; idx += NT) {
       const int fl = (int)((unsigned)idx / (unsigned)nb), q = idx - fl * nb;
-      hot_bfly_at<R, LENP, S, DIF, MASK, TW, NOUT, NZ>(fl * fsb, q, tw, ptw, sgn, nvalid);
+      hot_bfly_at<R, LENP, S, DIF, TW, NOUT, NZ>(fl * fsb, q, bt, sgn);
     }
   } else {
     for (int fl = 0; fl < nfl; fl++) {
@@ -1569,45 +1573,55 @@ EMI_DEVFN void hot_pass_body(int nfl, int fsb, const real2 *tw, const real2 *ptw
 #pragma nounroll
       for (int q0 = 0; q0 < nb; q0 += NT) {
         const int q = q0 + EMI_TID;
-        if (q0 + NT <= nb || q < nb) hot_bfly_at<R, LENP, S, DIF, MASK, TW, NOUT, NZ>(fl * fsb, q, tw, ptw, sgn, nvalid);
+        if (q0 + NT <= nb || q < nb) hot_bfly_at<R, LENP, S, DIF, TW, NOUT, NZ>(fl * fsb, q, bt, sgn);
       }
     }
   }
 }
-// blue_middle_at for the specialised kernels (first factor 8: contiguous runs of 8, no zero padding left at this point)
+// blue_middle_at for the specialised kernels (first factor 8: contiguous runs of 8, no zero padding left at this point); the filter
+// spectrum [t][q] through a buffer descriptor (leg offsets t nb as scalar operands)
 template <int R, int S>
-EMI_DEVFN void hot_middle_at(int fo, int q, const real2 *tw, const real2 *bh, int conj_b) {
+EMI_DEVFN void hot_middle_at(int fo, int q, const EmiBuf &bb, int conj_b) {
   constexpr int nb = S / R;
+  constexpr unsigned SZ2 = sizeof(real2);
   real2 v[R], b[R];
 #pragma unroll
-  for (int t = 0; t < R; t++) b[t] = (bh + t * nb)[(unsigned)q];  // filter values, table [t][q]
+  for (int t = 0; t < R; t++) b[t] = emi_buf_ld<real2>(bb, (unsigned)q * SZ2, (unsigned)(t * nb) * SZ2);  // filter values, table [t][q]
   const HotLegs<R, 1> L(fo, q * R);
 #pragma unroll
   for (int t = 0; t < R; t++) v[t] = hot_ld(L.at(t));
-  butterfly<R>(v, tw, S, -1);
+  butterfly<R>(v, nullptr, S, -1);
 #pragma unroll
   for (int t = 0; t < R; t++) v[t] = conj_b ? cmulc(v[t], b[t]) : cmul(v[t], b[t]);
-  butterfly<R>(v, tw, S, +1);
+  butterfly<R>(v, nullptr, S, +1);
 #pragma unroll
   for (int t = 0; t < R; t++) hot_st(L.at(t), v[t]);
 }
 template <int NT, int R, int S, int FLAT>
-EMI_DEVFN void hot_middle(int nfl, int fsb, const real2 *tw, const real2 *bh, int conj_b) {
+EMI_DEVFN void hot_middle(int nfl, int fsb, const real2 *bh, int conj_b) {
   constexpr int nb = S / R;
+  const EmiBuf bb = emi_buf_all(bh);
   if (FLAT) {
     for (int idx = EMI_TID; idx < nfl * nb; idx += NT) {
       const int fl = (int)((unsigned)idx / (unsigned)nb), q = idx - fl * nb;
-      hot_middle_at<R, S>(fl * fsb, q, tw, bh, conj_b);
+      hot_middle_at<R, S>(fl * fsb, q, bb, conj_b);
     }
   } else {
     for (int fl = 0; fl < nfl; fl++) {
 #pragma nounroll
       for (int q0 = 0; q0 < nb; q0 += NT) {
         const int q = q0 + EMI_TID;
-        if (q0 + NT <= nb || q < nb) hot_middle_at<R, S>(fl * fsb, q, tw, bh, conj_b);
+        if (q0 + NT <= nb || q < nb) hot_middle_at<R, S>(fl * fsb, q, bb, conj_b);
       }
     }
   }
+}
+
+// z times the chirp in the input stage of the direct kernels: ONE rounding sequence for the buffer path (row inside an NPROMA block) and
+// the element-wise path (row cut by blocks) -- which of the two a row takes depends on the decomposition, the gathered fields must not
+EMI_DEVFN real2 hot_chirp_mul(real2 z, real2 c) {
+  EMI_FP_STRICT();
+  return mk2(z.x * c.x - z.y * c.y, z.x * c.y + z.y * c.x);
 }
 
 // threads of the workgroup of plan pc in this precision: the host's rule (build_fft_plans: 256 / 512 / 1024 for <= 40 / 80 /
@@ -1640,44 +1654,111 @@ EMI_DEVFN constexpr bool hot_local(int ip) {  // is the pass of factor ip wave-l
 
 // Bluestein convolution chain on the nfl fields of a workgroup: DIF passes nfac-1..1, fused middle, DIT
 // passes 1..nfac-2 (or all of them when LASTDIT), as compile-time recursions over the factor index
+// The first pass reads the legs t < NZ only; the input stages of the kernels clear the work array between the end of the chirped row and
+// NZ LENP (hot_zero_to), so the pass needs no per-leg `index < sz` test
 template <int PC, int IP>
-EMI_DEVFN void hot_dif(real2 *a, int nfl, int fs, const FftPlanDev &pl, const real2 *tw, const real2 *ptw, int nvalid) {
+EMI_DEVFN void hot_dif(int nfl, int fs, const FftPlanDev &pl, const real2 *ptw) {
   constexpr HotPlanC H = hot_plan(PC);
   if constexpr (IP >= 1) {
     if constexpr (IP == H.nfac - 1) {
       // first pass: the chirped row occupies sz <= S/2 elements, i.e. only the legs t < R/2 of an even radix
       constexpr int R = H.fac[IP], NZ = (R % 2 == 0) ? R / 2 : R;
-      hot_pass_body<hot_threads(PC), R, hot_lenp(PC, IP), H.S, 1, 1, 1, (H.nfl > 1), R, NZ>(nfl, fs * (int)sizeof(real2), tw, ptw + pl.ptw_off[IP], -1, nvalid);
+      hot_pass_body<hot_threads(PC), R, hot_lenp(PC, IP), H.S, 1, 1, (H.nfl > 1), R, NZ>(nfl, fs * (int)sizeof(real2), ptw + pl.ptw_off[IP], -1);
     }
     else
-      hot_pass_body<hot_threads(PC), H.fac[IP], hot_lenp(PC, IP), H.S, 1, 0, 1, (H.nfl > 1)>(nfl, fs * (int)sizeof(real2), tw, ptw + pl.ptw_off[IP], -1, H.S);
+      hot_pass_body<hot_threads(PC), H.fac[IP], hot_lenp(PC, IP), H.S, 1, 1, (H.nfl > 1)>(nfl, fs * (int)sizeof(real2), ptw + pl.ptw_off[IP], -1);
     HOT_SYNC(IP, IP - 1);
-    hot_dif<PC, IP - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
+    hot_dif<PC, IP - 1>(nfl, fs, pl, ptw);
   }
 }
+// elements of the work array the first pass reads: the input stage writes (or clears) all of them
+template <int PC>
+EMI_DEVFN constexpr int hot_zero_to() {
+  constexpr HotPlanC H = hot_plan(PC);
+  constexpr int R = H.fac[H.nfac - 1];
+  return (R % 2 == 0) ? H.S / 2 : H.S;
+}
 template <int PC, int IP, int END>
-EMI_DEVFN void hot_dit(real2 *a, int nfl, int fs, const FftPlanDev &pl, const real2 *tw, const real2 *ptw) {
+EMI_DEVFN void hot_dit(int nfl, int fs, const FftPlanDev &pl, const real2 *ptw) {
   constexpr HotPlanC H = hot_plan(PC);
   if constexpr (IP < END) {
     // the very last pass of the convolution (direct transform): only the first half of its outputs is read
     constexpr int R = H.fac[IP], NOUT = (IP == H.nfac - 1) ? (R + 1) / 2 : R;
-    hot_pass_body<hot_threads(PC), R, hot_lenp(PC, IP), H.S, 0, 0, 1, (H.nfl > 1), NOUT>(nfl, fs * (int)sizeof(real2), tw, ptw + pl.ptw_off[IP], +1, H.S);
+    hot_pass_body<hot_threads(PC), R, hot_lenp(PC, IP), H.S, 0, 1, (H.nfl > 1), NOUT>(nfl, fs * (int)sizeof(real2), ptw + pl.ptw_off[IP], +1);
     if constexpr (IP + 1 < H.nfac)
       HOT_SYNC(IP, IP + 1);
     else
       EMI_SYNC();
-    hot_dit<PC, IP + 1, END>(a, nfl, fs, pl, tw, ptw);
+    hot_dit<PC, IP + 1, END>(nfl, fs, pl, ptw);
   }
 }
 template <int PC, int LASTDIT>
-EMI_DEVFN void hot_conv(real2 *a, int nfl, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b, int nvalid) {
+EMI_DEVFN void hot_conv(int nfl, int fs, const FftPlanDev &pl, const FftTabDev &T, int conj_b) {
   constexpr HotPlanC H = hot_plan(PC);
-  const real2 *tw = (const real2 *)T.tw + pl.tw_off, *bh = (const real2 *)T.bhat + pl.bhat_off;
+  const real2 *bh = (const real2 *)T.bhat + pl.bhat_off;
   const real2 *ptw = (const real2 *)T.ptw;
-  hot_dif<PC, H.nfac - 1>(a, nfl, fs, pl, tw, ptw, nvalid);
-  hot_middle<hot_threads(PC), H.fac[0], H.S, (H.nfl > 1)>(nfl, fs * (int)sizeof(real2), tw, bh, conj_b);
+  hot_dif<PC, H.nfac - 1>(nfl, fs, pl, ptw);
+  hot_middle<hot_threads(PC), H.fac[0], H.S, (H.nfl > 1)>(nfl, fs * (int)sizeof(real2), bh, conj_b);
   HOT_SYNC(0, 1);
-  hot_dit<PC, 1, LASTDIT ? H.nfac : H.nfac - 1>(a, nfl, fs, pl, tw, ptw);
+  hot_dit<PC, 1, LASTDIT ? H.nfac : H.nfac - 1>(nfl, fs, pl, ptw);
+}
+// final DIT pass of the inverse transform of the specialised kernels, stored straight to the grid array (dit_last_to_grid with the
+// stride at compile time): z_i = a'_i conj(chirp_i) / S, x_2i = Re z_i, x_(2i+1) = Im z_i for i = j + t LENP < sz <= (S + 1) / 2, i.e. the
+// outputs t < (R + 1) / 2 only.  Twiddles, chirp and -- for a row inside one NPROMA block (the usual case) -- the grid row itself go
+// through buffer descriptors: the chirp reads as zero and the store is dropped beyond the end of the row, so no output needs a
+// compare, a select or a 64-bit address.
+template <int NT, int R, int LENP, int S>
+EMI_DEVFN void hot_last_to_grid(int nfl, int fsb, const real2 *ptw, const real2 *chirp, int sz, int n, const GridFld *flds, int f0, long long gp0, int nproma) {
+  constexpr int NOUT = (R + 1) / 2, nb = S / R;
+  constexpr unsigned SZ2 = sizeof(real2);
+  const real_t invL = (real_t)(1.0 / (double)S);
+  const EmiBuf bt = emi_buf_all(ptw), b_ch = emi_buf(chirp, (unsigned)sz * SZ2);
+  for (int fl = 0; fl < nfl; fl++) {
+    const GridRow gr = grid_row(flds[f0 + fl], gp0, nproma);
+    const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
+    const EmiBuf b_out = emi_buf(gr.p0 + gr.rem0, flat ? (unsigned)n * (unsigned)sizeof(real_t) : 0u);
+#pragma nounroll
+    for (int q0 = 0; q0 < nb; q0 += NT) {
+      int j = q0 + EMI_TID;  // last pass: one block, j = q
+      if (q0 + NT <= nb || j < nb) {
+        EMI_OPAQUE(j);
+        real2 v[R], w[R], ch[NOUT];
+#pragma unroll
+        for (int t = 1; t < R; t++) w[t] = emi_buf_ld<real2>(bt, (unsigned)j * SZ2, (unsigned)((t - 1) * LENP) * SZ2);
+        const HotLegs<R, LENP> L(fl * fsb, j);
+#pragma unroll
+        for (int t = 0; t < R; t++) v[t] = hot_ld(L.at(t));
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmulc(v[t], w[t]);  // inverse: conjugate twiddles
+        if constexpr (R <= 8) {  // chirp values of the outputs: in flight during the butterfly
+#pragma unroll
+          for (int t = 0; t < NOUT; t++) ch[t] = emi_buf_ld<real2>(b_ch, (unsigned)(j + t * LENP) * SZ2, 0);
+        }
+        butterfly<R>(v, nullptr, S, +1);
+        if constexpr (R > 8) {  // composite radices: no registers to spare during the butterfly
+#pragma unroll
+          for (int t = 0; t < NOUT; t++) ch[t] = emi_buf_ld<real2>(b_ch, (unsigned)(j + t * LENP) * SZ2, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NOUT; t++) {
+          const real2 z = cscale(cmulc(v[t], ch[t]), invL);
+          if (flat) {  // (uniform) i >= sz: dropped by the range check
+            emi_buf_st<real2>(b_out, (unsigned)(j + t * LENP) * SZ2, 0, z);
+          } else {
+            const int i = j + t * LENP;
+            if (i < sz) {
+              if (grid_pair_ok(gr, 2u * i)) {
+                *(real2 *)grid_ptr(gr, 2u * i) = z;
+              } else {
+                *grid_ptr(gr, 2u * i) = z.x;
+                *grid_ptr(gr, 2u * i + 1) = z.y;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
 }
 #undef HOT_SYNC
 
@@ -1692,7 +1773,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   const int lat = Lc.lats[li];
   const FftPlanDev &pl = T.plans[T.planid[lat]];
   const int f0 = (bid - li * Lc.nchunk) * H.nfl;  // H.nfl fields per workgroup
-  const int nfl = (nfld - f0) < H.nfl ? (nfld - f0) : H.nfl;
+  const int nfl = (H.nfl == 1) ? 1 : ((nfld - f0) < H.nfl ? (nfld - f0) : H.nfl);
   const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
   constexpr int fs = FFT_LDS_ELEMS(H.S);
   const real_t racthe = (real_t)g.racthe[lat];
@@ -1740,17 +1821,18 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
           real2 zk, zk2;
           fin_pair(xa[i], xb[i], k, k2, fa, fb, fsc, wk, ck, ck2, zk, zk2);
           a[FPAD(k)] = zk;
-          a[FPAD(k2)] = zk2;
+          a[FPAD(k2)] = zk2;  // k = 0: slot sz, a zero (its chirp value reads as zero)
         }
       }
+      // the rest of what the first pass reads: zero (the pass itself then needs no `index < sz` test per leg)
+      for (int i = sz + 1 + (int)t; i < hot_zero_to<PC>(); i += NT) a[FPAD(i)] = mk2(0.0, 0.0);
     }
   }
   EMI_SYNC();
-  hot_conv<PC, 0>(a, nfl, fs, pl, T, 1, sz);
+  hot_conv<PC, 0>(nfl, fs, pl, T, 1);
   constexpr int last = H.nfac - 1;
-  dit_last_to_grid<H.fac[last], 1, hot_lenp(PC, last)>(a, nfl, fs, H.S, hot_lenp(PC, last), (const real2 *)T.tw + pl.tw_off,
-                                (const real2 *)T.ptw + pl.ptw_off[last], pl, chirp, flds, f0, g.gpoff[lat], nproma);
-  (void)n;
+  hot_last_to_grid<hot_threads(PC), H.fac[last], hot_lenp(PC, last), H.S>(nfl, fs * (int)sizeof(real2), (const real2 *)T.ptw + pl.ptw_off[last], chirp, sz, n, flds, f0,
+                                                                          g.gpoff[lat], nproma);
 }
 
 template <int PC>
@@ -1764,50 +1846,84 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
   const int lat = Lc.lats[li];
   const FftPlanDev &pl = T.plans[T.planid[lat]];
   const int f0 = (bid - li * Lc.nchunk) * H.nfl;
-  const int nfl = (nfld - f0) < H.nfl ? (nfld - f0) : H.nfl;
+  const int nfl = (H.nfl == 1) ? 1 : ((nfld - f0) < H.nfl ? (nfld - f0) : H.nfl);
   const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
   constexpr int fs = FFT_LDS_ELEMS(H.S);
+  constexpr int NT = hot_threads(PC);
+  constexpr unsigned SZ2 = sizeof(real2);
+  const unsigned t = (unsigned)EMI_TID;
   const int fb0 = g.fbase[lat];
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
   const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
   const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
-  // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp
+  const EmiBuf b_ch = emi_buf(chirp, (unsigned)sz * SZ2), b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
+  // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp.  A row inside one NPROMA block (the usual case) is one
+  // buffer: its tail and the chirp beyond sz read as zero, so the loop also clears what the first pass reads past the row
+  // (hot_zero_to) and neither needs a test per element; all loads of a thread first.
   for (int fl = 0; fl < nfl; fl++) {
     const GridFld gf = flds[f0 + fl];
     real2 *a = (real2 *)EMI_LDS_PTR + (long long)fl * fs;
     const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
-    for (int lz = EMI_TID; lz < sz; lz += EMI_NTHREADS) {
-      real2 z;
-      if (flat) {
-        z = *(const real2 *)(gr.p0 + gr.rem0 + 2u * lz);
-      } else if (grid_pair_ok(gr, 2u * lz)) {
-        z = *(const real2 *)grid_ptr(gr, 2u * lz);
-      } else {
-        z.x = *grid_ptr(gr, 2u * lz);
-        z.y = *grid_ptr(gr, 2u * lz + 1);
+    if (flat) {
+      constexpr int TRIPS = (hot_zero_to<PC>() + NT - 1) / NT;
+      const EmiBuf b_in = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));
+      real2 z[TRIPS], c[TRIPS];
+#pragma unroll
+      for (int i = 0; i < TRIPS; i++) {
+        const unsigned off = (t + (unsigned)(NT * i)) * SZ2;
+        z[i] = emi_buf_ld<real2>(b_in, off, 0);
+        c[i] = emi_buf_ld<real2>(b_ch, off, 0);
       }
-      a[FPAD(lz)] = cmul(z, chirp[lz]);
+#pragma unroll
+      for (int i = 0; i < TRIPS; i++) {
+        const int lz = (int)t + NT * i;
+        if ((i + 1) * NT <= hot_zero_to<PC>() || lz < hot_zero_to<PC>()) a[FPAD(lz)] = hot_chirp_mul(z[i], c[i]);
+      }
+    } else {
+      for (int lz = EMI_TID; lz < hot_zero_to<PC>(); lz += NT) {
+        real2 z = mk2(0.0, 0.0);
+        if (lz < sz) {
+          if (grid_pair_ok(gr, 2u * lz)) {
+            z = *(const real2 *)grid_ptr(gr, 2u * lz);
+          } else {
+            z.x = *grid_ptr(gr, 2u * lz);
+            z.y = *grid_ptr(gr, 2u * lz + 1);
+          }
+          z = hot_chirp_mul(z, chirp[lz]);
+        }
+        a[FPAD(lz)] = z;
+      }
     }
   }
   EMI_SYNC();
-  hot_conv<PC, 1>(a, nfl, fs, pl, T, 0, sz);
-  // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
+  hot_conv<PC, 1>(nfl, fs, pl, T, 0);
+  // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN.  Tables through
+  // buffer descriptors; with one task the rows of the latitude are consecutive and the output is one buffer too (lane offset k x row
+  // bytes, one 32-bit multiply per thread)
   const real_t invL = (real_t)(1.0 / (double)H.S);
+  const unsigned rowb = (unsigned)ldf * (unsigned)sizeof(real_t);
   for (int fl = 0; fl < nfl; fl++) {
-  const GridFld gf = flds[f0 + fl];
-  const real2 *a = (const real2 *)EMI_LDS_PTR + (long long)fl * fs;
-  const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
-  for (int k = EMI_TID; k <= nmen; k += EMI_NTHREADS) {
-    const int kb = (k == 0) ? 0 : sz - k;
-    real2 za = a[FPAD(k)], zb = a[FPAD(kb)];
-    za = cscale(cmul(za, chirp[k]), invL);
-    zb = cscale(cmul(zb, chirp[kb]), invL);
-    real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
-    real2 t = cmuli(cmul(rtw[k], d1));
-    real2 x = mk2((real_t)0.5 * (s1.x - t.x), (real_t)0.5 * (s1.y - t.y));
-    *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * (f0 + fl)) = cscale(x, sc);
-  }
+    const GridFld gf = flds[f0 + fl];
+    const real2 *a = (const real2 *)EMI_LDS_PTR + (long long)fl * fs;
+    const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
+    const EmiBuf b_fb = emi_buf(FB + (unsigned long long)(unsigned)fb0 * (unsigned)ldf + 2 * (f0 + fl), frow ? 0u : (unsigned)nmen * rowb + SZ2);
+    unsigned ko = t * rowb;
+    for (int k = EMI_TID; k <= nmen; k += NT, ko += (unsigned)NT * rowb) {
+      const int kb = (k == 0) ? 0 : sz - k;
+      const real2 ca = emi_buf_ld<real2>(b_ch, (unsigned)k * SZ2, 0), cb = emi_buf_ld<real2>(b_ch, (unsigned)kb * SZ2, 0);
+      const real2 wk = emi_buf_ld<real2>(b_rtw, (unsigned)k * SZ2, 0);
+      real2 za = a[FPAD(k)], zb = a[FPAD(kb)];
+      za = cscale(cmul(za, ca), invL);
+      zb = cscale(cmul(zb, cb), invL);
+      real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
+      real2 tt = cmuli(cmul(wk, d1));
+      const real2 x = cscale(mk2((real_t)0.5 * (s1.x - tt.x), (real_t)0.5 * (s1.y - tt.y)), sc);
+      if (!frow)
+        emi_buf_st<real2>(b_fb, ko, 0, x);
+      else
+        *(real2 *)(FB + (unsigned long long)(unsigned)frow[k] * (unsigned)ldf + 2 * (f0 + fl)) = x;
+    }
   }
 }
 

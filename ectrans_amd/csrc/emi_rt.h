@@ -66,6 +66,8 @@ EMI_DEVFN EmiBuf emi_buf(const void *p, unsigned bytes) {
   b.r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
   return b;
 }
+// a whole table: no range limit (the caller's lane offsets are inside it)
+EMI_DEVFN EmiBuf emi_buf_all(const void *p) { return emi_buf(p, 0xFFFFFFFCu); }
 template <class V>
 EMI_DEVFN V emi_buf_ld(const EmiBuf &b, unsigned voff, unsigned soff) {
   static_assert(sizeof(V) == 16 || sizeof(V) == 8, "emi_buf_ld: 8- or 16-byte values");
@@ -174,6 +176,7 @@ struct EmiBuf {
   unsigned bytes;
 };
 inline EmiBuf emi_buf(const void *p, unsigned bytes) { return EmiBuf{(const char *)p, bytes}; }
+inline EmiBuf emi_buf_all(const void *p) { return emi_buf(p, 0xFFFFFFFCu); }
 template <class V>
 inline V emi_buf_ld(const EmiBuf &b, unsigned voff, unsigned soff) {
   V v;
