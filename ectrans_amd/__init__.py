@@ -129,8 +129,9 @@ def _bind(L):
     L.emi_specnorm_partial.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, dp]
     L.emi_gpnorm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_int]
     L.emi_vordiv_to_uv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-    L.emi_ptr_space.argtypes = [C.c_void_p]
-    L.emi_wait.argtypes = [C.c_int]
+    if hasattr(L, "emi_ptr_space"):  # (an older build loaded for an A/B run, tools/ab_libs.sh)
+        L.emi_ptr_space.argtypes = [C.c_void_p]
+        L.emi_wait.argtypes = [C.c_int]
     L.emi_specnorm_kvset.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, dp]
     L.emi_set_alltoallv.argtypes = [C.c_void_p, C.c_void_p]
     L.emi_set_profile.argtypes = [C.c_int]

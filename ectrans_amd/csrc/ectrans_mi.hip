@@ -229,6 +229,7 @@ struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a w
   long long gm_elems = 0;
   std::vector<int> lats;
   int *d_lats = nullptr;
+  FftRowDev *d_rows = nullptr;  // one record per latitude of `lats`
   size_t lds = 0;
 };
 // Legendre tile maps for one column-tile count: block id -> (ml, row tile, column tile).
@@ -856,6 +857,19 @@ static int build_fft_plans(Plan &P) {
   for (FftClass &fc : P.fclass) {
     if (upload(fc.lats, &fc.d_lats)) return EMI_ERR_RUNTIME;
     P.dev_allocs.push_back(fc.d_lats);
+    std::vector<FftRowDev> rows(fc.lats.size());
+    for (size_t i = 0; i < fc.lats.size(); i++) {
+      const int j = fc.lats[i];
+      const FftPlanDev &pl = P.fplans[P.planid[j]];
+      FftRowDev &r = rows[i];
+      r.lat = j, r.planid = P.planid[j], r.n = pl.n, r.sz = pl.sz;
+      r.nmen = P.l_nmen[j], r.fb0 = P.l_fbase[j], r.gpoff = P.l_gpoff[j], r.chirp_off = pl.chirp_off;
+      r.rtw_off = pl.rtw_off, r.bhat_off = pl.bhat_off, r.ptw_off0 = pl.ptw_off[0];
+      r.mr_abc = pl.mr ? (pl.fac[0] | (pl.fac[1] << 8) | (pl.fac[2] << 16) | (pl.fbk << 24)) : 0;
+      r.racthe = P.racthe[P.lat0 + j], r.rw = P.rw[P.lat0 + j];
+    }
+    if (upload(rows, &fc.d_rows)) return EMI_ERR_RUNTIME;
+    P.dev_allocs.push_back(fc.d_rows);
   }
   return 0;
 }
@@ -2032,7 +2046,7 @@ static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, in
     if (fc.lats.empty() || nfld <= 0) continue;
     const int nchunk = (nfld + fc.fbk - 1) / fc.fbk;
     const long long nblocks = (long long)fc.lats.size() * nchunk;
-    FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0};
+    FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0, fc.d_rows};
     const int nthr = fc.nthr;
     if (fc.gmem) {  // work arrays in global memory, one slice per workgroup
       const size_t needb = (size_t)nblocks * fc.gm_elems * 2 * P.esz;

@@ -1770,18 +1770,18 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   real2 *a = (real2 *)EMI_LDS_PTR;
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
-  const int lat = Lc.lats[li];
-  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const FftRowDev rw_ = Lc.rows[li];  // one 64-byte record: everything the input stage needs
+  const FftPlanDev &pl = T.plans[rw_.planid];
   const int f0 = (bid - li * Lc.nchunk) * H.nfl;  // H.nfl fields per workgroup
   const int nfl = (H.nfl == 1) ? 1 : ((nfld - f0) < H.nfl ? (nfld - f0) : H.nfl);
-  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
+  const int n = rw_.n, sz = rw_.sz, nmen = rw_.nmen;
   constexpr int fs = FFT_LDS_ELEMS(H.S);
-  const real_t racthe = (real_t)g.racthe[lat];
-  const real_t adjw = (real_t)(g.rw[lat] / (double)pl.n);  // DIR_TRANSAD only (Lc.adj)
-  const int fb0 = g.fbase[lat];
+  const real_t racthe = (real_t)rw_.racthe;
+  const real_t adjw = (real_t)(rw_.rw / (double)rw_.n);  // DIR_TRANSAD only (Lc.adj)
+  const int fb0 = rw_.fb0;
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
-  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
-  const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
+  const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
+  const real2 *chirp = (const real2 *)T.chirp + rw_.chirp_off;
   // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}), times the chirp
   // Branch-free, the Fourier-row loads of a field first (see k_fft_inv_r16: the plain loop cost four to five serialised memory round
   // trips per pair).
@@ -1832,7 +1832,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_hot(EmiGeomDev g, FftTabDev T, FftL
   hot_conv<PC, 0>(nfl, fs, pl, T, 1);
   constexpr int last = H.nfac - 1;
   hot_last_to_grid<hot_threads(PC), H.fac[last], hot_lenp(PC, last), H.S>(nfl, fs * (int)sizeof(real2), (const real2 *)T.ptw + pl.ptw_off[last], chirp, sz, n, flds, f0,
-                                                                          g.gpoff[lat], nproma);
+                                                                          rw_.gpoff, nproma);
 }
 
 template <int PC>
@@ -1843,19 +1843,19 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
   real2 *a = (real2 *)EMI_LDS_PTR;
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
-  const int lat = Lc.lats[li];
-  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const FftRowDev rw_ = Lc.rows[li];  // one 64-byte record: everything the input stage needs
+  const FftPlanDev &pl = T.plans[rw_.planid];
   const int f0 = (bid - li * Lc.nchunk) * H.nfl;
   const int nfl = (H.nfl == 1) ? 1 : ((nfld - f0) < H.nfl ? (nfld - f0) : H.nfl);
-  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
+  const int n = rw_.n, sz = rw_.sz, nmen = rw_.nmen;
   constexpr int fs = FFT_LDS_ELEMS(H.S);
   constexpr int NT = hot_threads(PC);
   constexpr unsigned SZ2 = sizeof(real2);
   const unsigned t = (unsigned)EMI_TID;
-  const int fb0 = g.fbase[lat];
+  const int fb0 = rw_.fb0;
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
-  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
-  const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
+  const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
+  const real2 *chirp = (const real2 *)T.chirp + rw_.chirp_off;
   const EmiBuf b_ch = emi_buf(chirp, (unsigned)sz * SZ2), b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
   // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp.  A row inside one NPROMA block (the usual case) is one
   // buffer: its tail and the chirp beyond sz read as zero, so the loop also clears what the first pass reads past the row
@@ -1863,7 +1863,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
   for (int fl = 0; fl < nfl; fl++) {
     const GridFld gf = flds[f0 + fl];
     real2 *a = (real2 *)EMI_LDS_PTR + (long long)fl * fs;
-    const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
+    const GridRow gr = grid_row(gf, rw_.gpoff, nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
     if (flat) {
       constexpr int TRIPS = (hot_zero_to<PC>() + NT - 1) / NT;
@@ -1906,7 +1906,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_hot(EmiGeomDev g, FftTabDev T, FftL
   for (int fl = 0; fl < nfl; fl++) {
     const GridFld gf = flds[f0 + fl];
     const real2 *a = (const real2 *)EMI_LDS_PTR + (long long)fl * fs;
-    const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
+    const real_t sc = (Lc.adj ? (real_t)1.0 : (real_t)(rw_.rw / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)rw_.racthe);
     const EmiBuf b_fb = emi_buf(FB + (unsigned long long)(unsigned)fb0 * (unsigned)ldf + 2 * (f0 + fl), frow ? 0u : (unsigned)nmen * rowb + SZ2);
     unsigned ko = t * rowb;
     for (int k = EMI_TID; k <= nmen; k += NT, ko += (unsigned)NT * rowb) {
@@ -2308,23 +2308,22 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
   const bool edge = (NT == 256) ? true : (t < 256u);
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
-  const int lat = Lc.lats[li];
-  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const FftRowDev rw_ = Lc.rows[li];  // one 64-byte record instead of the chain lats -> planid -> plans -> offsets, nmen / fbase / gpoff [lat]
   const int f0 = bid - li * Lc.nchunk;  // one field per workgroup
-  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
-  const int fb0 = g.fbase[lat];
+  const int n = rw_.n, sz = rw_.sz, nmen = rw_.nmen;
+  const int fb0 = rw_.fb0;
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
-  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
-  const EmiBuf b_ch = emi_buf((const real2 *)T.chirp + pl.chirp_off, (unsigned)sz * SZ2);
-  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + pl.ptw_off[0], 7u * 256u * SZ2);
-  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + pl.bhat_off, (unsigned)S * SZ2);
+  const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
+  const EmiBuf b_ch = emi_buf((const real2 *)T.chirp + rw_.chirp_off, (unsigned)sz * SZ2);
+  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + rw_.ptw_off0, 7u * 256u * SZ2);
+  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + rw_.bhat_off, (unsigned)S * SZ2);
   R16_STAMP_BEGIN();
   if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
   // stage 1 (TRGTOL local copy): z_l = x_{2l} + i x_{2l+1}, times the chirp; l = t + 256 a
   real2 v[H];
   if (edge) {
-    const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
+    const GridRow gr = grid_row(gf, rw_.gpoff, nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
     if (flat) {  // whole row inside one NPROMA block and 2-element aligned (uniform): the row is one buffer, its tail reads as zero
       const EmiBuf b_in = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));
@@ -2365,7 +2364,7 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
   EMI_LDS_SYNC();
   R16_STAMP(2);
   // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
-  const real_t sc = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)g.racthe[lat]);
+  const real_t sc = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(rw_.rw / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)rw_.racthe);
   for (int k = (int)t; k <= nmen; k += NT) {
     const int kb = (k == 0) ? 0 : sz - k;
     const real2 za = zbuf[k], zb = zbuf[kb];
@@ -2389,19 +2388,18 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   const bool edge = (NT == 256) ? true : (t < 256u);
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
-  const int lat = Lc.lats[li];
-  const FftPlanDev &pl = T.plans[T.planid[lat]];
+  const FftRowDev rw_ = Lc.rows[li];  // one 64-byte record (see k_fft_dir_r16)
   const int f0 = bid - li * Lc.nchunk;
-  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
-  const real_t racthe = (real_t)g.racthe[lat];
-  const real_t adjw = (real_t)(g.rw[lat] / (double)pl.n);  // DIR_TRANSAD only (Lc.adj)
-  const int fb0 = g.fbase[lat];
+  const int n = rw_.n, sz = rw_.sz, nmen = rw_.nmen;
+  const real_t racthe = (real_t)rw_.racthe;
+  const real_t adjw = (real_t)(rw_.rw / (double)rw_.n);  // DIR_TRANSAD only (Lc.adj)
+  const int fb0 = rw_.fb0;
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
-  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
-  const real2 *chirp = (const real2 *)T.chirp + pl.chirp_off;
+  const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
+  const real2 *chirp = (const real2 *)T.chirp + rw_.chirp_off;
   const EmiBuf b_ch = emi_buf(chirp, (unsigned)sz * SZ2);
-  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + pl.ptw_off[0], 7u * 256u * SZ2);
-  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + pl.bhat_off, (unsigned)S * SZ2);
+  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + rw_.ptw_off0, 7u * 256u * SZ2);
+  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + rw_.bhat_off, (unsigned)S * SZ2);
   R16_STAMP_BEGIN();
   if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
@@ -2467,7 +2465,7 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   R16_STAMP(2);
   // stage 3 (TRLTOG local copy): z_i = conv_i conj(chirp_i) / S; x_{2i} = Re z_i, x_{2i+1} = Im z_i, straight from the registers
   if (edge) {
-    const GridRow gr = grid_row(gf, g.gpoff[lat], nproma);
+    const GridRow gr = grid_row(gf, rw_.gpoff, nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
     if (flat) {
       const EmiBuf b_out = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));

@@ -297,9 +297,9 @@ EMI_DEVFN void mr_pass_any(int R, real2 *a, int fs, int nfl, const MrPassArgs &p
 struct MrGeom {
   int A, B, C, P1, fs;
 };
-EMI_DEVFN MrGeom mr_geom(const FftPlanDev &pl) {
+EMI_DEVFN MrGeom mr_geom(int abc) {  // FftRowDev.mr_abc
   MrGeom m;
-  m.A = pl.fac[0], m.B = pl.fac[1], m.C = pl.fac[2];
+  m.A = abc & 255, m.B = (abc >> 8) & 255, m.C = (abc >> 16) & 255;
   const int bc = m.B * m.C;
   m.P1 = bc | 1;
   m.fs = m.A * m.P1;
@@ -325,17 +325,18 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_mr(EmiGeomDev g, FftTabDev T, FftLa
   real2 *a = (real2 *)EMI_LDS_PTR;
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
-  const int lat = Lc.lats[li];
-  const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = (bid - li * Lc.nchunk) * pl.fbk;
-  const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
-  const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
-  const MrGeom m = mr_geom(pl);
-  const int fb0 = g.fbase[lat];
+  const FftRowDev rw_ = Lc.rows[li];  // one 64-byte record instead of the chain lats -> planid -> plans -> ..., nmen / fbase / gpoff [lat]
+  const FftPlanDev &pl = T.plans[rw_.planid];  // (the permutation table of rows cut by NPROMA blocks only)
+  const int fbk = (int)((unsigned)rw_.mr_abc >> 24);
+  const int f0 = (bid - li * Lc.nchunk) * fbk;
+  const int nfl = (nfld - f0) < fbk ? (nfld - f0) : fbk;
+  const int n = rw_.n, sz = rw_.sz, nmen = rw_.nmen;
+  const MrGeom m = mr_geom(rw_.mr_abc);
+  const int fb0 = rw_.fb0;
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
-  const real2 *rtw = (const real2 *)T.rtw + pl.rtw_off;
-  const real2 *tw1 = (const real2 *)T.ptw + pl.ptw_off[0], *tw2 = (const real2 *)T.ptw + pl.ptw_off[1];
-  const long long gp0 = g.gpoff[lat];
+  const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
+  const real2 *tw1 = (const real2 *)T.ptw + rw_.ptw_off0, *tw2 = tw1 + m.A;
+  const long long gp0 = rw_.gpoff;
   const long long blk0 = gp0 / nproma;
   const unsigned rem0 = (unsigned)(gp0 - blk0 * nproma);
   // stages 1 + 2 (TRGTOL local copy + FTDIR): the first pass reads the grid rows -- unless NPROMA blocks cut them (or a field is not
@@ -386,7 +387,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_mr(EmiGeomDev g, FftTabDev T, FftLa
   {
     const int nk = nmen + 1, ntot = nfl * nk, NT = EMI_NTHREADS;
     const unsigned mnf = mr_magic((unsigned)nfl), mA = mr_magic((unsigned)m.A), mAB = mr_magic((unsigned)(m.A * m.B));
-    const real_t sc0 = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(g.rw[lat] / (double)n)), racthe = (real_t)g.racthe[lat];
+    const real_t sc0 = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(rw_.rw / (double)n)), racthe = (real_t)rw_.racthe;
     auto pos = [&](int k) {
       const int q1 = m.A > 1 ? (int)mr_div((unsigned)k, mA) : k;
       const int k3 = (int)mr_div((unsigned)k, mAB);
@@ -434,11 +435,17 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLa
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
   const int lat = Lc.lats[li];
+  // (the per-latitude record of k_fft_dir_mr was tried here too and LOST 13 %: this kernel sits on a register-allocation edge -- 128
+  // vector registers, 76 bytes of scratch, scalar registers spilled to lanes -- and the compiler placed the spills worse)
   const FftPlanDev &pl = T.plans[T.planid[lat]];
-  const int f0 = (bid - li * Lc.nchunk) * pl.fbk;
-  const int nfl = (nfld - f0) < pl.fbk ? (nfld - f0) : pl.fbk;
+  const int fbk = pl.fbk;
+  const int f0 = (bid - li * Lc.nchunk) * fbk;
+  const int nfl = (nfld - f0) < fbk ? (nfld - f0) : fbk;
   const int n = pl.n, sz = pl.sz, nmen = g.nmen[lat];
-  const MrGeom m = mr_geom(pl);
+  MrGeom m;
+  m.A = pl.fac[0], m.B = pl.fac[1], m.C = pl.fac[2];
+  m.P1 = (m.B * m.C) | 1;
+  m.fs = m.A * m.P1;
   const real_t racthe = (real_t)g.racthe[lat];
   const real_t adjw = (real_t)(g.rw[lat] / (double)pl.n);  // DIR_TRANSAD only (Lc.adj)
   const int fb0 = g.fbase[lat];
@@ -455,7 +462,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLa
     const unsigned mbc = mr_magic((unsigned)bc);
     const int npair = sz / 2 + 1, ntot = nfl * npair, NT = EMI_NTHREADS;
     const unsigned mnf = mr_magic((unsigned)nfl);
-    if (pl.fbk == 1) {  // (a property of the row length, not of the chunk: the same code path in every decomposition)
+    if (fbk == 1) {  // (a property of the row length, not of the chunk: the same code path in every decomposition)
       // one field per workgroup (the long rows): branch-free, four pairs per thread with all their loads first (round 4, as
       // k_fft_inv_r16: behind the `k <= nmen` / FSC-mode branches of the loop below every load waits alone).  One task: the Fourier rows
       // through a buffer descriptor (k > NMEN reads zero); several tasks: clamped look-up in the exchange-order table and a select.  ONE

@@ -111,6 +111,17 @@ struct FftTabDev {
   const int *planid;           // [ndgl]
 };
 
+// Everything a workgroup of the long-row FFT kernels needs to know about its latitude, in ONE 64-byte record per (launch group,
+// latitude): the kernels used to walk lats[li] -> planid[lat] -> plans[..] -> table offsets and nmen / fbase / gpoff / racthe / rw[lat],
+// four dependent scalar loads in front of the first vector load of a workgroup whose whole life is ~25 microseconds (round 4's clock
+// stamps: ~12 % of it).  One s_load_dwordx16 now.
+struct FftRowDev {
+  int lat, planid, n, sz;
+  int nmen, fb0, gpoff, chirp_off;
+  int rtw_off, bhat_off, ptw_off0;
+  int mr_abc;  // k_fft_*_mr: A | B << 8 | C << 16 | fields per workgroup << 24 (the second twiddle table follows the first: ptw_off0 + A)
+  double racthe, rw;
+};
 // block -> (latitude, field chunk) through a per-class prefix table
 struct FftLaunchDev {
   const int *lats;  // latitudes of this launch group (same workgroup size and fields per workgroup)
@@ -119,6 +130,7 @@ struct FftLaunchDev {
   long long nblocks;
   int adj;  // adjoint transforms: k_fft_dir* drop the Gaussian weight and 1/NLOEN (INV_TRANSAD, ftinvad_mod.F90:77-83),
             // k_fft_inv* apply them (DIR_TRANSAD, ledirad_mod.F90:151,183 + ftdirad_mod.F90:84-89)
+  const FftRowDev *rows;  // [nlat] the records of lats[] (k_fft_*_r16, k_fft_*_hot, k_fft_*_mr)
 };
 
 
