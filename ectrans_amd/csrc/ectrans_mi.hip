@@ -308,6 +308,14 @@ struct Plan {
   bool ev_valid = false;
 };
 
+static int roundup(int a, int b) { return (a + b - 1) / b * b; }
+// dynamic LDS of k_leg_dir: the two operand stages, the staged destinations of the tile's 64 fields (1 KiB) and -- fp32 library only; the
+// fp64 kernel takes its Fourier-row numbers through scalar loads -- the row-number tables of the wavenumber (2 x 4 bytes per latitude of
+// a hemisphere, whole 32-latitude stages).  Must fit the 80 KiB the kernel is allowed (set_lds_attrs): checked at SETUP_TRANS.
+static size_t leg_dir_lds_bytes(const Plan &P) {
+  return (size_t)LG_LDS_BYTES_DIR + 1024 + (P.esz == 4 ? (size_t)8 * roundup(P.ndgnh + 1, 32) : 0) + 64;
+}
+
 // order a call on `st` behind the previous call of the same resolution (device-side wait, nothing blocks the host)
 static int plan_begin(Plan &P, emi_stream_t st) {
 #ifndef EMI_CPU_EMU
@@ -401,7 +409,6 @@ extern "C" int emi_init(const emi_init_t *cfg) {
 // ------------------------------------------------------------------------------------------
 // SETUP_TRANS
 // ------------------------------------------------------------------------------------------
-static int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
 // Direct mixed-radix plan of k_fft_*_mr for a complex length sz: radices A, B, C (B, C may be 1) from EMI_MR_RADICES and the
 // workgroup threads for `nf` fields per workgroup, by a lane-time model: a pass of radix R costs ops(R) / R + 15 lane
@@ -433,12 +440,9 @@ static bool mr_choose(int sz, int esz, int fac[3], int &fbk, int &nthr) {
     const size_t per_field = (size_t)A * P1 * 2 * esz;
     if (per_field > 160 * 1024 || A * P1 > 65535) return;
     int fb = 16;
-    const size_t lds_budget = getenv("EMI_FFT_MR_LDS") ? (size_t)atol(getenv("EMI_FFT_MR_LDS")) : 40960;
-    while (fb > 1 && fb * per_field > lds_budget) fb >>= 1;
+    while (fb > 1 && fb * per_field > 40960) fb >>= 1;  // (80 / 160 KiB of fields per workgroup were measured: slower)
     const int R[3] = {A, B, C};
-    const int nt_only = getenv("EMI_FFT_MR_NT") ? atoi(getenv("EMI_FFT_MR_NT")) : 0;  // experiments: one workgroup size for every row
-    for (int nt = 64; nt <= 512; nt += 64) {
-      if (nt_only ? nt != nt_only : (nt < 128 || nt > 256)) continue;
+    for (int nt = 128; nt <= 256; nt += 64) {
       double cost = 0;
       for (int ip = 0; ip < 3; ip++) {
         if (R[ip] == 1) continue;
@@ -504,16 +508,16 @@ static int build_fft_plans(Plan &P) {
     pl.blue = !emi::factorize_smooth(pl.sz, fac);
     pl.S = pl.sz;
     // Register-resident kernels (k_fft_*_r16<R1>, round 3): rows of even length whose Bluestein work length fits 256 R1, R1 from
-    // EMI_R16_LIST and at least 8 -- at TCo1279 every row of 1540 to 4098 points.  EMI_FFT_R16=0 keeps the in-place LDS kernels.
-    // Rows of that range with a 7-smooth half-length take them too (EMI_FFT_R16_SMOOTH=0: the generic mixed-radix kernels): per
+    // EMI_R16_LIST and at least 8 -- at TCo1279 every row of 1540 to 4098 points.  EMI_FFT_R16=0 keeps the in-place LDS kernels (the
+    // tests run the same rows through both families).
+    // Rows of that range with a 7-smooth half-length take them too: per
     // point the generic kernels cost 8.7 ps and row, the convolution 5.5 - 6 ps per work point (profiles/r3c_pmc_fft.txt), although it
     // does four times the arithmetic -- every one of those 100-odd row lengths has its own factor list, which the generic kernels
     // walk at run time.
     // Direct mixed-radix kernels (k_fft_*_mr, round 3): even rows whose half-length is a product of at most three radices of
-    // EMI_MR_RADICES -- no convolution.  EMI_FFT_MR=0: off; EMI_FFT_MR_MIN=sz: only half-lengths of at least sz.
+    // EMI_MR_RADICES -- no convolution.  EMI_FFT_MR=0: off (tests: the same rows through the convolution kernels).
     int mr_fbk = 0, mr_nthr = 0, mr_fac[3] = {1, 1, 1};
-    if (!pl.cmode && pl.sz >= 2 && !(getenv("EMI_FFT_MR") && atoi(getenv("EMI_FFT_MR")) == 0) &&
-        pl.sz >= (getenv("EMI_FFT_MR_MIN") ? atoi(getenv("EMI_FFT_MR_MIN")) : 0))
+    if (!pl.cmode && pl.sz >= 2 && !(getenv("EMI_FFT_MR") && atoi(getenv("EMI_FFT_MR")) == 0))
       pl.mr = mr_choose(pl.sz, P.esz, mr_fac, mr_fbk, mr_nthr) ? 1 : 0;
     if (pl.mr) {
       pl.blue = 0;
@@ -525,9 +529,8 @@ static int build_fft_plans(Plan &P) {
           EMI_R16_LIST(EMI_R16_ROW)
 #undef EMI_R16_ROW
       };
-      const bool smooth_too = !(getenv("EMI_FFT_R16_SMOOTH") && atoi(getenv("EMI_FFT_R16_SMOOTH")) == 0);
       const int need = 2 * pl.sz - 1;
-      if ((pl.blue || smooth_too) && need > 1536)  // shorter rows: in-place kernels with several fields per workgroup
+      if (need > 1536)  // shorter rows: in-place kernels with several fields per workgroup
         for (int r : r1s)
           if (!pl.r16 && 256 * r >= need) pl.r16 = r;
       if (pl.r16) pl.blue = 1;
@@ -540,13 +543,10 @@ static int build_fft_plans(Plan &P) {
       emi::factorize_smooth(pl.S, fac);
       // Specialised kernels (EMI_HOT_PLAN_LIST): the work length and factor list of the cheapest one that is long
       // enough -- cost model S x (passes + 1), as next_235 -- replace the generic choice when they cost no more: that
-      // covers the merged tails (8, 8, 8, 6 | 9 | 10: one LDS round trip fewer than 8, 8, 8, 2, 3 ...; EMI_FFT_MERGE=0
-      // keeps the plain lists) and any work length of the list that is not of the form 2^a {1,3,5,9,15}
-      // (EMI_FFT_FINE=0 skips those; there are none at present, see emi_types.h).
+      // covers the merged tails (8, 8, 8, 6 | 9 | 10: one LDS round trip fewer than 8, 8, 8, 2, 3 ...) and any work length of the
+      // list that is not of the form 2^a {1,3,5,9,15} (there are none at present, see emi_types.h).
       // Even NLOEN only: odd rows run the generic kernels, which have no composite butterflies.  The plan must be the
       // one for the fields-per-workgroup this work length gets (the 40-KiB rule further down).
-      const char *mg = getenv("EMI_FFT_MERGE"), *fine = getenv("EMI_FFT_FINE");
-      const bool no_merge = mg && atoi(mg) == 0, no_fine = fine && atoi(fine) == 0;
       if (!pl.cmode && !getenv("EMI_FFT_NO_HOT")) {
         static const int hp[][9] = {
 #define EMI_HOT_ROW(pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_) {pc_, S_, nf_, a_, b_, c_, d_, e_, nfl_},
@@ -557,11 +557,6 @@ static int build_fft_plans(Plan &P) {
         const int *pick = nullptr;
         for (const auto &r : hp) {
           if (r[1] < 2 * pl.sz - 1) continue;
-          bool composite = false;
-          for (int i = 0; i < r[2]; i++) composite = composite || r[3 + i] == 6 || r[3 + i] > 8;
-          const bool is235 = r[1] == emi::next_235(r[1]);  // one of the 2^a {1,3,5,9,15} lengths
-          if (!is235 && no_fine) continue;
-          if (is235 && composite && no_merge) continue;
           int fbk_r = 16;
           while (fbk_r > 1 && (size_t)fbk_r * FFT_LDS_ELEMS(r[1]) * 2 * P.esz > 40960) fbk_r >>= 1;
           if (fbk_r != r[8]) continue;
@@ -635,7 +630,7 @@ static int build_fft_plans(Plan &P) {
     // 40 KiB, 512 up to 80 KiB, else 1024 -- i.e. always 16 waves per CU at 128 VGPRs.  (One thread per
     // radix-8 butterfly, S/8, removes the idle lanes of the second sweep at S = 2560/3072/4608/5120
     // but makes workgroups of 5, 9 and 10 waves, of which only one fits the 16-wave budget: measured
-    // 25 % slower.  EMI_FFT_THREADS = -1 selects that rule, N >= 64 a fixed size, for experiments.)
+    // 25 % slower.)
     size_t per_field = (size_t)FFT_LDS_ELEMS(pl.S) * 2 * P.esz;
     int fbk = 16;
     while (fbk > 1 && fbk * per_field > 40960) fbk >>= 1;
@@ -646,17 +641,6 @@ static int build_fft_plans(Plan &P) {
     // of a global scratch buffer (k_fft_*_gm): slow per row, but such rows are few
     const bool gmem = need > 160 * 1024;
     int nthr = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);
-    const char *ft = getenv("EMI_FFT_THREADS");
-    if (ft && atoi(ft) == -1) {
-      int rmax = 2;
-      for (int r : fac) rmax = std::max(rmax, r);
-      const long long nbf = (long long)fbk * (pl.S / rmax);
-      for (int k = 1;; k++) {
-        nthr = roundup((int)((nbf + k - 1) / k), 64);
-        if (nthr <= 1024) break;
-      }
-    }
-    if (ft && atoi(ft) >= 64) nthr = std::min(1024, roundup(atoi(ft), 64));
     const int nthr_rule = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);  // what the specialised kernels are compiled for (hot_threads)
     // specialised kernel for this work length?  (Bluestein, even NLOEN, one field per workgroup)
     int hot = 0;
@@ -671,7 +655,7 @@ static int build_fft_plans(Plan &P) {
         for (int i = 0; same && i < pl.nfac; i++) same = r[3 + i] == pl.fac[i];
         if (same) hot = r[0];
       }
-      if (hot) nthr = nthr_rule;  // the specialised kernels are compiled for this size: EMI_FFT_THREADS only reaches the generic ones
+      if (hot) nthr = nthr_rule;  // the specialised kernels are compiled for this size
     }
     if (pl.r16) {  // one field per workgroup, 256 or 320 threads, one plane + the 240 small twiddles of LDS
       hot = 0;
@@ -818,10 +802,6 @@ static int build_fft_plans(Plan &P) {
     else
       fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 2 * P.esz);
   }
-  if (getenv("EMI_DEBUG_FFT"))
-    for (const FftClass &fc : P.fclass)
-      fprintf(stderr, "emi: FFT launch group: %zu latitudes, %d threads, %d fields per workgroup, hot %d, r16 %d, mr %d, gmem %d, LDS %zu bytes\n", fc.lats.size(), fc.nthr,
-              fc.fbk, fc.hot, fc.r16, fc.mr, fc.gmem, fc.lds);
   // exp(-2 pi i c k1 / 256), [k1 - 1][c]: the small twiddles of k_fft_*_r16
   std::vector<d2> tw256(15 * 16);
   for (int k1 = 1; k1 < 16; k1++)
@@ -1081,13 +1061,11 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   // field, both directions, TCo1279 kernel statistics by work length): 20 ps per point up to NLOEN = 1500, falling
   // linearly to 16.9 ps at 4900, plus 1.75 ns per row -- with equal numbers of points the polar tasks of an 8-task
   // TCo1279 job spent 18 % longer in the FFT phase than the equatorial ones (26.8 against 22.6 ms) and set the
-  // job's pace.  EMI_LAT_ROW_COST=0 restores the reference's weight (NLOEN).
-  const char *rowc = getenv("EMI_LAT_ROW_COST");
-  const bool by_cost = !(rowc && atoi(rowc) == 0);
+  // job's pace (the reference's weight is NLOEN).
   std::vector<long long> wcum(L + 1, 0);
   for (int j = 0; j < L; j++) {
     const double n = (double)P.nloen[j];
-    const double w = by_cost ? n * (n <= 1500.0 ? 20.0 : std::max(15.0, 20.0 - (n - 1500.0) * 0.00091)) + 1750.0 : n;
+    const double w = n * (n <= 1500.0 ? 20.0 : std::max(15.0, 20.0 - (n - 1500.0) * 0.00091)) + 1750.0;
     wcum[j + 1] = wcum[j] + (long long)(w + 0.5);
   }
   P.latlo.assign(NP + 1, 0);
@@ -1213,9 +1191,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   P.leg_disp.assign(NP, 0);
   P.fft_rows.assign(NP, 0);
   P.fft_disp.assign(NP, 0);
-  const char *fbo = getenv("EMI_FB_ORDER");
-  const bool mmajor = fbo && fbo[0] == 'm';                 // experiment / A-B: wavenumber-major blocks
-  const bool tables = NP > 1 || mmajor || getenv("EMI_FB_TABLE");  // one task: plain affine rows unless asked
+  const bool tables = NP > 1;  // one task: plain affine rows, no table
   if (!tables) {
     for (int ml = 0; ml < NU; ml++) {
       const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
@@ -1241,18 +1217,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
     for (int d = 1; d < NP; d++) P.leg_disp[d] = P.leg_disp[d - 1] + P.leg_rows[d - 1];
     {
       std::vector<long long> pos(P.leg_disp);
-      if (mmajor) {
-        std::vector<int> rowof(L);
-        for (int ml = 0; ml < NU; ml++) {
-          const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
-          for (int lat = 0; lat < L; lat++)
-            if (P.nmen[lat] >= m) rowof[lat] = (int)pos[band_of(lat)]++;
-          for (int j = 0; j < nd; j++) {
-            legN[P.lbase[ml] + j] = rowof[isl0 + j];
-            legS[P.lbase[ml] + j] = rowof[L - 1 - isl0 - j];
-          }
-        }
-      } else {
+      {
         // the local wavenumbers are ascending, so those present at a latitude are ml = 0 .. cnt-1 and the
         // row of (lat, ml) is the first row of the latitude + ml
         std::vector<long long> latbase(L);
@@ -1277,14 +1242,8 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
     for (int sr = 1; sr < NP; sr++) P.fft_disp[sr] = P.fft_disp[sr - 1] + P.fft_rows[sr - 1];
     {
       std::vector<long long> pos(P.fft_disp);
-      if (mmajor) {
-        for (int m = 0; m <= N; m++)
-          for (int jl = 0; jl < NL; jl++)
-            if (P.l_nmen[jl] >= m) fftrow[P.l_fbase[jl] + m] = (int)pos[P.procm[m]]++;
-      } else {
-        for (int jl = 0; jl < NL; jl++)
-          for (int m = 0; m <= P.l_nmen[jl]; m++) fftrow[P.l_fbase[jl] + m] = (int)pos[P.procm[m]]++;
-      }
+      for (int jl = 0; jl < NL; jl++)
+        for (int m = 0; m <= P.l_nmen[jl]; m++) fftrow[P.l_fbase[jl] + m] = (int)pos[P.procm[m]]++;
     }
     long long tl = 0, tf = 0;
     for (int r = 0; r < NP; r++) tl += P.leg_rows[r], tf += P.fft_rows[r];
@@ -1422,8 +1381,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   g.nump = NU;
   g.nlat = NL;
   g.ngptot = P.ngptot;
-  // EMI_F32_M0_SINGLE=1: the fp32 library treats m = 0 like every other wavenumber (A/B against the reference's rule)
-  g.m0_wide = (P.esz == 4 && !(getenv("EMI_F32_M0_SINGLE") && atoi(getenv("EMI_F32_M0_SINGLE")))) ? 1 : 0;
+  g.m0_wide = P.esz == 4 ? 1 : 0;  // the fp32 library computes zonal wavenumber 0 in double (ledir_mod.F90:133-171)
   g.mval = d_mval;
   g.nmen = d_nmen;
   g.gpoff = d_gpoff;
@@ -1488,6 +1446,11 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       for (void *q : {(void *)d_dcl, (void *)d_ddl, (void *)d_zf, (void *)d_mu, (void *)d_blk}) emi_dev_free(q);
     }
     phase("legendre panels (device)");
+  }
+  if (leg_dir_lds_bytes(P) > 80 * 1024) {
+    delete pp;
+    EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: %d latitudes per hemisphere need %zu bytes of LDS in the direct Legendre kernel (limit 81920): grid too large for the %s library",
+             P.ndgnh, leg_dir_lds_bytes(P), P.esz == 4 ? "fp32" : "fp64");
   }
   int rc = build_fft_plans(P);
   phase("fft plans + tables");
@@ -1911,34 +1874,26 @@ static int ensure_desc(Plan &P, size_t bytes) {
   return 0;
 }
 
-// mg (1, 2, 4 or 8): the XCDs work in mg groups of 8/mg; consecutive wavenumbers go to different groups, and inside
-// a group every XCD takes a range of column tiles (and a residue class of row tiles when there are fewer column
-// tiles than XCDs in the group).  mg = 1: all eight XCDs share every wavenumber.
-// order 0: column tiles innermost (consecutive tiles of an XCD share the panel rows); 1: row tiles innermost (they share the
-// column stream: the Fourier rows of k_leg_dir, the packed spectral rows of k_leg_inv).
-static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int mg, int order, int2 **d_map, long long *nblocks) {
-  const int nx = 8 / mg;  // XCDs per group
+// All eight XCDs share every wavenumber: an XCD takes a range of column tiles (and a residue class of row tiles when there are fewer
+// column tiles than XCDs), column tiles innermost, so that consecutive tiles of an XCD share the panel rows.  (Measured and rejected,
+// wavenumber groups of 4 / 2 / 1 XCDs -- fetched bytes go up, time never down; row tiles innermost -- 10 % fewer
+// bytes for k_leg_dir and 1.4 % more time.)
+static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int2 **d_map, long long *nblocks) {
+  const int nx = 8;  // XCDs
   int gx = 1;
   while (gx * 2 <= std::min(nct, nx)) gx *= 2;
   const int gy = nx / gx;
   std::vector<std::vector<int2>> per(8);
   for (int ml = 0; ml < P.nump; ml++) {
     const int nrt = pref[ml + 1] - pref[ml];
-    const int grp = ml % mg, mlg = ml / mg;
-    for (int xi = 0; xi < nx; xi++) {
-      const int x = grp * nx + xi;
+    for (int x = 0; x < nx; x++) {
       // rotate the column ranges and row residues with the wavenumber: the ranges differ by one tile, rotation
       // evens the per-XCD totals out (a fixed assignment leaves XCDs with 4 of 26 column tiles 23 %
       // more work than those with 3)
-      const int xc = (xi + mlg) % gx, xl = (xi / gx + mlg) % gy;
+      const int xc = (x + ml) % gx, xl = (x / gx + ml) % gy;
       const int c0 = (int)((long long)xc * nct / gx), c1 = (int)((long long)(xc + 1) * nct / gx);
-      if (order == 1) {
-        for (int ct = c0; ct < c1; ct++)
-          for (int rt = xl; rt < nrt; rt += gy) per[x].push_back(int2{ml, (rt << 16) | ct});
-      } else {
-        for (int rt = xl; rt < nrt; rt += gy)
-          for (int ct = c0; ct < c1; ct++) per[x].push_back(int2{ml, (rt << 16) | ct});
-      }
+      for (int rt = xl; rt < nrt; rt += gy)
+        for (int ct = c0; ct < c1; ct++) per[x].push_back(int2{ml, (rt << 16) | ct});
     }
   }
   size_t mx = 0;
@@ -1954,18 +1909,7 @@ static int leg_tilemaps(Plan &P, int nct, LegMaps **out) {
   auto it = P.legmaps.find(nct);
   if (it == P.legmaps.end()) {
     LegMaps lm;
-    auto groups = [](const char *name, int dflt) {
-      const char *e = getenv(name);
-      const int v = e ? atoi(e) : dflt;
-      return (v == 1 || v == 2 || v == 4 || v == 8) ? v : dflt;
-    };
-    auto order = [](const char *name, int dflt) {
-      const char *e = getenv(name);
-      return e ? atoi(e) : dflt;
-    };
-    if (build_tilemap(P, P.lattile_pref, nct, groups("EMI_LEG_INV_MGROUPS", 1), order("EMI_LEG_INV_ORDER", 0), &lm.d_inv, &lm.n_inv) ||
-        build_tilemap(P, P.ktile_pref, nct, groups("EMI_LEG_DIR_MGROUPS", 1), order("EMI_LEG_DIR_ORDER", 0), &lm.d_dir, &lm.n_dir))
-      return EMI_ERR_RUNTIME;
+    if (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv, &lm.n_inv) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir, &lm.n_dir)) return EMI_ERR_RUNTIME;
     it = P.legmaps.emplace(nct, lm).first;
   }
   *out = &it->second;
@@ -2173,15 +2117,10 @@ static Pipeline g_pipe;
 
 // number of field batches to pipeline (1 = plain sequential execution on the caller's stream)
 static int pipeline_depth(const Plan &P, int nfields) {
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char *e = getenv("EMI_PIPELINE");
-    // default 1 = sequential: on MI355X co-running the two kernel families was measured SLOWER
-    // (TCo1279/KF=1645: 555 vs 531 ms per pair with depth 4) -- the FFT kernels need all 16 waves per
-    // CU to hide latency and the Legendre kernels lose MFMA issue slots; kept as an option.
-    cfg = e ? atoi(e) : 1;
-    if (cfg < 1) cfg = 1;
-  }
+  // one task: sequential.  Co-running the two kernel families of neighbouring field batches was measured SLOWER on MI355X
+  // (TCo1279/KF=1645: 555 vs 531 ms per pair with 4 batches; round 2: 400.7 vs 391.7) -- the FFT kernels need all 16 waves per CU
+  // to hide latency and the Legendre kernels lose MFMA issue slots.
+  const int cfg = 1;
 #ifdef EMI_CPU_EMU
   (void)P;
   (void)nfields;
@@ -2714,8 +2653,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
   if (ensure_work(P, bfpad, piped ? 2 : 1, st)) return EMI_ERR_RUNTIME;
   const int ldw_max = 2 * bfpad;  // row width of the widest batch; every batch has its own (2 x its fields rounded up to 64)
   struct Bat { size_t off_g, off_o, off_f; int ng, no, ldw; };
-  // EMI_NO_FUSE_DIR: every field through W and k_postpack_dir (the path before the fused epilogue; A/B)
-  const bool fuse_dir = !getenv("EMI_NO_FUSE_DIR");
+  const bool fuse_dir = true;  // plain-copy fields leave k_leg_dir's epilogue straight for the caller's arrays
   std::vector<Bat> bats;
   std::vector<char> hdesc;
   for (auto &b : batches) {
@@ -2833,7 +2771,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
     emi_dev_memset(FBl + (size_t)lrows_call * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
     const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
     LegMaps *lmaps = bmaps[ib];
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, LG_LDS_BYTES_DIR + 1024 + 8 * roundup(P.ndgnh + 1, P.esz == 4 ? 32 : 16) + 64, sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
+    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, leg_dir_lds_bytes(P), sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);
@@ -2984,6 +2922,7 @@ extern "C" int emi_specnorm_partial(int kresol, int mem_space, const void *spec,
 // task that holds the latitude (whole latitudes here, so the reference's TRGTOL is not needed); the per-latitude values of all tasks
 // are gathered and summed in latitude order on every task (the reference: on task 1), so the average does not depend on the
 // decomposition.  ave_only (LDAVE_ONLY): pmin / pmax come in as the caller's local extrema and are only reduced over the tasks.
+// Host arrays are staged whole (all gp_nfld fields of PGP, although only the first kfields are reduced): a diagnostic, not a hot path.
 extern "C" int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld, int kfields, int kproma, double *ave, double *pmin, double *pmax,
                           int ave_only) {
   Plan *Pp = get_plan(kresol);
@@ -3000,26 +2939,28 @@ extern "C" int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld
   const int nproma = kproma > 0 ? kproma : (int)std::max<long long>(myp, 1);
   const long long ngpblks = myp > 0 ? (myp - 1) / nproma + 1 : 0;
   std::vector<double> loc((size_t)3 * kfields * std::max(nl, 1), 0.0);
+  int lerr = 0;
   if (nl > 0) {
     HostStage hs(P.esz);
     if (plan_begin(P, (emi_stream_t)0)) return EMI_ERR_RUNTIME;  // behind the transform that produced the fields
     const void *d_gp = hs.in(gp, (size_t)nproma * gp_nfld * ngpblks, mem_space == EMI_MEM_HOST, 0);
     int *d_off = nullptr;
     void *d_out = nullptr;
+    // a local failure must not leave the other tasks waiting in the gather below: it travels as a status word of this task's block
     if (hs.failed || upload(rowoff, &d_off) || emi_dev_malloc(&d_out, loc.size() * 8)) {
-      emi_dev_free(d_off);
-      EMI_FAIL(EMI_ERR_RUNTIME, "GPNORM_TRANS: no device memory (%s)", emi_last_error());
+      lerr = 1;
+    } else {
+      EMI_LAUNCH_P(P.esz, k_gpnorm, (long long)nl * kfields, 256, 3 * 256 * 8, (emi_stream_t)0, (const int *)d_off, nl, (const RT *)d_gp, gp_nfld, kfields, nproma,
+                   (double *)d_out);
+      if (emi_d2h(loc.data(), d_out, loc.size() * 8, 0) || emi_stream_sync(0)) lerr = 1;
     }
-    EMI_LAUNCH_P(P.esz, k_gpnorm, (long long)nl * kfields, 256, 3 * 256 * 8, (emi_stream_t)0, (const int *)d_off, nl, (const RT *)d_gp, gp_nfld, kfields, nproma,
-                 (double *)d_out);
-    emi_d2h(loc.data(), d_out, loc.size() * 8, 0);
-    emi_stream_sync(0);
     emi_dev_free(d_off);
     emi_dev_free(d_out);
   }
-  // this task's block: [field][latitude] RW / NLOEN x row sums, then the field minima and maxima
+  // this task's block: [field][latitude] RW / NLOEN x row sums, then the field minima and maxima, then the status word
   const size_t nn = (size_t)kfields * nl;
-  std::vector<double> blk(nn + 2 * (size_t)kfields);
+  std::vector<double> blk(nn + 2 * (size_t)kfields + 1);
+  blk.back() = (double)lerr;
   for (int f = 0; f < kfields; f++) {
     double mn = ave_only ? pmin[f] : 0.0, mx = ave_only ? pmax[f] : 0.0;
     for (int j = 0; j < nl; j++) {
@@ -3042,7 +2983,7 @@ extern "C" int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld
       for (int v = 0; v < P.nprv; v++) {
         const int t = w * P.nprv + v;
         nlat_of[t] = P.vlast(w, v) - P.vfirst(w, v);
-        cnt[t] = 8LL * ((long long)kfields * nlat_of[t] + 2 * kfields), dsp[t] = tot, tot += cnt[t];
+        cnt[t] = 8LL * ((long long)kfields * nlat_of[t] + 2 * kfields + 1), dsp[t] = tot, tot += cnt[t];
       }
     all.resize((size_t)(tot / 8));
     if (G.hc_gather(G.hc_user, blk.data(), cnt[G.myproc_all - 1], all.data(), cnt.data(), dsp.data(), NA)) EMI_FAIL(EMI_ERR_RUNTIME, "GPNORM_TRANS: all-gather-v failed");
@@ -3050,6 +2991,9 @@ extern "C" int emi_gpnorm(int kresol, int mem_space, const void *gp, int gp_nfld
     nlat_of[0] = nl, cnt[0] = 8LL * (long long)blk.size();
     all = blk;
   }
+  for (int t = 0; t < NA; t++)
+    if (all[(size_t)(dsp[t] / 8) + (size_t)kfields * nlat_of[t] + 2 * (size_t)kfields] != 0.0)
+      EMI_FAIL(EMI_ERR_RUNTIME, "GPNORM_TRANS: task %d could not stage or reduce its fields (no device memory?)", t + 1);
   for (int f = 0; f < kfields; f++) {  // latitude order = task order (bands and sub-bands ascend with the task number)
     double a = 0.0, mn = 0.0, mx = 0.0;
     bool first = true;
@@ -3426,6 +3370,7 @@ struct VGroups {
   std::vector<int> osc;            // their owners
   int nsc_g[4] = {0, 0, 0, 0};     // global counts: PSPSCALAR fields, PSPSC2 fields, PSPSC3A levels, PSPSC3B levels
   int nvar3a = 0, nvar3b = 0;      // variables of PSPSC3A / PSPSC3B = IF_SC3A_G3 / IF_SC3B_G3 (inv_trans.F90:277, 310): the same on every task
+  int ext3a = 0, ext3b = 0;        // variables PGP3A / PGP3B have room for (third extent / 3 with LDSCDERS): >= the count, as the reference requires
 };
 template <class ARGS>
 static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) {
@@ -3475,10 +3420,13 @@ static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) 
       // The reference takes the variable count from UBOUND(PSPSC3A,3), which a task whose V-set owns no level still passes as a
       // zero-level array (inv_trans.F90:272-277 aborts without it).  Here such a task may have no spectral array at all, so the
       // count also travels in the KVSET block (from the grid array); without either the peers would disagree on the field list.
-      vg.nvar3a = vs->nvar3a_g > 0 ? vs->nvar3a_g : a.sc3a_nvar;
+      // the count is UBOUND(PSPSC3A,3) wherever the task names one (also with zero levels); the grid array may have room for more
+      // variables than that (the reference only asks UBOUND(PGP3A,3) >= IF_SC3A_G3 [x 3])
+      vg.nvar3a = a.sc3a_nvar > 0 ? a.sc3a_nvar : vs->nvar3a_g;
       if (vg.nvar3a <= 0) EMI_FAIL(EMI_ERR_ARG, "%s:KVSETSC3A BUT NOT PSPSC3A (number of variables unknown: pass sc3a_nvar or emi_vsets_t.nvar3a_g)", who);
-      if (a.sc3a_nvar > 0 && a.sc3a_nvar != vg.nvar3a)
-        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PSPSC3A INCONSISTENT (%d, IF_SC3A_G3 = %d)", who, a.sc3a_nvar, vg.nvar3a);
+      if (vs->nvar3a_g > 0 && vs->nvar3a_g < vg.nvar3a)
+        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3A TOO SMALL (room for %d variables, IF_SC3A_G3 = %d)", who, vs->nvar3a_g, vg.nvar3a);
+      vg.ext3a = std::max(vg.nvar3a, vs->nvar3a_g);
       for (int v = 0; v < vg.nvar3a; v++)
         for (int l = 0; l < vs->nsc3a_g; l++) vg.sc_g.push_back({2, l, v}), vg.osc.push_back(o[l]);
       if (check_local("KVSETSC3A", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3a ? a.sc3a_nlev : 0)) return EMI_ERR_ARG;
@@ -3486,10 +3434,13 @@ static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) 
     if (vs->kvsetsc3b) {
       if (owners(vs->kvsetsc3b, vs->nsc3b_g, "KVSETSC3B", o)) return EMI_ERR_ARG;
       vg.nsc_g[3] = vs->nsc3b_g;
-      vg.nvar3b = vs->nvar3b_g > 0 ? vs->nvar3b_g : a.sc3b_nvar;
+      // the count is UBOUND(PSPSC3B,3) wherever the task names one (also with zero levels); the grid array may have room for more
+      // variables than that (the reference only asks UBOUND(PGP3B,3) >= IF_SC3B_G3 [x 3])
+      vg.nvar3b = a.sc3b_nvar > 0 ? a.sc3b_nvar : vs->nvar3b_g;
       if (vg.nvar3b <= 0) EMI_FAIL(EMI_ERR_ARG, "%s:KVSETSC3B BUT NOT PSPSC3B (number of variables unknown: pass sc3b_nvar or emi_vsets_t.nvar3b_g)", who);
-      if (a.sc3b_nvar > 0 && a.sc3b_nvar != vg.nvar3b)
-        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PSPSC3B INCONSISTENT (%d, IF_SC3B_G3 = %d)", who, a.sc3b_nvar, vg.nvar3b);
+      if (vs->nvar3b_g > 0 && vs->nvar3b_g < vg.nvar3b)
+        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3B TOO SMALL (room for %d variables, IF_SC3B_G3 = %d)", who, vs->nvar3b_g, vg.nvar3b);
+      vg.ext3b = std::max(vg.nvar3b, vs->nvar3b_g);
       for (int v = 0; v < vg.nvar3b; v++)
         for (int l = 0; l < vs->nsc3b_g; l++) vg.sc_g.push_back({3, l, v}), vg.osc.push_back(o[l]);
       if (check_local("KVSETSC3B", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3b ? a.sc3b_nlev : 0)) return EMI_ERR_ARG;
@@ -3503,7 +3454,8 @@ struct VGridList {
   std::vector<int> owner;
 };
 static void v_grid_fields(const VGroups &vg, bool lvorgp, bool ldivgp, bool lscders, bool luvder, void *gp, int gp_nfld, void *gpuv, int uv_dim3,
-                          void *gp2, void *gp3a, int nvar3a, void *gp3b, int nvar3b, VGridList &out) {
+                          void *gp2, void *gp3a, void *gp3b, VGridList &out) {
+  const int nvar3a = vg.nvar3a, nvar3b = vg.nvar3b;
   const int nuv = vg.nuv_g, nsc = (int)vg.sc_g.size(), dmul = lscders ? 3 : 1;
   int gcount = 0, uvvar = 0;
   auto uvf = [&](int lev) {
@@ -3518,8 +3470,8 @@ static void v_grid_fields(const VGroups &vg, bool lvorgp, bool ldivgp, bool lscd
     const ScalarRef &r = vg.sc_g[isc];
     if (gp) { g.base = gp; g.nf_arr = gp_nfld; g.fidx = gcount; }
     else if (r.arr == 1) { g.base = gp2; g.nf_arr = vg.nsc_g[1] * dmul; g.fidx = r.lev + kder * vg.nsc_g[1]; }
-    else if (r.arr == 2) { g.base = gp3a; g.nf_arr = vg.nsc_g[2] * nvar3a * dmul; g.fidx = (r.var + kder * nvar3a) * vg.nsc_g[2] + r.lev; }
-    else { g.base = gp3b; g.nf_arr = vg.nsc_g[3] * nvar3b * dmul; g.fidx = (r.var + kder * nvar3b) * vg.nsc_g[3] + r.lev; }
+    else if (r.arr == 2) { g.base = gp3a; g.nf_arr = vg.nsc_g[2] * vg.ext3a * dmul; g.fidx = (r.var + kder * nvar3a) * vg.nsc_g[2] + r.lev; }
+    else { g.base = gp3b; g.nf_arr = vg.nsc_g[3] * vg.ext3b * dmul; g.fidx = (r.var + kder * nvar3b) * vg.nsc_g[3] + r.lev; }
     out.g.push_back(g), out.owner.push_back(vg.osc[isc]);
     gcount++;
   };
@@ -3607,11 +3559,11 @@ static int inv_trans_vsets(int kresol, const emi_invtrans_t *ap, bool adj) {
   void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host, gpad || a.gp_nfld > if_gp_g, st);
   void *d_gpuv = hs.out(a.gpuv, gsz * nuvg * nvar_uv, host && nuvg, gpad, st);
   void *d_gp2 = hs.out(a.gp2, gsz * vg.nsc_g[1] * dmul, host, gpad, st);
-  void *d_gp3a = hs.out(a.gp3a, gsz * vg.nsc_g[2] * vg.nvar3a * dmul, host, gpad, st);
-  void *d_gp3b = hs.out(a.gp3b, gsz * vg.nsc_g[3] * vg.nvar3b * dmul, host, gpad, st);
+  void *d_gp3a = hs.out(a.gp3a, gsz * vg.nsc_g[2] * vg.ext3a * dmul, host, gpad || vg.ext3a > vg.nvar3a, st);
+  void *d_gp3b = hs.out(a.gp3b, gsz * vg.nsc_g[3] * vg.ext3b * dmul, host, gpad || vg.ext3b > vg.nvar3b, st);
   if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
   VGridList gl;
-  v_grid_fields(vg, lvorgp, ldivgp, lscders, luvder, d_gp, a.gp_nfld, d_gpuv, nvar_uv, d_gp2, d_gp3a, vg.nvar3a, d_gp3b, vg.nvar3b, gl);
+  v_grid_fields(vg, lvorgp, ldivgp, lscders, luvder, d_gp, a.gp_nfld, d_gpuv, nvar_uv, d_gp2, d_gp3a, d_gp3b, gl);
   std::vector<int> nl(P.nprv, 0);  // grid fields every V-set computes
   for (int o : gl.owner) nl[o]++;
   const int nlm = nl[P.mev];
@@ -3698,11 +3650,11 @@ static int dir_trans_vsets(int kresol, const emi_dirtrans_t *ap, bool adj, const
   void *d_gp = (void *)hs.in(a.gp, gsz * a.gp_nfld, host, st);
   void *d_gpuv = (void *)hs.in(a.gpuv, gsz * nuvg * 2, host && nuvg, st);
   void *d_gp2 = (void *)hs.in(a.gp2, gsz * vg.nsc_g[1], host, st);
-  void *d_gp3a = (void *)hs.in(a.gp3a, gsz * vg.nsc_g[2] * vg.nvar3a, host, st);
-  void *d_gp3b = (void *)hs.in(a.gp3b, gsz * vg.nsc_g[3] * vg.nvar3b, host, st);
+  void *d_gp3a = (void *)hs.in(a.gp3a, gsz * vg.nsc_g[2] * vg.ext3a, host, st);
+  void *d_gp3b = (void *)hs.in(a.gp3b, gsz * vg.nsc_g[3] * vg.ext3b, host, st);
   if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
   VGridList gl;  // u(nuv_g) v(nuv_g) scalars: dir_trans.F90:301
-  v_grid_fields(vg, false, false, false, false, d_gp, a.gp_nfld, d_gpuv, 2, d_gp2, d_gp3a, vg.nvar3a, d_gp3b, vg.nvar3b, gl);
+  v_grid_fields(vg, false, false, false, false, d_gp, a.gp_nfld, d_gpuv, 2, d_gp2, d_gp3a, d_gp3b, gl);
   std::vector<int> nl(P.nprv, 0);
   for (int o : gl.owner) nl[o]++;
   const int nlm = nl[P.mev];

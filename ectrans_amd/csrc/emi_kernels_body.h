@@ -1685,7 +1685,12 @@ EMI_DEVFN void hot_dit(int nfl, int fs, const FftPlanDev &pl, const real2 *ptw) 
     // the very last pass of the convolution (direct transform): only the first half of its outputs is read
     constexpr int R = H.fac[IP], NOUT = (IP == H.nfac - 1) ? (R + 1) / 2 : R;
     hot_pass_body<hot_threads(PC), R, hot_lenp(PC, IP), H.S, 0, 1, (H.nfl > 1), NOUT>(nfl, fs * (int)sizeof(real2), ptw + pl.ptw_off[IP], +1);
-    if constexpr (IP + 1 < H.nfac)
+    // The pass that follows the last one of an inverse kernel's chain is hot_last_to_grid, which walks field after field: with several
+    // fields per workgroup its butterflies sit in other waves than those of this pass (dealt flat), so the wave-level fence of HOT_SYNC is
+    // not enough -- a race that showed (one row and field in 10^5, TCo399 / KF = 823) once round 5 had shortened the last pass.
+    if constexpr (IP + 1 == END && END < H.nfac && H.nfl > 1)
+      EMI_SYNC();
+    else if constexpr (IP + 1 < H.nfac)
       HOT_SYNC(IP, IP + 1);
     else
       EMI_SYNC();
@@ -1699,7 +1704,10 @@ EMI_DEVFN void hot_conv(int nfl, int fs, const FftPlanDev &pl, const FftTabDev &
   const real2 *ptw = (const real2 *)T.ptw;
   hot_dif<PC, H.nfac - 1>(nfl, fs, pl, ptw);
   hot_middle<hot_threads(PC), H.fac[0], H.S, (H.nfl > 1)>(nfl, fs * (int)sizeof(real2), bh, conj_b);
-  HOT_SYNC(0, 1);
+  if constexpr (!LASTDIT && H.nfac == 2 && H.nfl > 1)
+    EMI_SYNC();  // hot_last_to_grid follows directly (see hot_dit)
+  else
+    HOT_SYNC(0, 1);
   hot_dit<PC, 1, LASTDIT ? H.nfac : H.nfac - 1>(nfl, fs, pl, ptw);
 }
 // final DIT pass of the inverse transform of the specialised kernels, stored straight to the grid array (dit_last_to_grid with the

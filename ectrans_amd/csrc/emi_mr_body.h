@@ -319,7 +319,7 @@ EMI_DEVFN MrPassArgs mr_args(const MrGeom &m, int ip, const real2 *tw1, const re
   return pa;
 }
 
-EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_mr(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+EMI_KERNEL_MR(EMI_MR_WAVES) void k_fft_dir_mr(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
                                                   int nproma) {
   EMI_LDS_DECL;
   real2 *a = (real2 *)EMI_LDS_PTR;
@@ -428,7 +428,7 @@ EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_dir_mr(EmiGeomDev g, FftTabDev T, FftLa
   MR_STAMP_END();
 }
 
-EMI_KERNEL_FFT(EMI_FFT_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+EMI_KERNEL_MR(EMI_MR_WAVES) void k_fft_inv_mr(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
                                                   int ldf, int nproma) {
   EMI_LDS_DECL;
   real2 *a = (real2 *)EMI_LDS_PTR;

@@ -24,6 +24,8 @@
 // waves per SIMD, so W = 4 lets the scheduler spend 128 VGPRs on keeping loads in flight instead of
 // chasing 8 waves per SIMD; the fp32 kernels need half the LDS and registers and run at W = 8.
 #define EMI_KERNEL_FFT(W) __global__ __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_waves_per_eu(W, W)))
+// direct mixed-radix FFT kernels: workgroups of 128 - 256 threads (mr_choose)
+#define EMI_KERNEL_MR(W) __global__ __attribute__((amdgpu_flat_work_group_size(64, 256), amdgpu_waves_per_eu(W, W)))
 #define EMI_KERNEL_LB2(T, W) __global__ __attribute__((amdgpu_flat_work_group_size(T, T), amdgpu_waves_per_eu(W, W)))
 #define EMI_DEVFN __device__ __forceinline__
 #define EMI_TID ((int)threadIdx.x)
@@ -152,6 +154,7 @@ typedef hipStream_t emi_stream_t;
 #define EMI_KERNEL_LB(T)
 #define EMI_KERNEL_FFT(W)
 #define EMI_KERNEL_LB2(T, W)
+#define EMI_KERNEL_MR(W)
 #define EMI_DEVFN inline
 struct EmuCtx {
   int tid, bid, nthreads;

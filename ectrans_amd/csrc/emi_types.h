@@ -161,18 +161,15 @@ struct FftLaunchDev {
 // workgroup).  The factor lists are what emi::factorize_smooth yields for S and the field count what the
 // 40-KiB rule gives in fp64 (both checked when a plan is matched).  1-8: the rows that carry TCo1279;
 // 9-12: the longer rows of TCo2559 (fp32: up to 10240 points fit the LDS); 13-21: the short rows, several
-// fields per workgroup (most of TCo399); 22-27: plans 3, 5, 6, 16, 17, 19 with their last two factors merged into
-// one composite radix (6, 9, 10: one LDS round trip fewer), preferred when present.
+// fields per workgroup (most of TCo399); 22-27: 3072, 4608, 5120, 640, 576, 384 with their last two factors (2 3, 3 3, 2 5) merged into
+// one composite radix (6, 9, 10: one LDS round trip fewer; the plain five-factor plans 3, 5, 6, 16, 17, 19 they replaced are gone).
 // (Measured and rejected, round 2: nine intermediate work lengths 64 R3 R4 -- 1600, 1728, 1920, 2304, 2880, 3200, 3456,
 // 3840, 5184 as 8, 8, R3, R4 -- cut the summed work length of TCo1279's long rows by 4.5 %, but their third pass is
 // not wave-local and their lanes fill worse: FFT phase 197.9 ms against 197.4 ms without them.)
 #define EMI_HOT_PLAN_LIST(X)          \
   X(1, 2048, 4, 8, 8, 8, 4, 1, 1)     \
   X(2, 2560, 4, 8, 8, 8, 5, 1, 1)     \
-  X(3, 3072, 5, 8, 8, 8, 2, 3, 1)     \
   X(4, 4096, 4, 8, 8, 8, 8, 1, 1)     \
-  X(5, 4608, 5, 8, 8, 8, 3, 3, 1)     \
-  X(6, 5120, 5, 8, 8, 8, 2, 5, 1)     \
   X(7, 1536, 4, 8, 8, 8, 3, 1, 1)     \
   X(8, 1280, 4, 8, 8, 4, 5, 1, 2)     \
   X(9, 6144, 5, 8, 8, 8, 4, 3, 1)     \
@@ -182,10 +179,7 @@ struct FftLaunchDev {
   X(13, 1024, 4, 8, 8, 8, 2, 1, 2)    \
   X(14, 960, 4, 8, 8, 3, 5, 1, 2)     \
   X(15, 768, 4, 8, 8, 4, 3, 1, 2)     \
-  X(16, 640, 4, 8, 8, 2, 5, 1, 4)     \
-  X(17, 576, 4, 8, 8, 3, 3, 1, 4)     \
   X(18, 512, 3, 8, 8, 8, 1, 1, 4)     \
-  X(19, 384, 4, 8, 8, 2, 3, 1, 4)     \
   X(20, 320, 3, 8, 8, 5, 1, 1, 8)     \
   X(21, 256, 3, 8, 8, 4, 1, 1, 8)     \
   X(22, 3072, 4, 8, 8, 8, 6, 1, 1)    \

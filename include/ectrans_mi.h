@@ -145,9 +145,11 @@ typedef struct {
   const int *kvsetsc2;  int nsc2_g;   /* KVSETSC2(nsc2_g)                                          */
   const int *kvsetsc3a; int nsc3a_g;  /* KVSETSC3A(nsc3a_g): V-set of every LEVEL of PSPSC3A       */
   const int *kvsetsc3b; int nsc3b_g;
-  /* Variables of PSPSC3A / PSPSC3B (the reference's IF_SC3A_G3 = UBOUND(PSPSC3A,3), inv_trans.F90:277): every task must name the
-   * same count, also one whose V-set owns no level and therefore passes no spectral array (sc3a_nlev = 0, sc3a_nvar = 0) -- take
-   * it from the grid array (third extent of PGP3A, / 3 with LDSCDERS).  0: sc3a_nvar / sc3b_nvar of the call are used.        */
+  /* Room for variables in PGP3A / PGP3B: their third extent (/ 3 with LDSCDERS).  The number of variables itself (the reference's
+   * IF_SC3A_G3 = UBOUND(PSPSC3A,3), inv_trans.F90:277) is sc3a_nvar / sc3b_nvar of the call wherever a task names it -- a task whose V-set owns
+   * no level passes it with sc3a_nlev = 0, as the reference's zero-level array -- and must be the same on every task; the grid arrays may have
+   * room for more (the reference asks UBOUND(PGP3A,3) >= IF_SC3A_G3 [x 3]), fewer is an error.  0: as many as the call names; a task that
+   * names none (sc3a_nvar = 0) takes the count from here.                                                                                */
   int nvar3a_g, nvar3b_g;
 } emi_vsets_t;
 

@@ -8,16 +8,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,order", [(2, "lat"), (3, "lat"), (2, "m")])  # 4 tasks and more: GPU tier (tests/test_gpu_shims.py)
-def test_wset_sharding_with_alltoallv(world, order):
-    """order: row order inside the exchanged Fourier blocks -- latitude-major (default) or wavenumber-major
-    (EMI_FB_ORDER=m, kept for A/B measurements)."""
+@pytest.mark.parametrize("world", [2, 3])  # 4 tasks and more: GPU tier (tests/test_gpu_shims.py)
+def test_wset_sharding_with_alltoallv(world):
+    """W-set sharding (zonal wavenumbers zig-zag, latitude bands) with the all-to-all-v of whole Fourier blocks over gloo."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
     port = 29510 + world
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1024", EMI_TEST_NSMAX="9", EMI_FB_ORDER=order,
+                   OMP_NUM_THREADS="1024", EMI_TEST_NSMAX="9",
                    EMI_GATH_CHUNK="1000" if world == 3 else "")  # world 3: GATH_* in chunks of one or two fields (the bounded-memory path)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))

@@ -119,11 +119,10 @@ def test_register_resident_fft_kernels_adjoints(et, monkeypatch):
     assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
 
 
-@pytest.mark.parametrize("env", [("EMI_NO_FUSE_DIR", "1"), ("EMI_FB_TABLE", "1"), ("EMI_FB_ORDER", "m"), ("EMI_FFT_NO_HOT", "1"), ("EMI_FFT_MR", "0")])
+@pytest.mark.parametrize("env", [("EMI_FFT_NO_HOT", "1"), ("EMI_FFT_MR", "0")])
 def test_ab_switches_keep_parity(et, monkeypatch, env):
-    """The environment switches kept for A/B measurements select code that must stay correct: every field through
-    W and k_postpack_dir; Fourier rows through the row table on one task; wavenumber-major Fourier rows; the
-    generic FFT kernels only."""
+    """The two switches the tests use to send the same rows through another kernel family: the generic FFT kernels instead of the
+    specialised ones, the convolution kernels instead of the direct mixed-radix ones."""
     monkeypatch.setenv(*env)
     n, nloen, nuv, nsc, flags, nproma = CASES["nproma_blocks"]
     e_inv, e_dir = run_case(et, Oracle, XP, n, nloen, nuv, nsc, flags, nproma)

@@ -259,17 +259,6 @@ def test_register_resident_fft_kernels_adjoints(et, dev, precision, monkeypatch)
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
-def test_unmerged_radix_fft_kernels_match_oracle(et, dev, monkeypatch):
-    """EMI_FFT_MERGE=0: work lengths 3072, 4608, 5120 with plain factor lists (the default merges the last two factors
-    into a composite radix 6, 9, 10; the other specialised-kernel tests cover that)."""
-    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
-    from oracle.oracle import Oracle as O
-    monkeypatch.setenv("EMI_FFT_MERGE", "0")
-    half = [2564, 3068, 4100, 4604, 4612, 5116, 2052, 4092]
-    e_inv, e_dir = run_case(et, O, dev, 15, np.array(half + half[::-1], dtype=np.int32), 1, 1, dict(scders=True), None)
-    assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
-
-
 def test_device_legendre_setup_matches_host_and_oracle(et, monkeypatch):
     """k_legpol (SUPOLF on the GPU, fp contraction off) against the host recurrence bit for bit and
     against the oracle: a full grid F64 / T127 (1e+-100 rescaling near the poles) and TCo639 rows."""
@@ -687,8 +676,7 @@ def test_fp32_library_mean_wavenumber_in_double(et, dev, monkeypatch):
     """fp32 library, zonal wavenumber 0 on the fp64 matrix cores with promoted operands (the reference's sp build:
     "DGEM for the mean to improve mass conservation", cpu/internal/ledir_mod.F90:133-171): the global mean -- coefficient
     (0, 0) -- of TCo399 fields with a 250 K mean matches the oracle's sp mode (float operands, double accumulation for
-    m = 0) to one float ulp and the whole m = 0 column to one ulp of its maximum; with EMI_F32_M0_SINGLE=1 (m = 0 like
-    every other wavenumber: 400 float additions) the mean is visibly worse."""
+    m = 0) to one float ulp and the whole m = 0 column to one ulp of its maximum."""
     to, back = dev
     N = 399
     nloen = octahedral(N)
@@ -703,9 +691,7 @@ def test_fp32_library_mean_wavenumber_in_double(et, dev, monkeypatch):
     ulp = float(np.finfo(np.float32).eps)
     m0 = slice(0, 2 * (N + 1), 2)
     err = {}
-    for single in (False, True):
-        if single:
-            monkeypatch.setenv("EMI_F32_M0_SINGLE", "1")
+    for single in (False,):
         r = et.setup_trans(N, len(nloen), nloen, precision=4)
         try:
             out = to(np.zeros((o.nspec2, nf), dtype=np.float32))
@@ -719,7 +705,6 @@ def test_fp32_library_mean_wavenumber_in_double(et, dev, monkeypatch):
         finally:
             et.trans_release(r)
     assert err[False][0] <= 1.0 and err[False][1] <= 1.0, err
-    assert err[True][0] > err[False][0], err
 
 
 @pytest.mark.parametrize("nsmax,precision", [(10, 8), (21, 8), (10, 4)])
