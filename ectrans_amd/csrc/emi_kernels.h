@@ -29,13 +29,8 @@ namespace emi_f64 {
 #define EMI_MFMA emi_mfma_f64
 #define EMI_ACC_ROW(l, i) (((l) >> 4) + 4 * (i))
 #define EMI_FFT_WAVES 4
-#ifndef EMI_MR_WAVES_F64
-#define EMI_MR_WAVES_F64 4
-#endif
-#define EMI_MR_WAVES EMI_MR_WAVES_F64
 #define EMI_MR_EXTRA(X)
 #include "emi_kernels_body.h"
-#undef EMI_MR_WAVES
 #undef EMI_MR_EXTRA
 #undef EMI_REAL
 #undef EMI_REAL2
@@ -52,7 +47,6 @@ namespace emi_f32 {
 #define EMI_MFMA emi_mfma_f32
 #define EMI_ACC_ROW(l, i) (4 * ((l) >> 4) + (i))
 #define EMI_FFT_WAVES 4
-#define EMI_MR_WAVES 4
 #ifdef EMI_MR_RADICES_F32
 #define EMI_MR_EXTRA(X) EMI_MR_RADICES_F32(X)
 #else
@@ -66,5 +60,4 @@ namespace emi_f32 {
 #undef EMI_MFMA
 #undef EMI_ACC_ROW
 #undef EMI_FFT_WAVES
-#undef EMI_MR_WAVES
 }  // namespace emi_f32

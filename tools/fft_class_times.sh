@@ -2,7 +2,7 @@
 TAG=$1; shift
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for kv in "$@"; do export "$kv"; done
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -o ${TAG} -- python3 tools/gpu_perf.py 1279 137 10 2 > gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -o ${TAG} -- python3 tools/gpu_perf.py ${EMI_PERF_N:-1279} ${EMI_PERF_NLEV:-137} ${EMI_PERF_NFLD:-10} 2 > gpurun_out/${TAG}_stats.log 2>&1
 f=$(find gpurun_out/${TAG}_stats -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/${TAG}_kernel_stats.csv
 python3 - <<PY
