@@ -1,0 +1,21 @@
+#!/bin/bash
+# round-end collection on the GPU box (through gpurun): tests, profiles of the bench command, counters, the other single-GPU configurations
+TAG=${1:-r5z}
+O=gpurun_out
+python3 -m pytest tests -x -q -m gpu > $O/${TAG}_gputests.log 2>&1
+grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" $O/${TAG}_gputests.log | tail -3
+bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.txt 2>&1
+bash tools/pmc_fft.sh $TAG > $O/${TAG}_pmc_fft_stdout.txt 2>&1
+bash tools/pmc_ea.sh $TAG > $O/${TAG}_pmc_ea_stdout.txt 2>&1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_tco1279_driver_cmd.json 2> $O/${TAG}_bench_driver_err.log
+python3 bench.py --nsmax 399 --nfld 4 --steps 20 --warmup 5 --no-fortran > $O/${TAG}_bench_tco399.json 2>> $O/${TAG}_bench_driver_err.log
+python3 bench.py --precision 4 --no-cpu-baseline --no-api-level > $O/${TAG}_bench_tco1279_fp32.json 2>> $O/${TAG}_bench_driver_err.log
+python3 bench.py --nsmax 2559 --precision 4 --steps 3 --warmup 1 --no-cpu-baseline --no-api-level > $O/${TAG}_bench_tco2559_fp32.json 2>> $O/${TAG}_bench_driver_err.log
+for f in tco1279_driver_cmd tco399 tco1279_fp32 tco2559_fp32; do python3 - <<PY
+import json
+try:
+    j=json.loads(open("$O/${TAG}_bench_$f.json").read().strip().splitlines()[-1])
+    print("$f", round(j["value"],3), "pairs/s", round(j["ms_per_step"],2), "ms", j["phase_ms_per_step"], "frac", round(j["roofline"]["frac"],3), "dense", j.get("dense_timing",{}).get("ms_per_step"), "fortran", (j.get("fortran_device_resident") or {}).get("ms_per_pair"))
+except Exception as e: print("$f failed", e)
+PY
+done
