@@ -309,7 +309,7 @@ struct Plan {
 };
 
 static int roundup(int a, int b) { return (a + b - 1) / b * b; }
-// dynamic LDS of k_leg_dir: the two operand stages, the staged destinations of the tile's 64 fields (1 KiB) and -- fp32 library only; the
+// dynamic LDS of k_leg_dir: the operand stage (panel and Fourier rows), the staged destinations of the tile's 64 fields (1 KiB) and -- fp32 library only; the
 // fp64 kernel takes its Fourier-row numbers through scalar loads -- the row-number tables of the wavenumber (2 x 4 bytes per latitude of
 // a hemisphere, whole 32-latitude stages).  Must fit the 80 KiB the kernel is allowed (set_lds_attrs): checked at SETUP_TRANS.
 static size_t leg_dir_lds_bytes(const Plan &P) {
@@ -1143,13 +1143,13 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       P.offS[ml] = poff;
       P.offA[ml] = poff + pan;
       poff += 2 * pan;
-      P.ldk[ml] = roundup(P.wrows[ml] / 2, 64);
+      P.ldk[ml] = roundup(P.wrows[ml] / 2, 128);  // whole 128-k tiles of k_leg_dir (zero padded)
       long long pant = (long long)roundup(std::max(nd, 1), P.esz == 4 ? 32 : 16) * P.ldk[ml];  // k_leg_dir reads stages of 16 (fp64) | 32 (fp32) latitudes (LG_LS)
       P.offTS[ml] = ptoff;
       P.offTA[ml] = ptoff + pant;
       ptoff += 2 * pant;
       P.lattile_pref[ml + 1] = P.lattile_pref[ml] + (nd + 63) / 64;
-      P.ktile_pref[ml + 1] = P.ktile_pref[ml] + (P.wrows[ml] / 2 + 63) / 64;
+      P.ktile_pref[ml + 1] = P.ktile_pref[ml] + 2 * ((P.wrows[ml] / 2 + 127) / 128);  // k_leg_dir tiles: parity + 2 x (tile of 128 n-pairs)
       ebase[ml] = (int)eps.size();
       for (int n = m; n <= N + 2; n++)  // REPSNM (pre_suleg_mod.F90:55-63)
         eps.push_back(std::sqrt((double)(n * n - m * m) / (double)(4 * n * n - 1)));
