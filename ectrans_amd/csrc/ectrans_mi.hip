@@ -1149,7 +1149,11 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       P.offTA[ml] = ptoff + pant;
       ptoff += 2 * pant;
       P.lattile_pref[ml + 1] = P.lattile_pref[ml] + (nd + 63) / 64;
-      P.ktile_pref[ml + 1] = P.ktile_pref[ml] + 2 * ((P.wrows[ml] / 2 + 127) / 128);  // k_leg_dir tiles: parity + 2 x (tile of 128 n-pairs)
+      {  // k_leg_dir's row tiles.  fp64: 2 per 128 n-pairs (one parity each), and for the rest none | one two-parity tile (<= 64 n-pairs) | two;
+         // fp32: two-parity tiles of 64 n-pairs
+        const int nk = P.wrows[ml] / 2, r = nk % 128;
+        P.ktile_pref[ml + 1] = P.ktile_pref[ml] + (P.esz == 4 ? (nk + 63) / 64 : 2 * (nk / 128) + (r == 0 ? 0 : r <= 64 ? 1 : 2));
+      }
       ebase[ml] = (int)eps.size();
       for (int n = m; n <= N + 2; n++)  // REPSNM (pre_suleg_mod.F90:55-63)
         eps.push_back(std::sqrt((double)(n * n - m * m) / (double)(4 * n * n - 1)));

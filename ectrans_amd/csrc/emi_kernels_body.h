@@ -433,16 +433,23 @@ EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const r
 // ---- direct: W[m][n][col] = sum_lat P[lat,n] * (FB_north +- FB_south)[lat][col]
 // (prfi2b_mod.F90:82-94, ledir_mod.F90:100-267 DGEMM('T','N') x2; Gaussian weights and
 //  1/(a cos) were folded into FB by k_fft_dir)
-// tile: 128 k (n-pairs) of ONE parity x 128 columns; wave (wk, wn) owns the 16-row groups wk, wk + 2, wk + 4, wk + 6 of the tile x 64 col
-// (interleaved, so that the last, partial tile of a wavenumber occupies both k waves alike).  Until round 5 a tile held 64 k of BOTH
-// parities: the same sixteen accumulator fragments and 64 | 128 matrix instructions per wave and stage, but 12 instead of 8 vectors
-// per thread stored to LDS (panel rows of both parities, sums AND differences of the Fourier rows) and 16 instead of 8 sums per stage --
-// the two largest items of round 4's piece-removal table; loads per thread and stage are twelve in both (four panel vectors, four
-// north and four south rows).  93.4 against 96.0 ms at TCo1279 (profiles/r5_fft_experiments.txt section 5).
+// fp64 tile (round 5): 128 k (n-pairs) of ONE parity x 128 columns; wave (wk, wn) owns the 16-row groups wk, wk + 2, wk + 4, wk + 6 of the
+// tile x 64 col (interleaved, so that a partial tile occupies both k waves alike).  The tile of rounds 1 - 4 (leg_dir_tile2 below: 64 k of
+// BOTH parities) has the same sixteen accumulator fragments and 64 | 128 matrix instructions per wave and stage, but stores 12 instead
+// of 8 vectors per thread to LDS (panel rows of both parities, sums AND differences of the Fourier rows) and forms 16 instead of 8 sums
+// per stage -- the two largest items of round 4's piece-removal table; loads per thread and stage are twelve in both (four panel
+// vectors, four north and four south rows).  The last <= 64 n-pairs of a wavenumber still run on ONE two-parity tile (two half-empty
+// one-parity tiles would each pay a full stage's loads and barriers), and the fp32 library uses the two-parity tile throughout.
+// 90.1 - 91.5 against 95.5 ms at TCo1279 (profiles/r5_fft_experiments.txt section 5).
 // FULL: all eight 16-row groups of the tile are live: the stage loop is then one
 // straight-line block, which lets the compiler interleave the LDS fragment reads with the MFMAs.
+// EMI_LD_COMB_BACK: the k step of a stage (counted from its end) in front of whose matrix instructions north +- south of the NEXT stage's
+// rows is formed (measured 1 | 2 | 3 | wherever the scheduler puts them: 95.7 | 92.6 | 94.3 | 92.5 - 93.1 ms, without the two-parity tails).
 EMI_DEVFN real2 lg_fma(real2 b, real_t sg, real2 a) { return mk2(a.x + sg * b.x, a.y + sg * b.y); }  // a + sg b
 EMI_DEVFN v4f lg_fma(v4f b, real_t sg, v4f a) { return a + b * (float)sg; }
+#ifndef EMI_LD_COMB_BACK
+#define EMI_LD_COMB_BACK 2
+#endif
 #define LG_LDK LG_LDB  // row stride of both LDS images of leg_dir_tile (128 values + padding, as Bs of the other kernels)
 template <bool FULL, bool WIDE>
 EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, const int kt, const int ct, const int nlive, const real_t *FB, const int zrow, int ldf,
@@ -628,12 +635,21 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
       real_t a[4], b[4];                                                                                                  \
       _Pragma("unroll") for (int i = 0; i < 4; i++) a[i] = As[fa[ks] + i * 32];                                           \
       _Pragma("unroll") for (int j = 0; j < 4; j++) b[j] = Bs[fb[ks] + j * 16];                                           \
+      if constexpr (!(LAST_)) {                                                                                           \
+        /* north +- south of the rows requested in this stage, ahead of the stage's last sixteen matrix instructions: in front of the matrix */ \
+        /* phase (where the scheduler puts them by itself) the wave waits for the rows just requested, behind the last matrix instruction */ \
+        /* the LDS writes of the next stage wait for the sums (profiles/r5_fft_experiments.txt section 5) */              \
+        if (ks == LG_LS / 4 - EMI_LD_COMB_BACK) {                                                                         \
+          EMI_SCHED_FENCE();                                                                                              \
+          LEGDIR_COMBINE();                                                                                               \
+          EMI_SCHED_FENCE();                                                                                              \
+        }                                                                                                                 \
+      }                                                                                                                   \
       _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                       \
         if (FULL || i < ni) { /* the last k tile of a wavenumber: 16-row groups past the end are skipped */               \
           _Pragma("unroll") for (int j = 0; j < 4; j++) acc[i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[i][j]);             \
         }                                                                                                                 \
     }                                                                                                                     \
-    if constexpr (!(LAST_)) LEGDIR_COMBINE();                                                                             \
     EMI_PRIO_LO();                                                                                                        \
     LEG_STAMP(4);                                                                                                         \
   }
@@ -687,24 +703,299 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
     }
   LEG_STAMP_EPI(2);
 }
+// ---- direct, the tile of rounds 1 - 4: 64 k (n-pairs) x 2 parities x 128 columns; wave (par, wn) owns 64 k x 64 col.  Kept for the
+// LAST tile of a wavenumber when at most 64 n-pairs are left: one workgroup then does what two half-empty one-parity tiles would, each
+// with a full stage's loads and barriers (k_leg_dir below).
+template <bool FULL, bool WIDE>
+EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, const int ct, const int ni, const real_t *FB, const int zrow, int ldf,
+                            real_t *W, int ldw, const FuseDst *fd) {
+  typedef typename LegAcc<WIDE>::type acc_t;
+  LEG_STAMP_T0();
+  EMI_LDS_DECL;
+  real_t *As = (real_t *)EMI_LDS_PTR;
+  real_t *Bs = As + 2 * LG_LS * LG_LDA;
+  const int tid = EMI_TID, w = tid >> 6, l = tid & 63;
+  const int par = w & 1, wn = w >> 1;
+  const int k0 = kt * 64, col0 = ct * LG_BN;
+  const int nkpad = g.wrows[m] >> 1;
+  const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
+  const int nst = (ndglu + LG_LS - 1) / LG_LS;  // stages of 16 | 32 latitudes: 64 | 128 MFMAs per wave between barriers
+  const long long wb = g.wbase[m];
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
+
+  // P^T tile: LG_LS latitudes x 64 k per parity, k contiguous in HBM (coalesced rows) and in LDS; a row is 64 / LGV lanes wide, so the
+  // workgroup covers RA = 8 | 16 latitude rows per pass and the stage in two passes
+  constexpr int LA = 64 / LGV, RA = LG_THREADS / LA, LB = LG_BN / LGV, RB = LG_THREADS / LB;  // RB = 4 | 8 Fourier rows per pass, four passes
+  constexpr int WRA = 64 / LA;                       // panel rows that one wave loads per instruction
+  constexpr bool SROWS = (LB == 64);                 // a wave loads ONE Fourier row per instruction (fp64): row addresses are scalar
+  const int wv = emi_uniform(w);
+  const int arow = tid / LA, ac = (tid % LA) * LGV;  // latitude rows arow and arow + RA of the stage
+  const int ldk = g.ldk[m];
+  // as in leg_inv_tile: uniform bases in scalar registers + constant 32-bit lane offsets, no vector address arithmetic per stage
+  unsigned voA = (unsigned)(((l / LA) * ldk + ac) * (int)sizeof(real_t));
+  const char *uS = emi_uniform_ptr((const real_t *)g.PT + g.offTS[m] + (long long)(wv * WRA) * ldk + k0);
+  const char *uA = emi_uniform_ptr((const real_t *)g.PT + g.offTA[m] + (long long)(wv * WRA) * ldk + k0);
+  const long long stepA = (long long)LG_LS * ldk * (long long)sizeof(real_t), rowA8 = (long long)RA * ldk * (long long)sizeof(real_t);
+  const int brow = tid / LB, bc = (tid % LB) * LGV;  // latitude rows brow + RB i, i = 0..3, of each stage
+  const real_t *FBc = FB + col0 + bc;
+  unsigned voB = (unsigned)(bc * (int)sizeof(real_t));
+  const char *uFB = emi_uniform_ptr(FB + col0);
+  lgvec ra0, ra1, ra2, ra3;                      // P^T of stage s+1
+  lgvec rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
+  // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT kernels), so each stage touches 32
+  // far-apart rows, prefetched one stage (~2 x 4096 MFMA cycles per SIMD) ahead.  fp64 (SROWS): a wave loads one whole row piece per
+  // instruction, so its row numbers (fbase[lat]+m) are SCALAR loads from the latitude tables, fetched a further stage ahead, and the
+  // row address is scalar arithmetic (before: eight LDS look-ups, eight 32 x 32 -> 64-bit vector multiply-adds and eight 64-bit vector
+  // adds per stage, which together took the matrix pipe for as long as two matrix instructions).  Latitudes past the last one read
+  // row `zrow` of the buffer, a row of zeros behind the Fourier rows: no branch around the loads.
+  // fp32: a wave loads two rows per instruction; their numbers are staged once per tile in LDS, so that looking them up is an LDS
+  // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
+  // destinations of the tile's 64 fields (fused epilogue), staged in LDS now: fetched in the epilogue they cost eight serialised memory
+  // round trips (descriptor, then index / stride / NASM0 behind a divergent branch, per 16-column group) -- about 20 k of the 35 k clocks
+  // a tile spent between its last matrix instruction and its last store (tools/leg_stamp.py)
+  FuseDst *efd = (FuseDst *)(Bs + 2 * LG_LS * LG_LDB);
+  if (tid < 64) {
+    FuseDst d_;
+    d_.dst = nullptr;
+    d_.stride = 0;
+    d_.idx = 0;
+    if (fd) d_ = fd[(col0 >> 1) + tid];
+    efd[tid] = d_;
+  }
+  const int nasm0_m = emi_ld_const(g.nasm0, m), mval_m = emi_ld_const(g.mval, m);
+  int *rowN = (int *)(efd + 64);
+  int *rowS = rowN + LG_LS * nst;
+  if constexpr (!SROWS) {
+    for (int j = tid; j < LG_LS * nst; j += LG_THREADS) {
+      int rn_ = zrow, rs_ = zrow;
+      if (j < ndglu) {
+        rn_ = g.legN[lb + j];
+        rs_ = g.legS[lb + j];
+      }
+      rowN[j] = rn_;
+      rowS[j] = rs_;
+    }
+    EMI_SYNC();
+  }
+  int qn[4], qs[4];  // SROWS: row numbers of the stage that is requested next
+#define LEGDIR_ROWS(s_)                                    \
+  if constexpr (SROWS) {                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
+      const int j_ = LG_LS * (s_) + wv + RB * i_;          \
+      const int jc_ = j_ < ndglu ? j_ : ndglu - 1;         \
+      qn[i_] = emi_ld_const(g.legN, lb + jc_);             \
+      qs[i_] = emi_ld_const(g.legS, lb + jc_);             \
+    }                                                      \
+  }
+  unsigned qrn[4], qrs[4];  // SROWS: the rows that LEGDIR_LOADB requests
+  // the selects sit a stage after the scalar loads were issued (nothing waits for them) and BEFORE the next ones overwrite qn / qs
+#define LEGDIR_SEL(s_)                                     \
+  if constexpr (SROWS) {                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
+      const bool live_ = LG_LS * (s_) + wv + RB * i_ < ndglu; \
+      qrn[i_] = live_ ? qn[i_] : zrow;                     \
+      qrs[i_] = live_ ? qs[i_] : zrow;                     \
+    }                                                      \
+  }
+#define LEGDIR_LOADB(s_)                                                            \
+  if constexpr (SROWS) {                                                            \
+    const unsigned long long ldfb_ = (unsigned long long)(unsigned)ldf * sizeof(real_t); \
+    EMI_OPAQUE(voB);                                                                \
+    rn0 = emi_ld_sv<lgvec>(uFB + qrn[0] * ldfb_, voB);                                 \
+    rs0 = emi_ld_sv<lgvec>(uFB + qrs[0] * ldfb_, voB);                                 \
+    rn1 = emi_ld_sv<lgvec>(uFB + qrn[1] * ldfb_, voB);                                 \
+    rs1 = emi_ld_sv<lgvec>(uFB + qrs[1] * ldfb_, voB);                                 \
+    rn2 = emi_ld_sv<lgvec>(uFB + qrn[2] * ldfb_, voB);                                 \
+    rs2 = emi_ld_sv<lgvec>(uFB + qrs[2] * ldfb_, voB);                                 \
+    rn3 = emi_ld_sv<lgvec>(uFB + qrn[3] * ldfb_, voB);                                 \
+    rs3 = emi_ld_sv<lgvec>(uFB + qrs[3] * ldfb_, voB);                                 \
+  } else {                                                                          \
+    const int j0_ = LG_LS * (s_) + brow;                                            \
+    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + RB], is1 = rowS[j0_ + RB];         \
+    const int in2 = rowN[j0_ + 2 * RB], is2 = rowS[j0_ + 2 * RB], in3 = rowN[j0_ + 3 * RB], is3 = rowS[j0_ + 3 * RB]; \
+    rn0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in0 * (unsigned)ldf); \
+    rs0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is0 * (unsigned)ldf); \
+    rn1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in1 * (unsigned)ldf); \
+    rs1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is1 * (unsigned)ldf); \
+    rn2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in2 * (unsigned)ldf); \
+    rs2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is2 * (unsigned)ldf); \
+    rn3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in3 * (unsigned)ldf); \
+    rs3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is3 * (unsigned)ldf); \
+  }
+#define LEGDIR_LOADA(s_)                                          \
+  {                                                               \
+    const char *us_ = uS + (s_) * stepA, *ua_ = uA + (s_) * stepA; \
+    EMI_OPAQUE(voA);                                              \
+    ra0 = emi_ld_sv<lgvec>(us_, voA);                             \
+    ra1 = emi_ld_sv<lgvec>(ua_, voA);                             \
+    ra2 = emi_ld_sv<lgvec>(us_ + rowA8, voA);                     \
+    ra3 = emi_ld_sv<lgvec>(ua_ + rowA8, voA);                     \
+  }
+  // fragment positions, one register per k step (leg_inv_tile)
+  int fa[LG_LS / 4], fb[LG_LS / 4];
+#pragma unroll
+  for (int ks = 0; ks < LG_LS / 4; ks++) {
+    fa[ks] = (par * LG_LS + 4 * ks + (l >> 4)) * LG_LDA + (l & 15);
+    fb[ks] = (par * LG_LS + 4 * ks + (l >> 4)) * LG_LDB + wn * 64 + (l & 15);
+    EMI_OPAQUE(fa[ks]);
+    EMI_OPAQUE(fb[ks]);
+  }
+  // PRFI2B: (north, south) -> (symmetric, antisymmetric), in place, as soon as the rows of the next stage have arrived
+#define LEGDIR_SUMDIFF()                                   \
+  {                                                        \
+    lgvec t_;                                              \
+    t_ = lg_sub(rn0, rs0), rn0 = lg_add(rn0, rs0), rs0 = t_; \
+    t_ = lg_sub(rn1, rs1), rn1 = lg_add(rn1, rs1), rs1 = t_; \
+    t_ = lg_sub(rn2, rs2), rn2 = lg_add(rn2, rs2), rs2 = t_; \
+    t_ = lg_sub(rn3, rs3), rn3 = lg_add(rn3, rs3), rs3 = t_; \
+  }
+  LEGDIR_ROWS(0);
+  LEGDIR_SEL(0);
+  LEGDIR_LOADB(0);
+  LEGDIR_LOADA(0);
+  LEGDIR_SUMDIFF();
+  // Order of a stage: barrier, LDS writes (no arithmetic), loads of the next stage, barrier, matrix phase, sums and differences of the rows
+  // that arrived meanwhile.  The sixteen fp64 adds used to sit in front of the LDS writes, where the wave runs at low priority beside the
+  // other workgroup's matrix phase and every add waited for a gap between matrix instructions (2.3 k of a stage's 9 k clocks); at the end
+  // of the wave's own matrix phase they issue back to back.
+  LEGDIR_ROWS(nst > 1 ? 1 : 0);
+  LEG_STAMP_PRO(2);
+  LEG_STAMP_BEGIN(2);
+  // One stage; LAST_: the last stage of the tile requests nothing (the loop is peeled rather than guarded: with the loads inside an
+  // `if (s + 1 < nst)` the compiler copies all twelve prefetch registers at the loop back edge, 44 moves per stage; and a last stage that
+  // re-requested its own rows, as it did until round 4, made the epilogue wait a memory round trip for data nobody reads)
+#define LEGDIR_STAGE(s, LAST_)                                                                                            \
+  {                                                                                                                       \
+    if ((s) > 0) EMI_SYNC();                                                                                              \
+    LEG_STAMP(0);                                                                                                         \
+    if constexpr (!(LAST_)) {                                                                                             \
+      /* row numbers: those of stage s+1 (requested a stage ago) are consumed, those of stage s+2 requested -- here, ahead of the LDS */ \
+      /* writes and the second barrier, so that the matrix phase's first fragment reads never wait on a scalar load */     \
+      LEGDIR_SEL((s) + 1);                                                                                                \
+      const int sn2 = ((s) + 2 < nst) ? (s) + 2 : (s) + 1;                                                                \
+      LEGDIR_ROWS(sn2);                                                                                                   \
+      EMI_SCHED_FENCE(); /* left to itself the scheduler sinks the scalar loads to the wait in front of the second barrier */ \
+    }                                                                                                                     \
+    /* As[par][latitude in stage][k index], Bs[par][latitude in stage][column] */                                         \
+    *(lgvec *)(As + (0 * LG_LS + arow) * LG_LDA + ac) = ra0;                                                              \
+    *(lgvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;                                                              \
+    *(lgvec *)(As + (0 * LG_LS + arow + RA) * LG_LDA + ac) = ra2;                                                         \
+    *(lgvec *)(As + (1 * LG_LS + arow + RA) * LG_LDA + ac) = ra3;                                                         \
+    *(lgvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = rn0; /* symmetric part */                                         \
+    *(lgvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = rs0; /* antisymmetric part */                                     \
+    *(lgvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = rn1;                                                         \
+    *(lgvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = rs1;                                                         \
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rn2;                                                     \
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rs2;                                                     \
+    *(lgvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rn3;                                                     \
+    *(lgvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rs3;                                                     \
+    LEG_STAMP(1);                                                                                                         \
+    if constexpr (!(LAST_)) {                                                                                             \
+      LEGDIR_LOADB((s) + 1);                                                                                              \
+      LEGDIR_LOADA((s) + 1);                                                                                              \
+    }                                                                                                                     \
+    LEG_STAMP(2);                                                                                                         \
+    EMI_SYNC();                                                                                                           \
+    LEG_STAMP(3);                                                                                                         \
+    EMI_PRIO_HI();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < LG_LS / 4; ks++) {                                                            \
+      real_t a[4], b[4];                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 4; i++) a[i] = As[fa[ks] + i * 16];                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) b[j] = Bs[fb[ks] + j * 16];                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                       \
+        if (FULL || i < ni) { /* the last k tile of a wavenumber: 16-row groups past the end are skipped */               \
+          _Pragma("unroll") for (int j = 0; j < 4; j++) acc[i][j] = LegAcc<WIDE>::mma(a[i], b[j], acc[i][j]);             \
+        }                                                                                                                 \
+    }                                                                                                                     \
+    if constexpr (!(LAST_)) LEGDIR_SUMDIFF();                                                                             \
+    EMI_PRIO_LO();                                                                                                        \
+    LEG_STAMP(4);                                                                                                         \
+  }
+  for (int s = 0; s < nst - 1; s++) LEGDIR_STAGE(s, false);
+  LEGDIR_STAGE(nst - 1, true);
+#undef LEGDIR_STAGE
+  LEG_STAMP_END(nst);
+  LEG_STAMP_EPI0();
+#undef LEGDIR_ROWS
+#undef LEGDIR_SEL
+#undef LEGDIR_SUMDIFF
+#undef LEGDIR_LOADA
+#undef LEGDIR_LOADB
+  // Epilogue.  Fields whose spectral output is a plain copy (UPDSP, updsp_mod.F90:100-161: every scalar) go
+  // straight to the caller's array -- element (NASM0(m) + 2 (n-m) + c, field), n <= N, imaginary parts of m = 0
+  // zero (updspb_mod.F90:106,117) -- instead of through W and k_postpack_dir; the wind fields (U, V), which
+  // UVTVD combines over n-1, n, n+1, and the padding columns still go to W.  A lane holds one component
+  // (c = l & 1) of four fields.
+  real_t *ud[4];
+  long long us[4];
+  const int cpar = l & 1;
+#pragma unroll
+  for (int jn = 0; jn < 4; jn++) {
+    ud[jn] = nullptr;
+    us[jn] = 0;
+    const FuseDst d = efd[wn * 32 + jn * 8 + ((l & 15) >> 1)];
+    if (d.dst) {
+      ud[jn] = (real_t *)d.dst + d.idx + (long long)(nasm0_m + cpar) * d.stride;
+      us[jn] = 2LL * d.stride;
+    }
+  }
+  const int rmax = g.nsmax - mval_m;  // rows r = n - m <= rmax carry a coefficient
+  const bool zero_im = (mval_m == 0) && cpar;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int k = k0 + i * 16 + LegAcc<WIDE>::row(l, q);
+      if (k < nkpad) {
+        const int r = 2 * k + par;
+        real_t *pw = W + (wb + r) * ldw + col0 + wn * 64 + (l & 15);
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+          if (ud[jn]) {
+            if (r <= rmax) ud[jn][(long long)r * us[jn]] = zero_im ? (real_t)0.0 : (real_t)acc[i][jn][q];
+          } else {
+            pw[jn * 16] = (real_t)acc[i][jn][q];
+          }
+        }
+      }
+    }
+  LEG_STAMP_EPI(2);
+}
 EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const int zrow, int ldf, real_t *W, int ldw,
                                       const FuseDst *fd) {
   const int2 tm = tilemap[EMI_BID];
   if (tm.x < 0) return;
-  // tile (m, par, kt, ct): row tile number = par + 2 kt, 128 n-pairs of one parity each (Plan::ktile_pref counts 2 ceil(nk / 128) per wavenumber)
+  // row tiles of a wavenumber with nk n-pairs (Plan::ktile_pref counts them the same way).  fp64: 2 floor(nk / 128) one-parity tiles of
+  // 128 n-pairs (parity + 2 x tile), then the rest r = nk mod 128: none | ONE two-parity tile of 64 n-pairs (r <= 64) | two one-parity
+  // tiles.  fp32: two-parity tiles of 64 n-pairs throughout (the one-parity tile is 2 % slower there, profiles/r5_fft_experiments.txt section 5).
   const int m = tm.x, rt = tm.y >> 16, ct = tm.y & 0xffff;
-  const int par = rt & 1, kt = rt >> 1;
-  const int left = ((g.wrows[m] >> 1) - kt * 128 + 15) >> 4;  // live 16-row groups of this tile
+  const int nk = g.wrows[m] >> 1;
   if constexpr (sizeof(real_t) == 4) {
-    if (g.m0_wide && g.mval[m] == 0) {  // fp32 library: the mean wavenumber in double (LegAcc)
-      leg_dir_tile<false, true>(g, m, par, kt, ct, left < 8 ? left : 8, FB, zrow, ldf, W, ldw, fd);
+    const int left = (nk - rt * 64 + 15) >> 4;  // live 16-row groups of this tile
+    if (g.m0_wide && g.mval[m] == 0)            // the mean wavenumber in double (LegAcc)
+      leg_dir_tile2<false, true>(g, m, rt, ct, left < 4 ? left : 4, FB, zrow, ldf, W, ldw, fd);
+    else if (left >= 4)
+      leg_dir_tile2<true, false>(g, m, rt, ct, 4, FB, zrow, ldf, W, ldw, fd);
+    else
+      leg_dir_tile2<false, false>(g, m, rt, ct, left, FB, zrow, ldf, W, ldw, fd);
+  } else {
+    const int nfull = nk >> 7, r = nk - (nfull << 7);
+    if (rt >= 2 * nfull && r <= 64) {
+      leg_dir_tile2<false, false>(g, m, 2 * nfull, ct, (r + 15) >> 4, FB, zrow, ldf, W, ldw, fd);
       return;
     }
+    const int par = rt & 1, kt = rt >> 1;        // (in the rest rt - 2 nfull is the parity: 2 nfull is even)
+    const int left = (nk - kt * 128 + 15) >> 4;  // live 16-row groups of this tile
+    if (left >= 8)
+      leg_dir_tile<true, false>(g, m, par, kt, ct, 8, FB, zrow, ldf, W, ldw, fd);
+    else
+      leg_dir_tile<false, false>(g, m, par, kt, ct, left, FB, zrow, ldf, W, ldw, fd);
   }
-  if (left >= 8)
-    leg_dir_tile<true, false>(g, m, par, kt, ct, 8, FB, zrow, ldf, W, ldw, fd);
-  else
-    leg_dir_tile<false, false>(g, m, par, kt, ct, left, FB, zrow, ldf, W, ldw, fd);
 }
 
 // ==========================================================================================

@@ -34,7 +34,7 @@ struct EmiGeomDev {
   const long long *offTS, *offTA;  // [nump]
   const int *ldk;              // [nump] padded k count (multiple of 64)
   const int *lattile_pref;     // [nump+1] prefix of ceil(ndglu/64)
-  const int *ktile_pref;       // [nump+1] prefix of 2 ceil((wrows/2)/128): k_leg_dir's row tiles (parity + 2 x tile of 128 n-pairs)
+  const int *ktile_pref;       // [nump+1] k_leg_dir's row tiles: 2 floor(nk/128) one-parity tiles + 0 | 1 | 2 for the rest (nk = wrows/2)
   const double *specw;         // [nspec2 local] SPECNORM weight of every spectral entry (0, 1 or 2)
 };
 
@@ -140,7 +140,7 @@ struct FftLaunchDev {
 #define LG_LDA 80
 #define LG_LDB 144
 #define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)  // k_leg_inv, 8-row stages; sized for fp64 (fp32 uses half)
-#define LG_LDS_BYTES_DIR (2 * 16 * LG_LDB * 8)                // k_leg_dir: panel + Fourier rows of one 16 (fp64) | 32 (fp32)-latitude stage, 128 values a row (+ its row-number tables)
+#define LG_LDS_BYTES_DIR (2 * LG_LDS_BYTES)                  // k_leg_dir, 16-row stages of its two-parity tile (the one-parity tile needs 2 x 16 x LG_LDB x 8) (+ its row-number tables)
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 // First radices R1 of the register-resident kernels (work length 256 R1).  R1 = 18 and 20 (work lengths 4608, 5120) were built and

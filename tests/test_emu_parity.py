@@ -46,6 +46,16 @@ def test_emulated_kernels_match_oracle(et, name):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
+@pytest.mark.skipif(not os.environ.get("EMI_EMU_LARGE"), reason="six minutes in the emulator: EMI_EMU_LARGE=1 (the GPU tier covers these tiles at TCo399 / TCo1279)")
+def test_emulated_legendre_tiles_of_a_long_wavenumber(et):
+    """N = 260: the low wavenumbers have more than 128 (n - m) pairs per parity, so k_leg_dir runs its full one-parity tiles of 128
+    pairs, the partial ones and the two-parity tile of the last <= 64 pairs (the cases above only reach the latter)."""
+    n, h = 260, 6
+    nl = [min(20 + 4 * i, 2 * n + 4) for i in range(h)]
+    e_inv, e_dir = run_case(et, Oracle, XP, n, nl + nl[::-1], 0, 1, {}, None)
+    assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
+
+
 @pytest.mark.parametrize("name", ["octahedral_winds", "bluestein_even", "odd_lengths", "derivatives"])
 def test_emulated_fp32_library_matches_oracle(et, name):
     """precision=4 (the reference's libtrans_sp arithmetic): same kernels instantiated for float with
