@@ -1190,7 +1190,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   // every Fourier row of a latitude a separate far-apart line: measured on one task, EMI_FB_ORDER=m with
   // EMI_FB_TABLE=1, the FFT kernels are 13-20 % slower and the Legendre kernels 1 % faster; the row table
   // itself costs the FFT kernels 1.5 %.)
-  std::vector<int> legN(P.lbase[NU]), legS(P.lbase[NU]), fftrow(P.frows);
+  std::vector<int> legN(std::max(P.lbase[NU], 1)), legS(std::max(P.lbase[NU], 1)), fftrow(P.frows);  // never empty: k_leg_dir clamps its look-ups to an entry that exists
   P.leg_rows.assign(NP, 0);
   P.leg_disp.assign(NP, 0);
   P.fft_rows.assign(NP, 0);

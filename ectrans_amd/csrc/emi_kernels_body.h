@@ -464,7 +464,9 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
   const int k0 = kt * 128, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
-  const int nst = (ndglu + LG_LS - 1) / LG_LS;
+  // at least one stage: a wavenumber above every latitude's NMEN (truncation finer than the grid) has no latitudes but still has coefficients
+  // to zero -- its one stage multiplies the zero row; with no stage at all the prologue's loads would use row numbers nobody staged
+  const int nst = ndglu > 0 ? (ndglu + LG_LS - 1) / LG_LS : 1;
   const long long wb = g.wbase[m];
 #ifdef EMI_CPU_EMU  // lanes are threads there and a matrix instruction is a rendezvous of the whole workgroup: every wave takes the same number
   const int ni = FULL ? 4 : (nlive > 4 ? 4 : nlive);
@@ -518,13 +520,14 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
     EMI_SYNC();
   }
   int qn[4], qs[4];
+  const int lb_last = lb + ndglu > 0 ? lb + ndglu - 1 : 0;  // a row number that exists, for the look-ups past the last latitude (their rows are then replaced by the zero row)
 #define LEGDIR_ROWS(s_)                                       \
   if constexpr (SROWS) {                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
       const int j_ = LG_LS * (s_) + wv + RA * i_;          \
-      const int jc_ = j_ < ndglu ? j_ : ndglu - 1;         \
-      qn[i_] = emi_ld_const(g.legN, lb + jc_);             \
-      qs[i_] = emi_ld_const(g.legS, lb + jc_);             \
+      const int jc_ = j_ < ndglu ? lb + j_ : lb_last;      \
+      qn[i_] = emi_ld_const(g.legN, jc_);                  \
+      qs[i_] = emi_ld_const(g.legS, jc_);                  \
     }                                                      \
   }
   unsigned qrn[4], qrs[4];
@@ -719,7 +722,9 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
   const int k0 = kt * 64, col0 = ct * LG_BN;
   const int nkpad = g.wrows[m] >> 1;
   const int lb = g.lbase[m], ndglu = g.lbase[m + 1] - lb;
-  const int nst = (ndglu + LG_LS - 1) / LG_LS;  // stages of 16 | 32 latitudes: 64 | 128 MFMAs per wave between barriers
+  // at least one stage: a wavenumber above every latitude's NMEN (truncation finer than the grid) has no latitudes but still has coefficients
+  // to zero -- its one stage multiplies the zero row; with no stage at all the prologue's loads would use row numbers nobody staged
+  const int nst = ndglu > 0 ? (ndglu + LG_LS - 1) / LG_LS : 1;  // stages of 16 | 32 latitudes: 64 | 128 MFMAs per wave between barriers
   const long long wb = g.wbase[m];
 
   acc_t acc[4][4];
@@ -783,13 +788,14 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
     EMI_SYNC();
   }
   int qn[4], qs[4];  // SROWS: row numbers of the stage that is requested next
+  const int lb_last = lb + ndglu > 0 ? lb + ndglu - 1 : 0;  // a row number that exists, for the look-ups past the last latitude (their rows are then replaced by the zero row)
 #define LEGDIR_ROWS(s_)                                    \
   if constexpr (SROWS) {                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
       const int j_ = LG_LS * (s_) + wv + RB * i_;          \
-      const int jc_ = j_ < ndglu ? j_ : ndglu - 1;         \
-      qn[i_] = emi_ld_const(g.legN, lb + jc_);             \
-      qs[i_] = emi_ld_const(g.legS, lb + jc_);             \
+      const int jc_ = j_ < ndglu ? lb + j_ : lb_last;      \
+      qn[i_] = emi_ld_const(g.legN, jc_);                  \
+      qs[i_] = emi_ld_const(g.legS, jc_);                  \
     }                                                      \
   }
   unsigned qrn[4], qrs[4];  // SROWS: the rows that LEGDIR_LOADB requests

@@ -80,6 +80,9 @@ CASES = {
     "scalars_only": (31, octahedral(31), 0, 4, {}, None),
     "winds_only": (31, octahedral(31), 3, 0, dict(uvder=True), None),
     "many_fields_two_tiles": (21, octahedral(21), 40, 70, {}, None),
+    # truncation finer than the grid: the wavenumbers 52 ... 63 lie above every latitude's NMEN -- no latitudes, coefficients zero (the fp32
+    # k_leg_dir used row numbers nobody had staged for them until round 5: memory fault)
+    "truncation_above_grid": (63, octahedral(21), 2, 3, {}, None),
 }
 
 
@@ -91,8 +94,28 @@ def test_device_arrays_match_oracle(et, dev, name):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
+# n-pairs of the mean wavenumber (N + 2) // 2 = 64, 65, 96, 127, 128, 129, 192, 193, 256: every rest class of k_leg_dir's row tiling at
+# the head of the wavenumber list, and every class below it as m rises
+TILE_EDGE_N = [126, 128, 190, 252, 254, 256, 382, 384, 510]
+
+
+@pytest.mark.parametrize("nsmax", TILE_EDGE_N)
+@pytest.mark.parametrize("precision", [8, 4])
+def test_direct_legendre_row_tiles(et, dev, nsmax, precision):
+    """k_leg_dir's row tiles (emi_kernels_body.h): per wavenumber 2 floor(nk / 128) one-parity tiles of 128 (n - m) pairs, then for the rest
+    r = nk mod 128 nothing, ONE two-parity tile of 64 pairs (r <= 64) or two partial one-parity tiles (fp32: two-parity tiles
+    throughout).  A few latitudes per hemisphere keep the oracle cheap; the truncation makes the Legendre side long."""
+    nh = 6
+    half = np.array([min(20 + 4 * i, 2 * nsmax + 4) for i in range(nh)], dtype=np.int32)
+    nloen = np.concatenate([half, half[::-1]])
+    from oracle.oracle import Oracle as O
+    e_inv, e_dir = run_case(et, O, dev, nsmax, nloen, 1, 2, {}, None, precision=precision)
+    tol = TOL if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (nsmax, e_inv, e_dir)
+
+
 FP32_CASES = ["O64_winds", "O160_winds", "full_grid_F64", "bluestein_even", "odd_lengths", "derivatives", "nproma_blocks",
-              "many_fields_two_tiles"]
+              "many_fields_two_tiles", "truncation_above_grid"]
 
 
 @pytest.mark.parametrize("name", FP32_CASES)

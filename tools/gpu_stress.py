@@ -33,6 +33,8 @@ def main():
         half = np.sort(rng.integers(8, top, nh))
         nloen = np.concatenate([half, half[::-1]]).astype(np.int32)
         nsmax = int(rng.integers(2, 2 * nh))
+        if rng.random() < 0.15:  # long Legendre side (k_leg_dir's one-parity tiles start at 65 (n - m) pairs), often finer than the grid
+            nsmax = int(rng.integers(65, 400))
         big = rng.random() < 0.25
         nuv = int(rng.integers(0, 40 if big else 3))
         nsc = int(rng.integers(0, 90 if big else 4))
