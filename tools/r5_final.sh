@@ -7,6 +7,8 @@ grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" $O/${TAG}_gputests.
 bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.txt 2>&1
 bash tools/pmc_fft.sh $TAG > $O/${TAG}_pmc_fft_stdout.txt 2>&1
 bash tools/pmc_ea.sh $TAG > $O/${TAG}_pmc_ea_stdout.txt 2>&1
+# the bench line quotes the counter files of ITS build (source hash): put the ones just collected where bench.py looks (the box's copy of the repo)
+cp $O/${TAG}_pmc_traffic.json $O/${TAG}_pmc_fft.json profiles/ 2>/dev/null
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_tco1279_driver_cmd.json 2> $O/${TAG}_bench_driver_err.log
 python3 bench.py --nsmax 399 --nfld 4 --steps 20 --warmup 5 --no-fortran > $O/${TAG}_bench_tco399.json 2>> $O/${TAG}_bench_driver_err.log
 python3 bench.py --precision 4 --no-cpu-baseline --no-api-level > $O/${TAG}_bench_tco1279_fp32.json 2>> $O/${TAG}_bench_driver_err.log
