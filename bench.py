@@ -243,11 +243,18 @@ def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=2
     # one untimed pair first, as the reference harness's warm-up iterations (ectrans-benchmark.F90:47-50): the FFT plans of every
     # row length, the BLAS threads' buffers and the first touch of the work arrays are set-up, not transform time
     direct(inverse(sc))
-    t = time.time()
-    g = inverse(sc)
-    t_inv = time.time() - t
-    s2 = direct(g)
-    dt = time.time() - t
+    # two timed pairs, the faster one quoted: the legs of one pair vary by a factor of three between hosts of the pool (thread placement of a
+    # 256-thread pool on a shared host), and a baseline is owed its best run
+    dt, t_inv, tm_best = None, None, None
+    for _ in range(2):
+        t = time.time()
+        g = inverse(sc)
+        ti = time.time() - t
+        s2 = direct(g)
+        d = time.time() - t
+        if dt is None or d < dt:
+            dt, t_inv, tm_best = d, ti, dict(tm)
+    tm = tm_best
     rel = lambda a, b: float((np.abs(a - b).max(axis=-1) / np.abs(b).max(axis=-1)).max())
     e_inv, e_dir = rel(g[:, :nref].T, g_ref), rel(s2[:, :nref].T, s_ref.T)
     pool.shutdown()
@@ -255,7 +262,7 @@ def cpu_baseline_blas(o, nsmax, kf_full, sc_ref, g_ref, s_ref, cores, nf_total=2
             "libraries": "torch.matmul (MKL, sequential) for LEINV / LEDIR on a pool of %d threads over the zonal wavenumbers (the reference: OpenMP over m, "
                          "sequential DGEMM per thread), scipy.fft (pocketfft) per latitude on the same pool" % cores,
             "sample": "same grid+truncation, dense spectrum, %d scalar fields (%d columns per panel product) of %d Fourier fields, scaled linearly in KF; "
-                      "panels and thread pool set up outside the timed pair" % (nf, 2 * nf, kf_full),
+                      "panels and thread pool set up outside the timed pairs; one warm-up pair, the faster of two timed pairs" % (nf, 2 * nf, kf_full),
             "seconds_at_sample": dict(tm, inverse=t_inv, direct=dt - t_inv),
             "inv_max_rel_err_vs_oracle": e_inv, "dir_max_rel_err_vs_oracle": e_dir}
 
