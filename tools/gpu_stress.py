@@ -15,7 +15,7 @@ import torch  # noqa: E402  (before the library: one HIP runtime)
 torch.cuda.init()
 import ectrans_amd as et  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
-from tests.common import run_case  # noqa: E402
+from tests.common import adjoint_case, run_case  # noqa: E402
 
 
 def main():
@@ -23,7 +23,7 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     et.setup_trans0(kmax_resol=4, device=0)
     dev = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0"), lambda t: t.cpu().numpy())
-    bad, worst = 0, {8: 0.0, 4: 0.0}
+    bad, worst, worst_adj = 0, {8: 0.0, 4: 0.0}, {8: 0.0, 4: 0.0}
     t0 = time.time()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     cur = open(os.path.join(ROOT, "gpurun_out", "stress_current_seed.txt"), "w")
@@ -40,7 +40,7 @@ def main():
             nh = int(rng.integers(1, 4))
             half = half[-nh:]
         nloen = np.concatenate([half, half[::-1]]).astype(np.int32)
-        nsmax = int(rng.integers(2, 2 * nh))
+        nsmax = int(rng.integers(2, max(2 * nh, 4)))
         if rng.random() < 0.15:  # long Legendre side (k_leg_dir's one-parity tiles start at 65 (n - m) pairs), often finer than the grid
             nsmax = int(rng.integers(65, 400))
         big = rng.random() < 0.25
@@ -54,13 +54,19 @@ def main():
         prec = 8 if rng.random() < 0.7 else 4
         mb = int(rng.choice([0, 64, 128]))
         tol = 1e-11 if prec == 8 else 3e-5
+        adj = rng.random() < 0.1
         cur.seek(0)
         cur.write("%d\n" % seed)  # a memory fault kills the process: the seed of the case in flight survives in this file
         cur.flush()
         try:
             et.set_max_batch(mb)
-            e_inv, e_dir = run_case(et, Oracle, dev, nsmax, nloen, nuv, nsc, flags, nproma, seed=seed, precision=prec)
-            worst[prec] = max(worst[prec], e_inv, e_dir)
+            if adj:  # INV_TRANSAD / DIR_TRANSAD against INV_TRANS / DIR_TRANS (dot-product identity, the reference's tolerance of 2000 epsilons)
+                e_inv, e_dir = adjoint_case(et, dev, nsmax, nloen, nuv, nsc, nproma, seed=seed, precision=prec)
+                tol = 2000 * float(np.finfo(np.float32 if prec == 4 else np.float64).eps)
+                worst_adj[prec] = max(worst_adj[prec], e_inv, e_dir)
+            else:
+                e_inv, e_dir = run_case(et, Oracle, dev, nsmax, nloen, nuv, nsc, flags, nproma, seed=seed, precision=prec)
+                worst[prec] = max(worst[prec], e_inv, e_dir)
             ok = e_inv < tol and e_dir < tol
             msg = "e_inv %.2e e_dir %.2e" % (e_inv, e_dir)
         except Exception as exc:  # noqa: BLE001
@@ -68,9 +74,10 @@ def main():
         if not ok:
             bad += 1
             print("FAIL seed", seed, dict(nloen=nloen.tolist(), nsmax=nsmax, nuv=nuv, nsc=nsc, flags=flags, nproma=nproma,
-                                          precision=prec, max_batch=mb), msg, flush=True)
+                                          precision=prec, max_batch=mb, adjoint=adj), msg, flush=True)
     et.set_max_batch(0)
-    print("stress: %d cases, %d failures, worst fp64 %.2e, worst fp32 %.2e, %.0f s" % (ncases, bad, worst[8], worst[4], time.time() - t0))
+    print("stress: %d cases, %d failures, worst fp64 %.2e, worst fp32 %.2e (adjoint identities: %.2e, %.2e), %.0f s"
+          % (ncases, bad, worst[8], worst[4], worst_adj[8], worst_adj[4], time.time() - t0))
     return 1 if bad else 0
 
 
