@@ -36,8 +36,6 @@ CASES = {
     "odd_lengths": (8, [19, 21, 23, 25, 27, 29, 33, 35, 37] + [19, 21, 23, 25, 27, 29, 33, 35, 37][::-1], 0, 2, {}, None),
     "derivatives": (8, SMOOTH + SMOOTH[::-1], 1, 1, dict(scders=True, vorgp=True, divgp=True, uvder=True), None),
     "nproma_blocks": (8, SMOOTH + SMOOTH[::-1], 1, 1, dict(scders=True), 37),
-    # truncation finer than the grid: the wavenumbers 26 ... 30 lie above every latitude's NMEN (no latitudes, coefficients zero)
-    "truncation_above_grid": (30, SMOOTH + SMOOTH[::-1], 1, 1, {}, None),
 }
 
 
@@ -58,7 +56,7 @@ def test_emulated_legendre_tiles_of_a_long_wavenumber(et):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
-@pytest.mark.parametrize("name", ["octahedral_winds", "bluestein_even", "odd_lengths", "derivatives", "truncation_above_grid"])
+@pytest.mark.parametrize("name", ["octahedral_winds", "bluestein_even", "odd_lengths", "derivatives"])
 def test_emulated_fp32_library_matches_oracle(et, name):
     """precision=4 (the reference's libtrans_sp arithmetic): same kernels instantiated for float with
     v_mfma_f32_16x16x4_f32's accumulator layout.  Tolerance: a few float epsilons x log-ish growth."""
