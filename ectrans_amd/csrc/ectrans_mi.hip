@@ -240,8 +240,8 @@ struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a w
 // column blocks per row tile (measured: 13x the algorithmic HBM bytes).  Tiles stay m-ascending
 // (longest K first) within every XCD, so all XCDs progress through m together.
 struct LegMaps {
-  int2 *d_inv = nullptr, *d_dir = nullptr;
-  long long n_inv = 0, n_dir = 0;
+  int2 *d_inv = nullptr, *d_dir = nullptr, *d_inv_wide = nullptr;  // d_inv_wide: fp32 library, the tiles of zonal wavenumber 0 (k_leg_inv_wide)
+  long long n_inv = 0, n_dir = 0, n_inv_wide = 0;
 };
 
 struct Plan {
@@ -1497,6 +1497,7 @@ extern "C" int emi_release(int kresol) {
   for (void *p : P->dev_allocs) emi_dev_free(p);
   for (auto &kv : P->legmaps) {
     emi_dev_free(kv.second.d_inv);
+    emi_dev_free(kv.second.d_inv_wide);
     emi_dev_free(kv.second.d_dir);
   }
   emi_dev_free(P->d_W);
@@ -1882,13 +1883,16 @@ static int ensure_desc(Plan &P, size_t bytes) {
 // column tiles than XCDs), column tiles innermost, so that consecutive tiles of an XCD share the panel rows.  (Measured and rejected,
 // wavenumber groups of 4 / 2 / 1 XCDs -- fetched bytes go up, time never down; row tiles innermost -- 10 % fewer
 // bytes for k_leg_dir and 1.4 % more time.)
-static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int2 **d_map, long long *nblocks) {
+// which: 0 every wavenumber, 1 all but the wide one (fp32 library: m = 0 accumulates in double and has a kernel of its own), 2 only that one
+static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, int2 **d_map, long long *nblocks, int which = 0) {
   const int nx = 8;  // XCDs
   int gx = 1;
   while (gx * 2 <= std::min(nct, nx)) gx *= 2;
   const int gy = nx / gx;
   std::vector<std::vector<int2>> per(8);
   for (int ml = 0; ml < P.nump; ml++) {
+    const bool wide = P.esz == 4 && P.mval[ml] == 0;
+    if ((which == 1 && wide) || (which == 2 && !wide)) continue;
     const int nrt = pref[ml + 1] - pref[ml];
     for (int x = 0; x < nx; x++) {
       // rotate the column ranges and row residues with the wavenumber: the ranges differ by one tile, rotation
@@ -1906,6 +1910,10 @@ static int build_tilemap(const Plan &P, const std::vector<int> &pref, int nct, i
   for (int x = 0; x < 8; x++)
     for (size_t k = 0; k < per[x].size(); k++) map[k * 8 + x] = per[x][k];
   *nblocks = (long long)map.size();
+  if (map.empty()) {  // (which == 2 on a task that does not own m = 0)
+    *d_map = nullptr;
+    return 0;
+  }
   return upload(map, d_map);
 }
 
@@ -1913,7 +1921,10 @@ static int leg_tilemaps(Plan &P, int nct, LegMaps **out) {
   auto it = P.legmaps.find(nct);
   if (it == P.legmaps.end()) {
     LegMaps lm;
-    if (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv, &lm.n_inv) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir, &lm.n_dir)) return EMI_ERR_RUNTIME;
+    const bool split = P.esz == 4;  // fp32 library: k_leg_inv without the double-precision tiles, which go to k_leg_inv_wide
+    if (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv, &lm.n_inv, split ? 1 : 0) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir, &lm.n_dir) ||
+        (split && build_tilemap(P, P.lattile_pref, nct, &lm.d_inv_wide, &lm.n_inv_wide, 2)))
+      return EMI_ERR_RUNTIME;
     it = P.legmaps.emplace(nct, lm).first;
   }
   *out = &it->second;
@@ -2479,7 +2490,11 @@ static int inv_trans_impl(int kresol, const emi_invtrans_t *ap, bool adj) {
       g_pt.stop(iv, sA);
       iv = g_pt.start(1, sA);
       LegMaps *lmaps = bmaps[ib];
-      EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES + 512, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
+      // (the wide tiles first: they are the longest of the call)
+      if (lmaps->n_inv_wide > 0)
+        EMI_LAUNCH(emi_f32::k_leg_inv_wide, lmaps->n_inv_wide, LG_THREADS, LG_LDS_BYTES + 512, sA, P.g, (const int2 *)lmaps->d_inv_wide, (const float *)P.d_W, ldw, (float *)FBl, ldw);
+      if (lmaps->n_inv > 0)
+        EMI_LAUNCH_P(P.esz, k_leg_inv, lmaps->n_inv, LG_THREADS, LG_LDS_BYTES + 512, sA, P.g, (const int2 *)lmaps->d_inv, (const RT *)P.d_W, ldw, (RT *)FBl, ldw);
       g_pt.stop(iv, sA);
     }
     if (piped) g_pipe.signal(3 * ib, sA);

@@ -415,20 +415,21 @@ EMI_DEVFN void leg_inv_tile(const EmiGeomDev &g, const int m, const int lt, cons
     }
   LEG_STAMP_EPI(1);
 }
-EMI_KERNEL_LB2(256, 2) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const real_t *W, int ldw, real_t *FB, int ldf) {
+EMI_KERNEL_LB2(256, EMI_LEG_INV_WAVES) void k_leg_inv(EmiGeomDev g, const int2 *tilemap, const real_t *W, int ldw, real_t *FB, int ldf) {
   // host-built tile map (leg_tilemap): block -> (local wavenumber, latitude tile, column tile),
   // 2-D blocked per XCD for L2 reuse; padding entries have x < 0
   const int2 tm = tilemap[EMI_BID];
   if (tm.x < 0) return;
-  const int m = tm.x, lt = tm.y >> 16, ct = tm.y & 0xffff;
-  if constexpr (sizeof(real_t) == 4) {
-    if (g.m0_wide && g.mval[m] == 0) {  // uniform over the workgroup
-      leg_inv_tile<true>(g, m, lt, ct, W, ldw, FB, ldf);
-      return;
-    }
-  }
-  leg_inv_tile<false>(g, m, lt, ct, W, ldw, FB, ldf);
+  leg_inv_tile<false>(g, tm.x, tm.y >> 16, tm.y & 0xffff, W, ldw, FB, ldf);
 }
+#if EMI_LEG_WIDE_KERNEL
+// fp32 library: the tiles of zonal wavenumber 0, which accumulate in double (LegAcc<true>), from a tile map of their own (leg_tilemaps)
+EMI_KERNEL_LB2(256, 2) void k_leg_inv_wide(EmiGeomDev g, const int2 *tilemap, const real_t *W, int ldw, real_t *FB, int ldf) {
+  const int2 tm = tilemap[EMI_BID];
+  if (tm.x < 0) return;
+  leg_inv_tile<true>(g, tm.x, tm.y >> 16, tm.y & 0xffff, W, ldw, FB, ldf);
+}
+#endif
 
 // ---- direct: W[m][n][col] = sum_lat P[lat,n] * (FB_north +- FB_south)[lat][col]
 // (prfi2b_mod.F90:82-94, ledir_mod.F90:100-267 DGEMM('T','N') x2; Gaussian weights and
