@@ -240,8 +240,8 @@ struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a w
 // column blocks per row tile (measured: 13x the algorithmic HBM bytes).  Tiles stay m-ascending
 // (longest K first) within every XCD, so all XCDs progress through m together.
 struct LegMaps {
-  int2 *d_inv = nullptr, *d_dir = nullptr, *d_inv_wide = nullptr;  // d_inv_wide: fp32 library, the tiles of zonal wavenumber 0 (k_leg_inv_wide)
-  long long n_inv = 0, n_dir = 0, n_inv_wide = 0;
+  int2 *d_inv = nullptr, *d_dir = nullptr, *d_inv_wide = nullptr, *d_dir_wide = nullptr;  // *_wide: fp32 library, the tiles of zonal wavenumber 0 (k_leg_*_wide)
+  long long n_inv = 0, n_dir = 0, n_inv_wide = 0, n_dir_wide = 0;
 };
 
 struct Plan {
@@ -309,11 +309,10 @@ struct Plan {
 };
 
 static int roundup(int a, int b) { return (a + b - 1) / b * b; }
-// dynamic LDS of k_leg_dir: the operand stage (panel and Fourier rows), the staged destinations of the tile's 64 fields (1 KiB) and -- fp32 library only; the
-// fp64 kernel takes its Fourier-row numbers through scalar loads -- the row-number tables of the wavenumber (2 x 4 bytes per latitude of
-// a hemisphere, whole 32-latitude stages).  Must fit the 80 KiB the kernel is allowed (set_lds_attrs): checked at SETUP_TRANS.
+// dynamic LDS of k_leg_dir: the operand stage of its two-parity tile (panel and Fourier rows of 16 latitudes: 56 KiB in fp64, 28 in fp32) and the
+// staged destinations of the tile's 64 fields (1 KiB).  Must fit the 80 KiB the kernel is allowed (set_lds_attrs): checked at SETUP_TRANS.
 static size_t leg_dir_lds_bytes(const Plan &P) {
-  return (size_t)LG_LDS_BYTES_DIR + 1024 + (P.esz == 4 ? (size_t)8 * roundup(P.ndgnh + 1, 32) : 0) + 64;
+  return (size_t)LG_LDS_BYTES_DIR * P.esz / 8 + 1024 + 64;
 }
 
 // order a call on `st` behind the previous call of the same resolution (device-side wait, nothing blocks the host)
@@ -1498,6 +1497,7 @@ extern "C" int emi_release(int kresol) {
   for (auto &kv : P->legmaps) {
     emi_dev_free(kv.second.d_inv);
     emi_dev_free(kv.second.d_inv_wide);
+    emi_dev_free(kv.second.d_dir_wide);
     emi_dev_free(kv.second.d_dir);
   }
   emi_dev_free(P->d_W);
@@ -1921,9 +1921,9 @@ static int leg_tilemaps(Plan &P, int nct, LegMaps **out) {
   auto it = P.legmaps.find(nct);
   if (it == P.legmaps.end()) {
     LegMaps lm;
-    const bool split = P.esz == 4;  // fp32 library: k_leg_inv without the double-precision tiles, which go to k_leg_inv_wide
-    if (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv, &lm.n_inv, split ? 1 : 0) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir, &lm.n_dir) ||
-        (split && build_tilemap(P, P.lattile_pref, nct, &lm.d_inv_wide, &lm.n_inv_wide, 2)))
+    const bool split = P.esz == 4;  // fp32 library: k_leg_inv / k_leg_dir without the double-precision tiles, which go to k_leg_*_wide
+    if (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv, &lm.n_inv, split ? 1 : 0) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir, &lm.n_dir, split ? 1 : 0) ||
+        (split && (build_tilemap(P, P.lattile_pref, nct, &lm.d_inv_wide, &lm.n_inv_wide, 2) || build_tilemap(P, P.ktile_pref, nct, &lm.d_dir_wide, &lm.n_dir_wide, 2))))
       return EMI_ERR_RUNTIME;
     it = P.legmaps.emplace(nct, lm).first;
   }
@@ -2790,7 +2790,11 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
     emi_dev_memset(FBl + (size_t)lrows_call * ldw * P.esz, 0, (size_t)ldw * P.esz, sA);
     const FuseDst *d_bf = fuse_dir ? (const FuseDst *)((char *)P.d_desc + bt.off_f) : nullptr;
     LegMaps *lmaps = bmaps[ib];
-    EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, leg_dir_lds_bytes(P), sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
+    if (lmaps->n_dir_wide > 0)  // (the double-precision tiles first: they are the longest of the call)
+      EMI_LAUNCH(emi_f32::k_leg_dir_wide, lmaps->n_dir_wide, LG_THREADS, leg_dir_lds_bytes(P), sA, P.g, (const int2 *)lmaps->d_dir_wide, (const float *)FBl, (int)lrows_call, ldw, (float *)P.d_W, ldw,
+                 d_bf);
+    if (lmaps->n_dir > 0)
+      EMI_LAUNCH_P(P.esz, k_leg_dir, lmaps->n_dir, LG_THREADS, leg_dir_lds_bytes(P), sA, P.g, (const int2 *)lmaps->d_dir, (const RT *)FBl, (int)lrows_call, ldw, (RT *)P.d_W, ldw, d_bf);
     g_pt.stop(iv, sA);
     if (piped) g_pipe.signal(3 * ib + 1, sA);
     iv = g_pt.start(0, sA);

@@ -32,6 +32,7 @@ namespace emi_f64 {
 #define EMI_MR_EXTRA(X)
 // k_leg_inv: waves per SIMD, and whether the mean wavenumber in double has a kernel of its own (k_leg_inv_wide)
 #define EMI_LEG_INV_WAVES 2
+#define EMI_LEG_DIR_WAVES 2
 #define EMI_LEG_WIDE_KERNEL 0
 #include "emi_kernels_body.h"
 #undef EMI_MR_EXTRA
@@ -42,6 +43,7 @@ namespace emi_f64 {
 #undef EMI_ACC_ROW
 #undef EMI_FFT_WAVES
 #undef EMI_LEG_INV_WAVES
+#undef EMI_LEG_DIR_WAVES
 #undef EMI_LEG_WIDE_KERNEL
 }  // namespace emi_f64
 
@@ -59,8 +61,9 @@ namespace emi_f32 {
 #endif
 // fp32: the accumulators of k_leg_inv are 64 registers, not 128 -- without the double-precision tiles of the mean wavenumber in the same
 // kernel (LegAcc<true>: 128 registers of accumulators again) it fits three waves per SIMD in 136 registers: 47.0 -> 45.0 ms at TCo1279
-// (four waves: 128 registers + 32 bytes of scratch, 45.0).  k_leg_dir stays at two: three workgroups of its LDS image do not fit a CU.
+// (four waves: 128 registers + 32 bytes of scratch, 45.0).  k_leg_dir likewise (154 registers), with 8-byte loader vectors: emi_kernels_body.h, LG_LS.
 #define EMI_LEG_INV_WAVES 3
+#define EMI_LEG_DIR_WAVES 3
 #define EMI_LEG_WIDE_KERNEL 1
 #include "emi_kernels_body.h"
 #undef EMI_MR_EXTRA
@@ -71,5 +74,6 @@ namespace emi_f32 {
 #undef EMI_ACC_ROW
 #undef EMI_FFT_WAVES
 #undef EMI_LEG_INV_WAVES
+#undef EMI_LEG_DIR_WAVES
 #undef EMI_LEG_WIDE_KERNEL
 }  // namespace emi_f32

@@ -259,7 +259,14 @@ struct LegAcc<true> {
 typedef typename std::conditional<sizeof(real_t) == 8, real2, v4f>::type lgvec;
 #define LGV (16 / (int)sizeof(real_t))  // elements of a loader vector: 2 | 4
 #define LG_KR (4 * LGV)                 // k_leg_inv: rows per parity and stage: 8 | 16
-#define LG_LS (8 * LGV)                 // k_leg_dir: latitudes per stage: 16 | 32
+// k_leg_dir: loader vectors of TWO values in both precisions (16 | 8 bytes) and stages of 16 latitudes.  Until round 5 the fp32 kernel loaded 16 bytes
+// as k_leg_inv does (32-latitude stages, 57 KB of LDS + row-number tables: two workgroups per CU); with 8-byte vectors a wave's load
+// instruction covers ONE Fourier row, so the row numbers are scalar as in fp64 (no tables), the stage image is 29 KB and -- the
+// double-precision tiles of wavenumber 0 being in a kernel of their own -- three workgroups fit a CU: 50.9 -> 46.4 ms at TCo1279 fp32
+// (8-byte vectors at two waves per SIMD 49.9, at four 47.6; profiles/r5_fft_experiments.txt section 6)
+typedef real2 lgdvec;
+#define LGDV 2
+#define LG_LS 16
 EMI_DEVFN real2 lg_add(real2 a, real2 b) { return cadd(a, b); }
 EMI_DEVFN real2 lg_sub(real2 a, real2 b) { return csub(a, b); }
 EMI_DEVFN v4f lg_add(v4f a, v4f b) { return a + b; }
@@ -482,20 +489,19 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
 
-  constexpr int LA = 128 / LGV, RA = LG_THREADS / LA;  // lanes per row of 128 values; rows per pass of the workgroup: 4 | 8, four passes per stage
+  constexpr int LA = 128 / LGDV, RA = LG_THREADS / LA;  // lanes per row of 128 values; rows per pass of the workgroup: 4 | 8, four passes per stage
   constexpr int WRA = 64 / LA;                         // rows that one wave loads per instruction: 1 | 2
-  constexpr bool SROWS = (LA == 64);                   // fp64: a wave loads ONE row per instruction -- row addresses are scalar
+  static_assert(LA == 64, "a wave loads ONE row of 128 values per instruction: row addresses are scalar");
   const int wv = emi_uniform(w);
-  const int arow = tid / LA, ac = (tid % LA) * LGV;
+  const int arow = tid / LA, ac = (tid % LA) * LGDV;
   const int ldk = g.ldk[m];
   unsigned voA = (unsigned)(((l / LA) * ldk + ac) * (int)sizeof(real_t));
   const char *uP = emi_uniform_ptr((const real_t *)g.PT + (par ? g.offTA[m] : g.offTS[m]) + (long long)(wv * WRA) * ldk + k0);
   const long long stepA = (long long)LG_LS * ldk * (long long)sizeof(real_t), rowA = (long long)RA * ldk * (long long)sizeof(real_t);
-  const real_t *FBc = FB + col0 + ac;
   unsigned voB = (unsigned)(ac * (int)sizeof(real_t));
   const char *uFB = emi_uniform_ptr(FB + col0);
-  lgvec ra0, ra1, ra2, ra3;                      // P^T rows of stage s+1
-  lgvec rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1; rn* then hold the combination
+  lgdvec ra0, ra1, ra2, ra3;                      // P^T rows of stage s+1
+  lgdvec rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1; rn* then hold the combination
   FuseDst *efd = (FuseDst *)(Bs + LG_LS * LG_LDK);
   if (tid < 64) {
     FuseDst d_;
@@ -506,24 +512,10 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
     efd[tid] = d_;
   }
   const int nasm0_m = emi_ld_const(g.nasm0, m), mval_m = emi_ld_const(g.mval, m);
-  int *rowN = (int *)(efd + 64);
-  int *rowS = rowN + LG_LS * nst;
-  if constexpr (!SROWS) {
-    for (int j = tid; j < LG_LS * nst; j += LG_THREADS) {
-      int rn_ = zrow, rs_ = zrow;
-      if (j < ndglu) {
-        rn_ = g.legN[lb + j];
-        rs_ = g.legS[lb + j];
-      }
-      rowN[j] = rn_;
-      rowS[j] = rs_;
-    }
-    EMI_SYNC();
-  }
   int qn[4], qs[4];
   const int lb_last = lb + ndglu > 0 ? lb + ndglu - 1 : 0;  // a row number that exists, for the look-ups past the last latitude (their rows are then replaced by the zero row)
 #define LEGDIR_ROWS(s_)                                       \
-  if constexpr (SROWS) {                                   \
+  {                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
       const int j_ = LG_LS * (s_) + wv + RA * i_;          \
       const int jc_ = j_ < ndglu ? lb + j_ : lb_last;      \
@@ -533,7 +525,7 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
   }
   unsigned qrn[4], qrs[4];
 #define LEGDIR_SEL(s_)                                        \
-  if constexpr (SROWS) {                                   \
+  {                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
       const bool live_ = LG_LS * (s_) + wv + RA * i_ < ndglu; \
       qrn[i_] = live_ ? qn[i_] : zrow;                     \
@@ -541,38 +533,26 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
     }                                                      \
   }
 #define LEGDIR_LOADB(s_)                                                               \
-  if constexpr (SROWS) {                                                            \
+  {                                                                                 \
     const unsigned long long ldfb_ = (unsigned long long)(unsigned)ldf * sizeof(real_t); \
     EMI_OPAQUE(voB);                                                                \
-    rn0 = emi_ld_sv<lgvec>(uFB + qrn[0] * ldfb_, voB);                                 \
-    rs0 = emi_ld_sv<lgvec>(uFB + qrs[0] * ldfb_, voB);                                 \
-    rn1 = emi_ld_sv<lgvec>(uFB + qrn[1] * ldfb_, voB);                                 \
-    rs1 = emi_ld_sv<lgvec>(uFB + qrs[1] * ldfb_, voB);                                 \
-    rn2 = emi_ld_sv<lgvec>(uFB + qrn[2] * ldfb_, voB);                                 \
-    rs2 = emi_ld_sv<lgvec>(uFB + qrs[2] * ldfb_, voB);                                 \
-    rn3 = emi_ld_sv<lgvec>(uFB + qrn[3] * ldfb_, voB);                                 \
-    rs3 = emi_ld_sv<lgvec>(uFB + qrs[3] * ldfb_, voB);                                 \
-  } else {                                                                          \
-    const int j0_ = LG_LS * (s_) + arow;                                            \
-    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + RA], is1 = rowS[j0_ + RA];         \
-    const int in2 = rowN[j0_ + 2 * RA], is2 = rowS[j0_ + 2 * RA], in3 = rowN[j0_ + 3 * RA], is3 = rowS[j0_ + 3 * RA]; \
-    rn0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in0 * (unsigned)ldf); \
-    rs0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is0 * (unsigned)ldf); \
-    rn1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in1 * (unsigned)ldf); \
-    rs1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is1 * (unsigned)ldf); \
-    rn2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in2 * (unsigned)ldf); \
-    rs2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is2 * (unsigned)ldf); \
-    rn3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in3 * (unsigned)ldf); \
-    rs3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is3 * (unsigned)ldf); \
+    rn0 = emi_ld_sv<lgdvec>(uFB + qrn[0] * ldfb_, voB);                                 \
+    rs0 = emi_ld_sv<lgdvec>(uFB + qrs[0] * ldfb_, voB);                                 \
+    rn1 = emi_ld_sv<lgdvec>(uFB + qrn[1] * ldfb_, voB);                                 \
+    rs1 = emi_ld_sv<lgdvec>(uFB + qrs[1] * ldfb_, voB);                                 \
+    rn2 = emi_ld_sv<lgdvec>(uFB + qrn[2] * ldfb_, voB);                                 \
+    rs2 = emi_ld_sv<lgdvec>(uFB + qrs[2] * ldfb_, voB);                                 \
+    rn3 = emi_ld_sv<lgdvec>(uFB + qrn[3] * ldfb_, voB);                                 \
+    rs3 = emi_ld_sv<lgdvec>(uFB + qrs[3] * ldfb_, voB);                                 \
   }
 #define LEGDIR_LOADA(s_)                                             \
   {                                                               \
     const char *up_ = uP + (s_) * stepA;                          \
     EMI_OPAQUE(voA);                                              \
-    ra0 = emi_ld_sv<lgvec>(up_, voA);                             \
-    ra1 = emi_ld_sv<lgvec>(up_ + rowA, voA);                      \
-    ra2 = emi_ld_sv<lgvec>(up_ + 2 * rowA, voA);                  \
-    ra3 = emi_ld_sv<lgvec>(up_ + 3 * rowA, voA);                  \
+    ra0 = emi_ld_sv<lgdvec>(up_, voA);                             \
+    ra1 = emi_ld_sv<lgdvec>(up_ + rowA, voA);                      \
+    ra2 = emi_ld_sv<lgdvec>(up_ + 2 * rowA, voA);                  \
+    ra3 = emi_ld_sv<lgdvec>(up_ + 3 * rowA, voA);                  \
   }
   int fa[LG_LS / 4], fb[LG_LS / 4];
 #pragma unroll
@@ -618,14 +598,14 @@ EMI_DEVFN void leg_dir_tile(const EmiGeomDev &g, const int m, const int par, con
       EMI_SCHED_FENCE(); /* left to itself the scheduler sinks the scalar loads to the wait in front of the second barrier */ \
     }                                                                                                                     \
     /* As[latitude in stage][k index], Bs[latitude in stage][column] */                                                   \
-    *(lgvec *)(As + (arow) * LG_LDK + ac) = ra0;                                                                          \
-    *(lgvec *)(As + (arow + RA) * LG_LDK + ac) = ra1;                                                                     \
-    *(lgvec *)(As + (arow + 2 * RA) * LG_LDK + ac) = ra2;                                                                 \
-    *(lgvec *)(As + (arow + 3 * RA) * LG_LDK + ac) = ra3;                                                                 \
-    *(lgvec *)(Bs + (arow) * LG_LDK + ac) = rn0;                                                                          \
-    *(lgvec *)(Bs + (arow + RA) * LG_LDK + ac) = rn1;                                                                     \
-    *(lgvec *)(Bs + (arow + 2 * RA) * LG_LDK + ac) = rn2;                                                                 \
-    *(lgvec *)(Bs + (arow + 3 * RA) * LG_LDK + ac) = rn3;                                                                 \
+    *(lgdvec *)(As + (arow) * LG_LDK + ac) = ra0;                                                                          \
+    *(lgdvec *)(As + (arow + RA) * LG_LDK + ac) = ra1;                                                                     \
+    *(lgdvec *)(As + (arow + 2 * RA) * LG_LDK + ac) = ra2;                                                                 \
+    *(lgdvec *)(As + (arow + 3 * RA) * LG_LDK + ac) = ra3;                                                                 \
+    *(lgdvec *)(Bs + (arow) * LG_LDK + ac) = rn0;                                                                          \
+    *(lgdvec *)(Bs + (arow + RA) * LG_LDK + ac) = rn1;                                                                     \
+    *(lgdvec *)(Bs + (arow + 2 * RA) * LG_LDK + ac) = rn2;                                                                 \
+    *(lgdvec *)(Bs + (arow + 3 * RA) * LG_LDK + ac) = rn3;                                                                 \
     LEG_STAMP(1);                                                                                                         \
     if constexpr (!(LAST_)) {                                                                                             \
       LEGDIR_LOADB((s) + 1);                                                                                              \
@@ -734,33 +714,32 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (acc_t){0.0, 0.0, 0.0, 0.0};
 
-  // P^T tile: LG_LS latitudes x 64 k per parity, k contiguous in HBM (coalesced rows) and in LDS; a row is 64 / LGV lanes wide, so the
+  // P^T tile: LG_LS latitudes x 64 k per parity, k contiguous in HBM (coalesced rows) and in LDS; a row is 64 / LGDV lanes wide, so the
   // workgroup covers RA = 8 | 16 latitude rows per pass and the stage in two passes
-  constexpr int LA = 64 / LGV, RA = LG_THREADS / LA, LB = LG_BN / LGV, RB = LG_THREADS / LB;  // RB = 4 | 8 Fourier rows per pass, four passes
+  constexpr int LA = 64 / LGDV, RA = LG_THREADS / LA, LB = LG_BN / LGDV, RB = LG_THREADS / LB;  // RB = 4 | 8 Fourier rows per pass, four passes
   constexpr int WRA = 64 / LA;                       // panel rows that one wave loads per instruction
-  constexpr bool SROWS = (LB == 64);                 // a wave loads ONE Fourier row per instruction (fp64): row addresses are scalar
+  static_assert(LB == 64, "a wave loads ONE Fourier row per instruction: row addresses are scalar");
   const int wv = emi_uniform(w);
-  const int arow = tid / LA, ac = (tid % LA) * LGV;  // latitude rows arow and arow + RA of the stage
+  const int arow = tid / LA, ac = (tid % LA) * LGDV;  // latitude rows arow and arow + RA of the stage
   const int ldk = g.ldk[m];
   // as in leg_inv_tile: uniform bases in scalar registers + constant 32-bit lane offsets, no vector address arithmetic per stage
   unsigned voA = (unsigned)(((l / LA) * ldk + ac) * (int)sizeof(real_t));
   const char *uS = emi_uniform_ptr((const real_t *)g.PT + g.offTS[m] + (long long)(wv * WRA) * ldk + k0);
   const char *uA = emi_uniform_ptr((const real_t *)g.PT + g.offTA[m] + (long long)(wv * WRA) * ldk + k0);
   const long long stepA = (long long)LG_LS * ldk * (long long)sizeof(real_t), rowA8 = (long long)RA * ldk * (long long)sizeof(real_t);
-  const int brow = tid / LB, bc = (tid % LB) * LGV;  // latitude rows brow + RB i, i = 0..3, of each stage
-  const real_t *FBc = FB + col0 + bc;
+  const int brow = tid / LB, bc = (tid % LB) * LGDV;  // latitude rows brow + RB i, i = 0..3, of each stage
   unsigned voB = (unsigned)(bc * (int)sizeof(real_t));
   const char *uFB = emi_uniform_ptr(FB + col0);
-  lgvec ra0, ra1, ra2, ra3;                      // P^T of stage s+1
-  lgvec rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
+  lgdvec ra0, ra1, ra2, ra3;                      // P^T of stage s+1
+  lgdvec rn0, rn1, rn2, rn3, rs0, rs1, rs2, rs3;  // FB rows (north, south) of stage s+1
   // The FB rows of one zonal wavenumber are ~26 MB apart (FB is latitude-major for the FFT kernels), so each stage touches 32
-  // far-apart rows, prefetched one stage (~2 x 4096 MFMA cycles per SIMD) ahead.  fp64 (SROWS): a wave loads one whole row piece per
-  // instruction, so its row numbers (fbase[lat]+m) are SCALAR loads from the latitude tables, fetched a further stage ahead, and the
+  // far-apart rows, prefetched one stage (~2 x 4096 MFMA cycles per SIMD) ahead.  A wave loads one whole row piece per
+  // instruction (two values per lane in both precisions), so its row numbers (fbase[lat]+m) are SCALAR loads from the latitude tables, fetched a further stage ahead, and the
   // row address is scalar arithmetic (before: eight LDS look-ups, eight 32 x 32 -> 64-bit vector multiply-adds and eight 64-bit vector
   // adds per stage, which together took the matrix pipe for as long as two matrix instructions).  Latitudes past the last one read
   // row `zrow` of the buffer, a row of zeros behind the Fourier rows: no branch around the loads.
-  // fp32: a wave loads two rows per instruction; their numbers are staged once per tile in LDS, so that looking them up is an LDS
-  // read (lgkmcnt) and never a vector-memory load that would order behind the prefetches (vmcnt).
+  // (Until round 5 the fp32 kernel loaded four values per lane, two rows per instruction, and staged the row numbers of the whole
+  // wavenumber in LDS -- 10 - 20 KB per workgroup on top of a 57 KB stage image, which held it at two workgroups per CU.)
   // destinations of the tile's 64 fields (fused epilogue), staged in LDS now: fetched in the epilogue they cost eight serialised memory
   // round trips (descriptor, then index / stride / NASM0 behind a divergent branch, per 16-column group) -- about 20 k of the 35 k clocks
   // a tile spent between its last matrix instruction and its last store (tools/leg_stamp.py)
@@ -774,24 +753,10 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
     efd[tid] = d_;
   }
   const int nasm0_m = emi_ld_const(g.nasm0, m), mval_m = emi_ld_const(g.mval, m);
-  int *rowN = (int *)(efd + 64);
-  int *rowS = rowN + LG_LS * nst;
-  if constexpr (!SROWS) {
-    for (int j = tid; j < LG_LS * nst; j += LG_THREADS) {
-      int rn_ = zrow, rs_ = zrow;
-      if (j < ndglu) {
-        rn_ = g.legN[lb + j];
-        rs_ = g.legS[lb + j];
-      }
-      rowN[j] = rn_;
-      rowS[j] = rs_;
-    }
-    EMI_SYNC();
-  }
-  int qn[4], qs[4];  // SROWS: row numbers of the stage that is requested next
+  int qn[4], qs[4];  // row numbers of the stage that is requested next
   const int lb_last = lb + ndglu > 0 ? lb + ndglu - 1 : 0;  // a row number that exists, for the look-ups past the last latitude (their rows are then replaced by the zero row)
 #define LEGDIR_ROWS(s_)                                    \
-  if constexpr (SROWS) {                                   \
+  {                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
       const int j_ = LG_LS * (s_) + wv + RB * i_;          \
       const int jc_ = j_ < ndglu ? lb + j_ : lb_last;      \
@@ -799,10 +764,10 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
       qs[i_] = emi_ld_const(g.legS, jc_);                  \
     }                                                      \
   }
-  unsigned qrn[4], qrs[4];  // SROWS: the rows that LEGDIR_LOADB requests
+  unsigned qrn[4], qrs[4];  // the rows that LEGDIR_LOADB requests
   // the selects sit a stage after the scalar loads were issued (nothing waits for them) and BEFORE the next ones overwrite qn / qs
 #define LEGDIR_SEL(s_)                                     \
-  if constexpr (SROWS) {                                   \
+  {                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {     \
       const bool live_ = LG_LS * (s_) + wv + RB * i_ < ndglu; \
       qrn[i_] = live_ ? qn[i_] : zrow;                     \
@@ -810,38 +775,26 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
     }                                                      \
   }
 #define LEGDIR_LOADB(s_)                                                            \
-  if constexpr (SROWS) {                                                            \
+  {                                                                                 \
     const unsigned long long ldfb_ = (unsigned long long)(unsigned)ldf * sizeof(real_t); \
     EMI_OPAQUE(voB);                                                                \
-    rn0 = emi_ld_sv<lgvec>(uFB + qrn[0] * ldfb_, voB);                                 \
-    rs0 = emi_ld_sv<lgvec>(uFB + qrs[0] * ldfb_, voB);                                 \
-    rn1 = emi_ld_sv<lgvec>(uFB + qrn[1] * ldfb_, voB);                                 \
-    rs1 = emi_ld_sv<lgvec>(uFB + qrs[1] * ldfb_, voB);                                 \
-    rn2 = emi_ld_sv<lgvec>(uFB + qrn[2] * ldfb_, voB);                                 \
-    rs2 = emi_ld_sv<lgvec>(uFB + qrs[2] * ldfb_, voB);                                 \
-    rn3 = emi_ld_sv<lgvec>(uFB + qrn[3] * ldfb_, voB);                                 \
-    rs3 = emi_ld_sv<lgvec>(uFB + qrs[3] * ldfb_, voB);                                 \
-  } else {                                                                          \
-    const int j0_ = LG_LS * (s_) + brow;                                            \
-    const int in0 = rowN[j0_], is0 = rowS[j0_], in1 = rowN[j0_ + RB], is1 = rowS[j0_ + RB];         \
-    const int in2 = rowN[j0_ + 2 * RB], is2 = rowS[j0_ + 2 * RB], in3 = rowN[j0_ + 3 * RB], is3 = rowS[j0_ + 3 * RB]; \
-    rn0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in0 * (unsigned)ldf); \
-    rs0 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is0 * (unsigned)ldf); \
-    rn1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in1 * (unsigned)ldf); \
-    rs1 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is1 * (unsigned)ldf); \
-    rn2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in2 * (unsigned)ldf); \
-    rs2 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is2 * (unsigned)ldf); \
-    rn3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)in3 * (unsigned)ldf); \
-    rs3 = *(const lgvec *)(FBc + (unsigned long long)(unsigned)is3 * (unsigned)ldf); \
+    rn0 = emi_ld_sv<lgdvec>(uFB + qrn[0] * ldfb_, voB);                                 \
+    rs0 = emi_ld_sv<lgdvec>(uFB + qrs[0] * ldfb_, voB);                                 \
+    rn1 = emi_ld_sv<lgdvec>(uFB + qrn[1] * ldfb_, voB);                                 \
+    rs1 = emi_ld_sv<lgdvec>(uFB + qrs[1] * ldfb_, voB);                                 \
+    rn2 = emi_ld_sv<lgdvec>(uFB + qrn[2] * ldfb_, voB);                                 \
+    rs2 = emi_ld_sv<lgdvec>(uFB + qrs[2] * ldfb_, voB);                                 \
+    rn3 = emi_ld_sv<lgdvec>(uFB + qrn[3] * ldfb_, voB);                                 \
+    rs3 = emi_ld_sv<lgdvec>(uFB + qrs[3] * ldfb_, voB);                                 \
   }
 #define LEGDIR_LOADA(s_)                                          \
   {                                                               \
     const char *us_ = uS + (s_) * stepA, *ua_ = uA + (s_) * stepA; \
     EMI_OPAQUE(voA);                                              \
-    ra0 = emi_ld_sv<lgvec>(us_, voA);                             \
-    ra1 = emi_ld_sv<lgvec>(ua_, voA);                             \
-    ra2 = emi_ld_sv<lgvec>(us_ + rowA8, voA);                     \
-    ra3 = emi_ld_sv<lgvec>(ua_ + rowA8, voA);                     \
+    ra0 = emi_ld_sv<lgdvec>(us_, voA);                             \
+    ra1 = emi_ld_sv<lgdvec>(ua_, voA);                             \
+    ra2 = emi_ld_sv<lgdvec>(us_ + rowA8, voA);                     \
+    ra3 = emi_ld_sv<lgdvec>(ua_ + rowA8, voA);                     \
   }
   // fragment positions, one register per k step (leg_inv_tile)
   int fa[LG_LS / 4], fb[LG_LS / 4];
@@ -855,7 +808,7 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
   // PRFI2B: (north, south) -> (symmetric, antisymmetric), in place, as soon as the rows of the next stage have arrived
 #define LEGDIR_SUMDIFF()                                   \
   {                                                        \
-    lgvec t_;                                              \
+    lgdvec t_;                                              \
     t_ = lg_sub(rn0, rs0), rn0 = lg_add(rn0, rs0), rs0 = t_; \
     t_ = lg_sub(rn1, rs1), rn1 = lg_add(rn1, rs1), rs1 = t_; \
     t_ = lg_sub(rn2, rs2), rn2 = lg_add(rn2, rs2), rs2 = t_; \
@@ -889,18 +842,18 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
       EMI_SCHED_FENCE(); /* left to itself the scheduler sinks the scalar loads to the wait in front of the second barrier */ \
     }                                                                                                                     \
     /* As[par][latitude in stage][k index], Bs[par][latitude in stage][column] */                                         \
-    *(lgvec *)(As + (0 * LG_LS + arow) * LG_LDA + ac) = ra0;                                                              \
-    *(lgvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;                                                              \
-    *(lgvec *)(As + (0 * LG_LS + arow + RA) * LG_LDA + ac) = ra2;                                                         \
-    *(lgvec *)(As + (1 * LG_LS + arow + RA) * LG_LDA + ac) = ra3;                                                         \
-    *(lgvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = rn0; /* symmetric part */                                         \
-    *(lgvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = rs0; /* antisymmetric part */                                     \
-    *(lgvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = rn1;                                                         \
-    *(lgvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = rs1;                                                         \
-    *(lgvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rn2;                                                     \
-    *(lgvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rs2;                                                     \
-    *(lgvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rn3;                                                     \
-    *(lgvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rs3;                                                     \
+    *(lgdvec *)(As + (0 * LG_LS + arow) * LG_LDA + ac) = ra0;                                                              \
+    *(lgdvec *)(As + (1 * LG_LS + arow) * LG_LDA + ac) = ra1;                                                              \
+    *(lgdvec *)(As + (0 * LG_LS + arow + RA) * LG_LDA + ac) = ra2;                                                         \
+    *(lgdvec *)(As + (1 * LG_LS + arow + RA) * LG_LDA + ac) = ra3;                                                         \
+    *(lgdvec *)(Bs + (0 * LG_LS + brow) * LG_LDB + bc) = rn0; /* symmetric part */                                         \
+    *(lgdvec *)(Bs + (1 * LG_LS + brow) * LG_LDB + bc) = rs0; /* antisymmetric part */                                     \
+    *(lgdvec *)(Bs + (0 * LG_LS + brow + RB) * LG_LDB + bc) = rn1;                                                         \
+    *(lgdvec *)(Bs + (1 * LG_LS + brow + RB) * LG_LDB + bc) = rs1;                                                         \
+    *(lgdvec *)(Bs + (0 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rn2;                                                     \
+    *(lgdvec *)(Bs + (1 * LG_LS + brow + 2 * RB) * LG_LDB + bc) = rs2;                                                     \
+    *(lgdvec *)(Bs + (0 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rn3;                                                     \
+    *(lgdvec *)(Bs + (1 * LG_LS + brow + 3 * RB) * LG_LDB + bc) = rs3;                                                     \
     LEG_STAMP(1);                                                                                                         \
     if constexpr (!(LAST_)) {                                                                                             \
       LEGDIR_LOADB((s) + 1);                                                                                              \
@@ -973,7 +926,7 @@ EMI_DEVFN void leg_dir_tile2(const EmiGeomDev &g, const int m, const int kt, con
     }
   LEG_STAMP_EPI(2);
 }
-EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const int zrow, int ldf, real_t *W, int ldw,
+EMI_KERNEL_LB2(256, EMI_LEG_DIR_WAVES) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const int zrow, int ldf, real_t *W, int ldw,
                                       const FuseDst *fd) {
   const int2 tm = tilemap[EMI_BID];
   if (tm.x < 0) return;
@@ -984,9 +937,7 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
   const int nk = g.wrows[m] >> 1;
   if constexpr (sizeof(real_t) == 4) {
     const int left = (nk - rt * 64 + 15) >> 4;  // live 16-row groups of this tile
-    if (g.m0_wide && g.mval[m] == 0)            // the mean wavenumber in double (LegAcc)
-      leg_dir_tile2<false, true>(g, m, rt, ct, left < 4 ? left : 4, FB, zrow, ldf, W, ldw, fd);
-    else if (left >= 4)
+    if (left >= 4)
       leg_dir_tile2<true, false>(g, m, rt, ct, 4, FB, zrow, ldf, W, ldw, fd);
     else
       leg_dir_tile2<false, false>(g, m, rt, ct, left, FB, zrow, ldf, W, ldw, fd);
@@ -1004,6 +955,17 @@ EMI_KERNEL_LB2(256, 2) void k_leg_dir(EmiGeomDev g, const int2 *tilemap, const r
       leg_dir_tile<false, false>(g, m, par, kt, ct, left, FB, zrow, ldf, W, ldw, fd);
   }
 }
+#if EMI_LEG_WIDE_KERNEL
+// fp32 library: the tiles of zonal wavenumber 0 accumulate in double (LegAcc<true>, ledir_mod.F90:133-171), from a tile map of their own
+EMI_KERNEL_LB2(256, 2) void k_leg_dir_wide(EmiGeomDev g, const int2 *tilemap, const real_t *FB, const int zrow, int ldf, real_t *W, int ldw,
+                                           const FuseDst *fd) {
+  const int2 tm = tilemap[EMI_BID];
+  if (tm.x < 0) return;
+  const int m = tm.x, rt = tm.y >> 16, ct = tm.y & 0xffff;
+  const int left = ((g.wrows[m] >> 1) - rt * 64 + 15) >> 4;
+  leg_dir_tile2<false, true>(g, m, rt, ct, left < 4 ? left : 4, FB, zrow, ldf, W, ldw, fd);
+}
+#endif
 
 // ==========================================================================================
 // FFT engine in LDS (v2): in-place mixed-radix Cooley-Tukey on `nfl` fields of S complex points.
