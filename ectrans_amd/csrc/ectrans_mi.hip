@@ -180,7 +180,11 @@ extern "C" int emi_ptr_space(const void *p) {
 #endif
 }
 // mem_space of a call -> EMI_MEM_HOST or EMI_MEM_DEVICE; AUTO classifies every array that is present
-static int resolve_space(const char *who, int mem_space, std::initializer_list<const void *> arrays, int *out) {
+static int agree_on_mixed_arrays(const char *who, int ndev, int nhost);
+// `collective`: the routine is called by every task together (the transforms): with several tasks a task whose arrays are in both memories must
+// not fail alone -- its peers, whose arrays are all in one place, would go on into the exchange and wait for it forever -- so the outcome of
+// the classification is agreed over the host collectives (one word per task) before anybody starts.
+static int resolve_space(const char *who, int mem_space, std::initializer_list<const void *> arrays, int *out, bool collective = false) {
   if (mem_space == EMI_MEM_HOST || mem_space == EMI_MEM_DEVICE) {
     *out = mem_space;
     return 0;
@@ -189,8 +193,11 @@ static int resolve_space(const char *who, int mem_space, std::initializer_list<c
   int ndev = 0, nhost = 0;
   for (const void *q : arrays)
     if (q) (emi_ptr_space(q) == EMI_MEM_DEVICE ? ndev : nhost)++;
-  if (ndev && nhost)
+  if (collective) {
+    if (agree_on_mixed_arrays(who, ndev, nhost)) return EMI_ERR_ARG;
+  } else if (ndev && nhost) {
     EMI_FAIL(EMI_ERR_ARG, "%s: %d ARRAYS OF THE CALL ARE IN DEVICE MEMORY AND %d IN HOST MEMORY (all of them must live in one place)", who, ndev, nhost);
+  }
   *out = ndev ? EMI_MEM_DEVICE : EMI_MEM_HOST;
   return 0;
 }
@@ -309,8 +316,18 @@ struct Plan {
 };
 
 static int roundup(int a, int b) { return (a + b - 1) / b * b; }
+// EMI_TEST_PATHS (tests only; read at every SETUP_TRANS / call, so a test can flip it): bit 0 = exchange-order row tables on ONE task
+// (g.fftrow / legN / legS as with several tasks), bit 1 = the 4-batch three-stream pipeline on one task, bit 2 = the scalar fields of
+// DIR_TRANS through k_postpack_dir instead of k_leg_dir's epilogue.  Each is the code several tasks (or the adjoint options) run; the
+// switch keeps it under the one-GPU test tier.  Results are identical with and without.
+static int test_paths() {
+  const char *e = getenv("EMI_TEST_PATHS");
+  return e ? atoi(e) : 0;
+}
 // dynamic LDS of k_leg_dir: the operand stage of its two-parity tile (panel and Fourier rows of 16 latitudes: 56 KiB in fp64, 28 in fp32) and the
-// staged destinations of the tile's 64 fields (1 KiB).  Must fit the 80 KiB the kernel is allowed (set_lds_attrs): checked at SETUP_TRANS.
+// staged destinations of the tile's 64 fields (1 KiB).  A constant per precision since round 5 (no row-number tables, nothing depends on
+// NDGNH), so the check is a compile-time one: two workgroups per CU need it below 64 KiB each.
+static_assert(LG_LDS_BYTES_DIR + 1024 + 64 <= 65536, "k_leg_dir: stage image + epilogue table above 64 KiB, two workgroups per CU no longer fit");
 static size_t leg_dir_lds_bytes(const Plan &P) {
   return (size_t)LG_LDS_BYTES_DIR * P.esz / 8 + 1024 + 64;
 }
@@ -337,12 +354,23 @@ static int plan_end(Plan &P, emi_stream_t st) {
   return 0;
 }
 // host waits until the last call of the resolution has finished (before its buffers are freed or regrown)
-static void plan_quiesce(Plan &P) {
+static const char *emi_rt_errstr(int rc) {
 #ifndef EMI_CPU_EMU
-  if (P.ev_valid) (void)hipEventSynchronize(P.ev_done);
+  return hipGetErrorString((hipError_t)rc);
+#else
+  (void)rc;
+  return "";
+#endif
+}
+// Returns the status of the wait (0 = the stream reached the event): a kernel fault or a lost device surfaces here, and emi_wait -- the
+// only completion point of the Fortran shim and transi for device-resident arrays -- turns it into EMI_ERR_RUNTIME.
+static int plan_quiesce(Plan &P) {
+#ifndef EMI_CPU_EMU
+  if (P.ev_valid) return (int)hipEventSynchronize(P.ev_done);
 #else
   (void)P;
 #endif
+  return 0;
 }
 
 static struct {
@@ -1194,7 +1222,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
   P.leg_disp.assign(NP, 0);
   P.fft_rows.assign(NP, 0);
   P.fft_disp.assign(NP, 0);
-  const bool tables = NP > 1;  // one task: plain affine rows, no table
+  const bool tables = NP > 1 || (test_paths() & 1);  // one task: plain affine rows, no table
   if (!tables) {
     for (int ml = 0; ml < NU; ml++) {
       const int m = P.mval[ml], nd = P.lbase[ml + 1] - P.lbase[ml], isl0 = P.ndgnh - nd;
@@ -1449,11 +1477,6 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       for (void *q : {(void *)d_dcl, (void *)d_ddl, (void *)d_zf, (void *)d_mu, (void *)d_blk}) emi_dev_free(q);
     }
     phase("legendre panels (device)");
-  }
-  if (leg_dir_lds_bytes(P) > 80 * 1024) {
-    delete pp;
-    EMI_FAIL(EMI_ERR_UNSUPPORTED, "SETUP_TRANS: %d latitudes per hemisphere need %zu bytes of LDS in the direct Legendre kernel (limit 81920): grid too large for the %s library",
-             P.ndgnh, leg_dir_lds_bytes(P), P.esz == 4 ? "fp32" : "fp64");
   }
   int rc = build_fft_plans(P);
   phase("fft plans + tables");
@@ -2135,7 +2158,7 @@ static int pipeline_depth(const Plan &P, int nfields) {
   // one task: sequential.  Co-running the two kernel families of neighbouring field batches was measured SLOWER on MI355X
   // (TCo1279/KF=1645: 555 vs 531 ms per pair with 4 batches; round 2: 400.7 vs 391.7) -- the FFT kernels need all 16 waves per CU
   // to hide latency and the Legendre kernels lose MFMA issue slots.
-  const int cfg = 1;
+  const int cfg = (test_paths() & 2) ? 4 : 1;
 #ifdef EMI_CPU_EMU
   (void)P;
   (void)nfields;
@@ -2672,7 +2695,7 @@ static int dir_trans_impl(int kresol, const emi_dirtrans_t *ap, bool adj, const 
   if (ensure_work(P, bfpad, piped ? 2 : 1, st)) return EMI_ERR_RUNTIME;
   const int ldw_max = 2 * bfpad;  // row width of the widest batch; every batch has its own (2 x its fields rounded up to 64)
   struct Bat { size_t off_g, off_o, off_f; int ng, no, ldw; };
-  const bool fuse_dir = true;  // plain-copy fields leave k_leg_dir's epilogue straight for the caller's arrays
+  const bool fuse_dir = !(test_paths() & 4);  // plain-copy fields leave k_leg_dir's epilogue straight for the caller's arrays
   std::vector<Bat> bats;
   std::vector<char> hdesc;
   for (auto &b : batches) {
@@ -3393,7 +3416,6 @@ struct VGroups {
   std::vector<int> osc;            // their owners
   int nsc_g[4] = {0, 0, 0, 0};     // global counts: PSPSCALAR fields, PSPSC2 fields, PSPSC3A levels, PSPSC3B levels
   int nvar3a = 0, nvar3b = 0;      // variables of PSPSC3A / PSPSC3B = IF_SC3A_G3 / IF_SC3B_G3 (inv_trans.F90:277, 310): the same on every task
-  int ext3a = 0, ext3b = 0;        // variables PGP3A / PGP3B have room for (third extent / 3 with LDSCDERS): >= the count, as the reference requires
 };
 template <class ARGS>
 static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) {
@@ -3443,13 +3465,13 @@ static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) 
       // The reference takes the variable count from UBOUND(PSPSC3A,3), which a task whose V-set owns no level still passes as a
       // zero-level array (inv_trans.F90:272-277 aborts without it).  Here such a task may have no spectral array at all, so the
       // count also travels in the KVSET block (from the grid array); without either the peers would disagree on the field list.
-      // the count is UBOUND(PSPSC3A,3) wherever the task names one (also with zero levels); the grid array may have room for more
-      // variables than that (the reference only asks UBOUND(PGP3A,3) >= IF_SC3A_G3 [x 3])
+      // the count is UBOUND(PSPSC3A,3) wherever the task names one (also with zero levels), and the third extent of PGP3A (/ 3 with
+      // LDSCDERS) must EQUAL it: inv_trans.F90:557, :587 and dir_trans.F90:451, :481 abort on `IUBOUND(3) /= IF_SC3A_G3`.  A grid array with
+      // spare room would also let a task that names no PSPSC3A (count taken from the grid array) list other global fields than its peers.
       vg.nvar3a = a.sc3a_nvar > 0 ? a.sc3a_nvar : vs->nvar3a_g;
       if (vg.nvar3a <= 0) EMI_FAIL(EMI_ERR_ARG, "%s:KVSETSC3A BUT NOT PSPSC3A (number of variables unknown: pass sc3a_nvar or emi_vsets_t.nvar3a_g)", who);
-      if (vs->nvar3a_g > 0 && vs->nvar3a_g < vg.nvar3a)
-        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3A TOO SMALL (room for %d variables, IF_SC3A_G3 = %d)", who, vs->nvar3a_g, vg.nvar3a);
-      vg.ext3a = std::max(vg.nvar3a, vs->nvar3a_g);
+      if (vs->nvar3a_g > 0 && vs->nvar3a_g != vg.nvar3a)
+        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3A INCONSISTENT (%d variables, IF_SC3A_G3 = %d)", who, vs->nvar3a_g, vg.nvar3a);
       for (int v = 0; v < vg.nvar3a; v++)
         for (int l = 0; l < vs->nsc3a_g; l++) vg.sc_g.push_back({2, l, v}), vg.osc.push_back(o[l]);
       if (check_local("KVSETSC3A", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3a ? a.sc3a_nlev : 0)) return EMI_ERR_ARG;
@@ -3457,13 +3479,13 @@ static int v_groups(const Plan &P, const ARGS &a, const char *who, VGroups &vg) 
     if (vs->kvsetsc3b) {
       if (owners(vs->kvsetsc3b, vs->nsc3b_g, "KVSETSC3B", o)) return EMI_ERR_ARG;
       vg.nsc_g[3] = vs->nsc3b_g;
-      // the count is UBOUND(PSPSC3B,3) wherever the task names one (also with zero levels); the grid array may have room for more
-      // variables than that (the reference only asks UBOUND(PGP3B,3) >= IF_SC3B_G3 [x 3])
+      // the count is UBOUND(PSPSC3B,3) wherever the task names one (also with zero levels), and the third extent of PGP3B (/ 3 with
+      // LDSCDERS) must EQUAL it: inv_trans.F90:557, :587 and dir_trans.F90:451, :481 abort on `IUBOUND(3) /= IF_SC3B_G3`.  A grid array with
+      // spare room would also let a task that names no PSPSC3B (count taken from the grid array) list other global fields than its peers.
       vg.nvar3b = a.sc3b_nvar > 0 ? a.sc3b_nvar : vs->nvar3b_g;
       if (vg.nvar3b <= 0) EMI_FAIL(EMI_ERR_ARG, "%s:KVSETSC3B BUT NOT PSPSC3B (number of variables unknown: pass sc3b_nvar or emi_vsets_t.nvar3b_g)", who);
-      if (vs->nvar3b_g > 0 && vs->nvar3b_g < vg.nvar3b)
-        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3B TOO SMALL (room for %d variables, IF_SC3B_G3 = %d)", who, vs->nvar3b_g, vg.nvar3b);
-      vg.ext3b = std::max(vg.nvar3b, vs->nvar3b_g);
+      if (vs->nvar3b_g > 0 && vs->nvar3b_g != vg.nvar3b)
+        EMI_FAIL(EMI_ERR_ARG, "%s:THIRD DIMENSION OF PGP3B INCONSISTENT (%d variables, IF_SC3B_G3 = %d)", who, vs->nvar3b_g, vg.nvar3b);
       for (int v = 0; v < vg.nvar3b; v++)
         for (int l = 0; l < vs->nsc3b_g; l++) vg.sc_g.push_back({3, l, v}), vg.osc.push_back(o[l]);
       if (check_local("KVSETSC3B", (int)std::count(o.begin(), o.end(), P.mev), a.spsc3b ? a.sc3b_nlev : 0)) return EMI_ERR_ARG;
@@ -3493,8 +3515,8 @@ static void v_grid_fields(const VGroups &vg, bool lvorgp, bool ldivgp, bool lscd
     const ScalarRef &r = vg.sc_g[isc];
     if (gp) { g.base = gp; g.nf_arr = gp_nfld; g.fidx = gcount; }
     else if (r.arr == 1) { g.base = gp2; g.nf_arr = vg.nsc_g[1] * dmul; g.fidx = r.lev + kder * vg.nsc_g[1]; }
-    else if (r.arr == 2) { g.base = gp3a; g.nf_arr = vg.nsc_g[2] * vg.ext3a * dmul; g.fidx = (r.var + kder * nvar3a) * vg.nsc_g[2] + r.lev; }
-    else { g.base = gp3b; g.nf_arr = vg.nsc_g[3] * vg.ext3b * dmul; g.fidx = (r.var + kder * nvar3b) * vg.nsc_g[3] + r.lev; }
+    else if (r.arr == 2) { g.base = gp3a; g.nf_arr = vg.nsc_g[2] * nvar3a * dmul; g.fidx = (r.var + kder * nvar3a) * vg.nsc_g[2] + r.lev; }
+    else { g.base = gp3b; g.nf_arr = vg.nsc_g[3] * nvar3b * dmul; g.fidx = (r.var + kder * nvar3b) * vg.nsc_g[3] + r.lev; }
     out.g.push_back(g), out.owner.push_back(vg.osc[isc]);
     gcount++;
   };
@@ -3582,8 +3604,8 @@ static int inv_trans_vsets(int kresol, const emi_invtrans_t *ap, bool adj) {
   void *d_gp = hs.out(a.gp, gsz * a.gp_nfld, host, gpad || a.gp_nfld > if_gp_g, st);
   void *d_gpuv = hs.out(a.gpuv, gsz * nuvg * nvar_uv, host && nuvg, gpad, st);
   void *d_gp2 = hs.out(a.gp2, gsz * vg.nsc_g[1] * dmul, host, gpad, st);
-  void *d_gp3a = hs.out(a.gp3a, gsz * vg.nsc_g[2] * vg.ext3a * dmul, host, gpad || vg.ext3a > vg.nvar3a, st);
-  void *d_gp3b = hs.out(a.gp3b, gsz * vg.nsc_g[3] * vg.ext3b * dmul, host, gpad || vg.ext3b > vg.nvar3b, st);
+  void *d_gp3a = hs.out(a.gp3a, gsz * vg.nsc_g[2] * vg.nvar3a * dmul, host, gpad, st);
+  void *d_gp3b = hs.out(a.gp3b, gsz * vg.nsc_g[3] * vg.nvar3b * dmul, host, gpad, st);
   if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
   VGridList gl;
   v_grid_fields(vg, lvorgp, ldivgp, lscders, luvder, d_gp, a.gp_nfld, d_gpuv, nvar_uv, d_gp2, d_gp3a, d_gp3b, gl);
@@ -3673,8 +3695,8 @@ static int dir_trans_vsets(int kresol, const emi_dirtrans_t *ap, bool adj, const
   void *d_gp = (void *)hs.in(a.gp, gsz * a.gp_nfld, host, st);
   void *d_gpuv = (void *)hs.in(a.gpuv, gsz * nuvg * 2, host && nuvg, st);
   void *d_gp2 = (void *)hs.in(a.gp2, gsz * vg.nsc_g[1], host, st);
-  void *d_gp3a = (void *)hs.in(a.gp3a, gsz * vg.nsc_g[2] * vg.ext3a, host, st);
-  void *d_gp3b = (void *)hs.in(a.gp3b, gsz * vg.nsc_g[3] * vg.ext3b, host, st);
+  void *d_gp3a = (void *)hs.in(a.gp3a, gsz * vg.nsc_g[2] * vg.nvar3a, host, st);
+  void *d_gp3b = (void *)hs.in(a.gp3b, gsz * vg.nsc_g[3] * vg.nvar3b, host, st);
   if (hs.failed) EMI_FAIL(EMI_ERR_RUNTIME, "%s: cannot stage the host arrays through device memory (%s)", who, emi_last_error());
   VGridList gl;  // u(nuv_g) v(nuv_g) scalars: dir_trans.F90:301
   v_grid_fields(vg, false, false, false, false, d_gp, a.gp_nfld, d_gpuv, 2, d_gp2, d_gp3a, d_gp3b, gl);
@@ -3724,12 +3746,32 @@ static int dir_trans_vsets(int kresol, const emi_dirtrans_t *ap, bool adj, const
 
 // EMI_MEM_AUTO of a transform call: every array of the argument block is classified (emi_ptr_space); the call then runs as
 // EMI_MEM_DEVICE (arrays used in place) or EMI_MEM_HOST (staged) -- or is refused when the arrays are in both places
+// EMI_MEM_AUTO with several tasks: every task learns whether ANY task found its arrays in both memories, and then all of them fail together
+// with the text of the offending task (one 4-byte word per task over the host collectives; host and device callers may mix between tasks,
+// staging is local).  Without registered collectives (a host that drives the exchange hook only) the outcome must be identical on every
+// task by the caller's construction, as include/ectrans_mi.h says.
+static int agree_on_mixed_arrays(const char *who, int ndev, int nhost) {
+  const int mixed = (ndev && nhost) ? 1 : 0;
+  if (G.nproc_all > 1 && G.hc_gather) {
+    const int NA = G.nproc_all;
+    std::vector<int> all(NA, 0);
+    std::vector<long long> cnt(NA, 4), dsp(NA);
+    for (int r = 0; r < NA; r++) dsp[r] = 4LL * r;
+    if (G.hc_gather(G.hc_user, &mixed, 4, all.data(), cnt.data(), dsp.data(), NA)) EMI_FAIL(EMI_ERR_RUNTIME, "%s: all-gather-v failed", who);
+    for (int r = 0; r < NA; r++)
+      if (all[r] && !mixed)
+        EMI_FAIL(EMI_ERR_ARG, "%s: ARRAYS OF THE CALL ARE IN DEVICE MEMORY AND IN HOST MEMORY ON TASK %d (all of them must live in one place)", who, r + 1);
+  }
+  if (mixed)
+    EMI_FAIL(EMI_ERR_ARG, "%s: %d ARRAYS OF THE CALL ARE IN DEVICE MEMORY AND %d IN HOST MEMORY (all of them must live in one place)", who, ndev, nhost);
+  return 0;
+}
 template <class A>
 static int resolve_call(const char *who, const A *ap, A &a) {
   if (!ap) EMI_FAIL(EMI_ERR_ARG, "%s: null argument block", who);
   a = *ap;
   return resolve_space(who, ap->mem_space, {ap->spvor, ap->spdiv, ap->spscalar, ap->spsc3a, ap->spsc3b, ap->spsc2, ap->gp, ap->gpuv, ap->gp3a, ap->gp3b, ap->gp2},
-                       &a.mem_space);
+                       &a.mem_space, true);
 }
 extern "C" int emi_inv_trans(int kresol, const emi_invtrans_t *args) {
   EmiRange rg(EMI_LBL_INV);  // GSTATS 4
@@ -3750,11 +3792,14 @@ extern "C" int emi_wait(int kresol) {
   if (kresol > 0) {
     Plan *Pp = get_plan(kresol);
     if (!Pp) EMI_FAIL(EMI_ERR_STATE, "emi_wait: unknown resolution %d", kresol);
-    plan_quiesce(*Pp);
+    if (const int rc = plan_quiesce(*Pp)) EMI_FAIL(EMI_ERR_RUNTIME, "emi_wait: the last call of resolution %d did not complete (%s)", kresol, emi_rt_errstr(rc));
     return EMI_SUCCESS;
   }
-  for (Plan *Pp : G.plans)
-    if (Pp && Pp->active) plan_quiesce(*Pp);
+  for (size_t i = 0; i < G.plans.size(); i++) {
+    Plan *Pp = G.plans[i];
+    if (!Pp || !Pp->active) continue;
+    if (const int rc = plan_quiesce(*Pp)) EMI_FAIL(EMI_ERR_RUNTIME, "emi_wait: the last call of resolution %d did not complete (%s)", (int)i, emi_rt_errstr(rc));
+  }
   return EMI_SUCCESS;
 }
 

@@ -140,7 +140,7 @@ struct FftLaunchDev {
 #define LG_LDA 80
 #define LG_LDB 144
 #define LG_LDS_BYTES ((2 * 8 * LG_LDA + 2 * 8 * LG_LDB) * 8)  // k_leg_inv, 8-row stages; sized for fp64 (fp32 uses half)
-#define LG_LDS_BYTES_DIR (2 * LG_LDS_BYTES)                  // k_leg_dir, 16-row stages of its two-parity tile (the one-parity tile needs 2 x 16 x LG_LDB x 8) (+ its row-number tables)
+#define LG_LDS_BYTES_DIR (2 * LG_LDS_BYTES)                  // k_leg_dir, 16-row stages of its two-parity tile (the one-parity tile needs 2 x 16 x LG_LDB x 8)
 #define FPAD(i) ((i) ^ (((i) >> 3) & 15))
 #define FFT_LDS_ELEMS(S) (((S) + 15) & ~15)
 // First radices R1 of the register-resident kernels (work length 256 R1).  R1 = 18 and 20 (work lengths 4608, 5120) were built and

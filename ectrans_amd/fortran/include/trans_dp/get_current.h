@@ -1,0 +1,1 @@
+#include "../get_current.h"

@@ -1,0 +1,10 @@
+! Automatically generated interface header for backward compatibility of generic symbols !
+#if defined(inv_trans)
+#undef inv_trans
+#endif
+#if defined(INV_TRANS)
+#undef INV_TRANS
+#endif
+#include "../inv_trans_dp.h"
+#define inv_trans INV_TRANS_DP
+#define INV_TRANS INV_TRANS_DP

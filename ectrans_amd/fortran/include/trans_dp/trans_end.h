@@ -1,0 +1,10 @@
+! Automatically generated interface header for backward compatibility of generic symbols !
+#if defined(trans_end)
+#undef trans_end
+#endif
+#if defined(TRANS_END)
+#undef TRANS_END
+#endif
+#include "../trans_end_dp.h"
+#define trans_end TRANS_END_DP
+#define TRANS_END TRANS_END_DP

@@ -1,0 +1,10 @@
+! Automatically generated interface header for backward compatibility of generic symbols !
+#if defined(gpnorm_transtl)
+#undef gpnorm_transtl
+#endif
+#if defined(GPNORM_TRANSTL)
+#undef GPNORM_TRANSTL
+#endif
+#include "../gpnorm_transtl_sp.h"
+#define gpnorm_transtl GPNORM_TRANSTL_SP
+#define GPNORM_TRANSTL GPNORM_TRANSTL_SP

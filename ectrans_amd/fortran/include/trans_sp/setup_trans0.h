@@ -1,0 +1,1 @@
+#include "../setup_trans0.h"

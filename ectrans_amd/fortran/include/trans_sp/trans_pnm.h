@@ -1,0 +1,10 @@
+! Automatically generated interface header for backward compatibility of generic symbols !
+#if defined(trans_pnm)
+#undef trans_pnm
+#endif
+#if defined(TRANS_PNM)
+#undef TRANS_PNM
+#endif
+#include "../trans_pnm_sp.h"
+#define trans_pnm TRANS_PNM_SP
+#define TRANS_PNM TRANS_PNM_SP

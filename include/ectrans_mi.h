@@ -20,7 +20,9 @@
  *  - pointers are HOST pointers when mem_space == EMI_MEM_HOST (staged over PCIe) and DEVICE (HBM)
  *    pointers when mem_space == EMI_MEM_DEVICE (used in place, zero-copy; what bench.py times).
  *    mem_space == EMI_MEM_AUTO: the library classifies every array of the call (hipPointerGetAttributes):
- *    all in device memory -> used in place, all in host memory -> staged, a mixture -> EMI_ERR_ARG.  This is
+ *    all in device memory -> used in place, all in host memory -> staged, a mixture -> EMI_ERR_ARG (with several tasks
+ *    and registered host collectives every task of the call fails together; without them the caller must make sure
+ *    the outcome is the same on every task, or the others wait in the exchange).  This is
  *    what the Fortran shim and the transi layer pass, i.e. the reference GPU back-end's present-or-copyin
  *    treatment of its caller's arrays (trans/gpu/internal/trltog_mod.F90:501-523, trgtol_mod.F90:444-448,
  *    ltinv_mod.F90:334-338, updsp_mod.F90:96-97): a Fortran / C caller whose fields already live on the
@@ -145,11 +147,11 @@ typedef struct {
   const int *kvsetsc2;  int nsc2_g;   /* KVSETSC2(nsc2_g)                                          */
   const int *kvsetsc3a; int nsc3a_g;  /* KVSETSC3A(nsc3a_g): V-set of every LEVEL of PSPSC3A       */
   const int *kvsetsc3b; int nsc3b_g;
-  /* Room for variables in PGP3A / PGP3B: their third extent (/ 3 with LDSCDERS).  The number of variables itself (the reference's
+  /* Variables in PGP3A / PGP3B: their third extent (/ 3 with LDSCDERS).  The number of variables itself (the reference's
    * IF_SC3A_G3 = UBOUND(PSPSC3A,3), inv_trans.F90:277) is sc3a_nvar / sc3b_nvar of the call wherever a task names it -- a task whose V-set owns
-   * no level passes it with sc3a_nlev = 0, as the reference's zero-level array -- and must be the same on every task; the grid arrays may have
-   * room for more (the reference asks UBOUND(PGP3A,3) >= IF_SC3A_G3 [x 3]), fewer is an error.  0: as many as the call names; a task that
-   * names none (sc3a_nvar = 0) takes the count from here.                                                                                */
+   * no level passes it with sc3a_nlev = 0, as the reference's zero-level array -- and must be the same on every task.  The grid arrays must hold
+   * exactly that many: any other value fails with 'THIRD DIMENSION OF PGP3A INCONSISTENT' (inv_trans.F90:557, :587, dir_trans.F90:451, :481).
+   * 0: not stated (the call's count is used); a task that names no spectral array (sc3a_nvar = 0) takes the count from here.               */
   int nvar3a_g, nvar3b_g;
 } emi_vsets_t;
 

@@ -1,3 +1,4 @@
+#include "emi_variant.h"   /* the generic names of this file are the _DP (or, with -DEMI_SP, _SP) entry points: ectrans_amd/fortran/emi_variant.h */
 ! NPRTRV = 2 through the Fortran drop-in: `mpiexec -n 2` (NPRTRW x NPRTRV = 1 x 2) and `-n 4` (2 x 2).
 ! As in the IFS, the spectral arrays of a task hold the wavenumbers of its W-set and the fields of its V-set (KVSETSC), the
 ! grid arrays all fields on its own latitudes (inv_trans.F90:212-300).  Two checks without an oracle:

@@ -401,6 +401,18 @@ def test_field_batching_is_invisible(et, dev):
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
 
+@pytest.mark.parametrize("paths", [1, 2, 4, 7])
+def test_multi_task_code_paths_on_one_task(et, dev, paths, monkeypatch):
+    """EMI_TEST_PATHS (test-only switch of csrc/ectrans_mi.hip): bit 0 = the exchange-order row tables (legN / legS / fftrow) on one task,
+    bit 1 = the 4-batch three-stream pipeline on one task (needs >= 256 Fourier fields), bit 2 = the scalar fields of DIR_TRANS through
+    k_postpack_dir instead of the epilogue of k_leg_dir.  Several tasks (and the adjoint options) run exactly this code; the switch keeps it
+    covered on a box with one GPU.  Same bound as every other case."""
+    from oracle.oracle import Oracle as O
+    monkeypatch.setenv("EMI_TEST_PATHS", str(paths))
+    e_inv, e_dir = run_case(et, O, dev, 31, octahedral(31), 40, 200, dict(vorgp=True))
+    assert e_inv < TOL and e_dir < TOL, (paths, e_inv, e_dir)
+
+
 def test_call_mode_2(et, dev):
     """PSPSC3A/PSPSC2 + PGPUV/PGP3A/PGP2 (the arrays ectrans-benchmark uses, :450-479)."""
     to, back = dev

@@ -29,6 +29,21 @@ def test_fortran_shim_single_precision():
     _run("fortran", "test_shim_sp", "FORTRAN SHIM OK (JPRB = real32)")
 
 
+def test_fortran_shim_both_precisions_in_one_executable():
+    """ecTrans 1.7.0 names its entry points per precision (INV_TRANS_DP / INV_TRANS_SP, ...: src/trans/CMakeLists.txt:43-93,
+    sedrenames.txt) so that trans_dp and trans_sp live in one executable, as IFS uses them.  tests/fortran/test_shim_both.F90 links
+    libectrans_mi_f.so AND libectrans_mi_f_sp.so (+ the common library with SETUP_TRANS0), takes its interface blocks from
+    ectrans_amd/fortran/include/*_dp.h / *_sp.h and runs a real64 and a real32 resolution side by side: dp round trip 1e-12, sp against
+    dp at float accuracy (and not better: the sp library ran fp32 kernels)."""
+    _run("fortran", "test_shim_both", "FORTRAN SHIM OK (dp and sp in one executable)")
+
+
+def test_fortran_shim_generic_names_through_compat_headers():
+    """A caller written against the generic names (`#include "inv_trans.h"`, CALL INV_TRANS) compiled with -Iinclude/trans_dp: the
+    backward-compatibility headers of src/trans/CMakeLists.txt:76-85 map it onto the _DP entry points."""
+    _run("fortran", "test_shim_compat", "FORTRAN SHIM OK (generic names through include/trans_dp)")
+
+
 def test_transi_c_api():
     """trans_new/trans_setup/trans_inquire/trans_dirtrans/trans_invtrans/trans_specnorm
     (tests/transi/transi_test.c, modelled on the reference's transi_test_program.c)."""
