@@ -376,6 +376,35 @@ def recorded_traffic(N, nlev, nfld, esz, world, source_hash):
     return None, "no profiles/*_pmc_traffic.json for this build (source hash %s): re-run tools/collect_profiles.sh" % source_hash
 
 
+def exchange_report(rs, world, nprtrw, nprtrv, steps):
+    """The multi-GPU part of the bench line: what each rank spent where, and what the exchange cost.
+    rs[rank] = [ms per step (host wall clock of the rank), pack, Legendre, FFT, exchange (ms per step, HIP events on the stream each phase
+    runs on), bytes sent per step, exchanges per step].  The exchange of one field batch runs beside the kernels of its neighbours
+    (three streams), so the phases of a rank add up to MORE than its step: overlap_frac = the share of the exchange time that is hidden,
+    (sum of phases - step) / exchange, clipped to 0..1, on the slowest rank.  Bytes per link: xGMI is point to point, a task's blocks to
+    its NPRTRW - 1 W-set peers leave over that many links side by side (TRMTOL / TRLTOM: trmtol_mod.F90:101-119, trltom_mod.F90:96-114)."""
+    import numpy as np
+    rs = np.asarray(rs, dtype=float)
+    slow = int(np.argmax(rs[:, 0]))
+    step, pack, leg, fft, xch, xb, xn = rs[slow]
+    hidden = pack + leg + fft + xch - step
+    peers = max(nprtrw - 1, 1)
+    names = ("ms_per_step", "spectral_pack_unpack", "legendre_mfma", "fft", "exchange")
+    return {
+        "exchange_ms_per_step": float(rs[:, 4].max()),
+        "overlap_frac": float(min(1.0, max(0.0, hidden / xch))) if xch > 0 else None,
+        "rank_phase_ms_per_step": {n: {"min": float(rs[:, i].min()), "max": float(rs[:, i].max()), "mean": float(rs[:, i].mean())} for i, n in enumerate(names)},
+        "exchange": {"exchanges_per_step": float(rs[:, 6].max()), "bytes_sent_per_rank_and_step": float(rs[:, 5].max()),
+                     "bytes_per_link_and_direction_per_exchange": float(rs[:, 5].max() / max(rs[:, 6].max(), 1.0) / peers),
+                     "bytes_per_link_per_step": float(rs[:, 5].max() / peers),
+                     "achieved_GBps_per_link": float(rs[:, 5].max() / peers / 1e9 / max(rs[:, 4].max() * 1e-3, 1e-12)),
+                     "xgmi_link_peak_GBps_per_direction": 76.8, "links_used_per_rank": peers,
+                     "slowest_rank": slow, "compute_ms_per_step_slowest_rank": float(pack + leg + fft),
+                     "note": "exchange time = HIP events around the all-to-all-v hook on the exchange stream (includes waiting for the peers); "
+                             "with V-sets the grid-space exchange (TRLTOG / TRGTOL) is counted too"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -560,13 +589,15 @@ def main():
         med = sm[len(sm) // 2] if len(sm) % 2 else 0.5 * (sm[len(sm) // 2 - 1] + sm[len(sm) // 2])
         phases = et.last_phase_ms()
         launches = et.last_phase_launches()[1]
+        xch = et.last_exchange()          # (ms, calls, bytes sent by this rank) of the all-to-all-v exchanges of the loop
+        fftk = et.last_fft_launches()     # kernel launches of the FFT phases of the loop
         et.set_profile(0)
-        return dt, sm, med, phases, launches
+        return dt, sm, med, phases, launches, xch, fftk
 
     for _ in range(args.warmup):
         step()
     # ---- timed region: the reference harness's input (one harmonic), exactly K steps
-    dt, step_ms, med_ms, (pack_ms, leg_ms, fft_ms), leg_launches = timed_loop(args.steps)
+    dt, step_ms, med_ms, (pack_ms, leg_ms, fft_ms), leg_launches, (xch_ms, xch_calls, xch_bytes), fft_kernels = timed_loop(args.steps)
     n1 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
 
     # ---- the same loop on a DENSE spectrum: every coefficient of every field ~ U(-0.5, 0.5) / (n + 1) from
@@ -601,7 +632,7 @@ def main():
         fill(spvor, 0, True), fill(spdiv, 0, True), fill(spsc3a, 1, False), fill(spsc2, 0, False)
         nd0 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
         step()
-        d_dt, d_sm, d_med, (d_pack, d_leg, d_fft), d_launch = timed_loop(args.steps)
+        d_dt, d_sm, d_med, (d_pack, d_leg, d_fft), d_launch, _, _ = timed_loop(args.steps)
         nd1 = et.specnorm(r, spsc2, **({"kvset": kv["kvsetsc2"]} if kv else {}))[0]
         dense_t = {"dt": d_dt, "med": d_med, "pack": d_pack, "leg": d_leg, "fft": d_fft, "launches": d_launch, "drift": abs(nd0 / nd1 - 1.0)}
     kf_l = 2 * nlevl + nfld * nlevl + nsc2l  # Legendre / Fourier-space fields of this rank (= kf without V-sets)
@@ -616,7 +647,14 @@ def main():
     # per Legendre launch: packed spectral + panels + Fourier rows (read or written once)
     alg_leg_bytes = spec_bytes + pan_bytes + wm["fourier_bytes"]
     alg_pair_bytes = 2.0 * (grid_bytes + 2.0 * wm["fourier_bytes"] + 2.0 * spec_bytes + pan_bytes)
+    rank_stats = None
     if world > 1:
+        # what makes the first multi-GPU run self-explaining: every rank's own numbers, gathered BEFORE the maxima below replace them
+        mine = torch.tensor([dt / args.steps * 1e3, pack_ms / args.steps, leg_ms / args.steps, fft_ms / args.steps, xch_ms / args.steps,
+                             xch_bytes / max(args.steps, 1), float(xch_calls) / max(args.steps, 1)], dtype=torch.float64, device=rdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_stats = torch.stack(allr).cpu().numpy()  # [rank][ms_per_step, pack, legendre, fft, exchange, bytes sent per step, exchanges per step]
         tt = torch.tensor([dt, med_ms], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, med_ms = float(tt[0]), float(tt[1])
@@ -677,7 +715,11 @@ def main():
                         "achieved_GBps": 2 * (wm["fourier_bytes"] + kf * ngptot * float(esz)) / 1e9 / max(fft_ms / args.steps * 1e-3, 1e-9),
                         "peak_GBps": 8000.0 * world},
             "fft_bound": recorded_fft_bound(N, nlev, nfld, esz, world, et.source_hash()),
+            # FFT kernel launches per direction and field batch (one per row-length class: ftdir_ctl_mod.F90:182-190 loops over latitudes instead)
+            "fft_launches_per_direction": fft_kernels / max(2.0 * args.steps, 1.0),
         }
+        if world > 1:
+            out.update(exchange_report(rank_stats, world, nprtrw, nprtrv, args.steps))
         if dense_t is not None:
             d_ms = dense_t["dt"] / args.steps * 1e3
             d_ach = wm["legendre_flops"] * 2 * args.steps / max(dense_t["leg"] * 1e-3, 1e-12) / 1e12

@@ -136,6 +136,9 @@ def _bind(L):
     L.emi_set_alltoallv.argtypes = [C.c_void_p, C.c_void_p]
     L.emi_set_profile.argtypes = [C.c_int]
     L.emi_last_phase_launches.argtypes = [ip]
+    if hasattr(L, "emi_last_exchange"):  # (an older build loaded for an A/B run)
+        L.emi_last_exchange.argtypes = [dp, ip, dp]
+        L.emi_last_fft_launches.argtypes = [C.POINTER(C.c_longlong)]
     L.emi_crc64.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
     L.emi_set_host_collectives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.emi_dist_spec.argtypes = [C.c_int, C.c_void_p, C.c_int, ip, ip, C.c_void_p]
@@ -671,6 +674,20 @@ def last_phase_launches():
     out = (C.c_int * 3)()
     lib().emi_last_phase_launches(out)
     return list(out)
+
+
+def last_exchange():
+    """(ms, calls, bytes_sent) of the all-to-all-v exchanges since set_profile(): HIP events around the hook on the exchange stream."""
+    ms, n, b = C.c_double(), C.c_int(), C.c_double()
+    lib().emi_last_exchange(C.byref(ms), C.byref(n), C.byref(b))
+    return ms.value, n.value, b.value
+
+
+def last_fft_launches():
+    """kernel launches of the FFT phases since set_profile()"""
+    k = C.c_longlong()
+    lib().emi_last_fft_launches(C.byref(k))
+    return k.value
 
 
 def set_profile(on):

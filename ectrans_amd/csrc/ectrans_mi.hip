@@ -231,6 +231,7 @@ struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a w
   int nthr = 0, fbk = 0;
   int hot = 0;  // > 0: specialised kernel k_fft_*_hot<hot> (EMI_HOT_PLAN_LIST)
   int r16 = 0;  // > 0: register-resident kernel k_fft_*_r16<r16> (EMI_R16_LIST)
+  int split = 0;  // 2: k_fft_*_r16s<r16> (EMI_R16S_LIST): the row as two convolutions of half its half-length
   int mr = 0;   // 1: direct mixed-radix kernels k_fft_*_mr (EMI_MR_RADICES)
   int gmem = 0;  // 1: the work array does not fit the LDS; k_fft_*_gm on a global scratch buffer (elems: complex numbers per workgroup)
   long long gm_elems = 0;
@@ -560,6 +561,23 @@ static int build_fft_plans(Plan &P) {
       if (need > 1536)  // shorter rows: in-place kernels with several fields per workgroup
         for (int r : r1s)
           if (!pl.r16 && 256 * r >= need) pl.r16 = r;
+      // Split kernels (k_fft_*_r16s<R1>, round 6): a row too long for one register-resident convolution whose half-length is even runs as
+      // two convolutions of length sz / 2, side by side in one 8-wave workgroup, joined by one decimation step.  On by default in the fp32
+      // library only: there they beat the 1024-thread in-place LDS kernels of the long rows by 21 - 23 % (TCo2559: work lengths 6144 / 7680 /
+      // 8192, -45 ms per pair); in fp64 the exchanges move one real plane at a time (twice the workgroup barriers, each now over eight
+      // waves) and the same rows take 10 % LONGER than on k_fft_*_hot<23 | 24> (TCo1279: 54.4 against 49.6 ms per pair;
+      // profiles/r6_fft_experiments.txt).  EMI_FFT_R16S=1 / 0 forces them on / off (tests, A/B runs).
+      const char *e_r16s = getenv("EMI_FFT_R16S");
+      const bool use_r16s = e_r16s ? atoi(e_r16s) != 0 : (P.esz == 4);
+      if (!pl.r16 && need > 4096 && pl.sz % 2 == 0 && use_r16s) {
+        static const int r1ss[] = {
+#define EMI_R16S_ROW(r_) r_,
+            EMI_R16S_LIST(EMI_R16S_ROW)
+#undef EMI_R16S_ROW
+        };
+        for (int r : r1ss)
+          if (!pl.r16 && 256 * r >= pl.sz - 1) pl.r16 = r, pl.split = 2;
+      }
       if (pl.r16) pl.blue = 1;
     }
     if (pl.r16) {
@@ -586,7 +604,7 @@ static int build_fft_plans(Plan &P) {
           if (r[1] < 2 * pl.sz - 1) continue;
           int fbk_r = 16;
           while (fbk_r > 1 && (size_t)fbk_r * FFT_LDS_ELEMS(r[1]) * 2 * P.esz > 40960) fbk_r >>= 1;
-          if (fbk_r != r[8]) continue;
+          if (fbk_r < r[8]) continue;  // (the fp32 library has room for twice the fields: it runs the plan with the list's count, below)
           const long long cost = (long long)r[1] * (r[2] + 1);
           if (cost <= best) {  // list order: a merged tail (ids 22-27) comes after the plain list of its length
             best = cost;
@@ -647,7 +665,7 @@ static int build_fft_plans(Plan &P) {
     n_rtw += pl.sz + 1;
     if (pl.blue) {
       pl.chirp_off = (int)n_chirp;
-      n_chirp += pl.sz;
+      n_chirp += pl.split ? pl.sz / pl.split : pl.sz;
       pl.bhat_off = (int)n_bhat;
       n_bhat += pl.S;
     }
@@ -668,7 +686,6 @@ static int build_fft_plans(Plan &P) {
     // of a global scratch buffer (k_fft_*_gm): slow per row, but such rows are few
     const bool gmem = need > 160 * 1024;
     int nthr = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);
-    const int nthr_rule = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);  // what the specialised kernels are compiled for (hot_threads)
     // specialised kernel for this work length?  (Bluestein, even NLOEN, one field per workgroup)
     int hot = 0;
     if (pl.blue && !pl.cmode && !gmem && !getenv("EMI_FFT_NO_HOT")) {
@@ -677,18 +694,29 @@ static int build_fft_plans(Plan &P) {
           EMI_HOT_PLAN_LIST(EMI_HOT_ROW)
 #undef EMI_HOT_ROW
       };
+      // The list's fields-per-workgroup are those of the fp64 library.  The fp32 library could hold twice as many in its 40 KiB, for which no
+      // kernel is compiled: until round 6 its short rows (work lengths <= 1536) therefore fell through to the generic kernels -- 14.7 of the
+      // 117 ms of FFT per pair at TCo1279 (profiles/r6_pmc_fft_fp32.txt: k_fft_dir 8.35 + k_fft_inv 6.32 ms).  They take the list's plan with
+      // the list's field count now (half the LDS per workgroup; the wave budget of the CU is what limits both).
+      int hot_fbk = 0;
       for (const auto &r : hp) {
-        bool same = r[1] == pl.S && r[2] == pl.nfac && r[8] == fbk;
+        bool same = r[1] == pl.S && r[2] == pl.nfac && r[8] <= fbk;
         for (int i = 0; same && i < pl.nfac; i++) same = r[3 + i] == pl.fac[i];
-        if (same) hot = r[0];
+        if (same) hot = r[0], hot_fbk = r[8];
       }
-      if (hot) nthr = nthr_rule;  // the specialised kernels are compiled for this size
+      if (hot) {
+        fbk = hot_fbk;
+        pl.fbk = fbk;
+        need = fbk * per_field;
+        nthr = need <= 40960 ? 256 : (need <= 81920 ? 512 : 1024);  // = hot_threads(pc): what the specialised kernels are compiled for
+      }
     }
     if (pl.r16) {  // one field per workgroup, 256 or 320 threads, one plane + the 240 small twiddles of LDS
       hot = 0;
       fbk = 1;
       pl.fbk = 1;
       nthr = 16 * pl.r16 > 256 ? roundup(16 * pl.r16, 64) : 256;
+      if (pl.split) nthr = 512;  // k_fft_*_r16s: two halves of 256 threads, one convolution each
     }
     if (pl.mr) {
       hot = 0;
@@ -700,7 +728,7 @@ static int build_fft_plans(Plan &P) {
       if (!hot && !pl.r16 && !pl.mr && (pl.fac[i] == 6 || pl.fac[i] > 8)) EMI_FAIL(EMI_ERR_RUNTIME, "internal: composite FFT radix %d without a specialised kernel (length %d)", pl.fac[i], n);
     int cls = -1;
     for (size_t c = 0; c < P.fclass.size(); c++)
-      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot && P.fclass[c].r16 == pl.r16 && P.fclass[c].mr == pl.mr && P.fclass[c].gmem == (gmem && !pl.mr ? 1 : 0)) cls = (int)c;
+      if (P.fclass[c].nthr == nthr && P.fclass[c].fbk == fbk && P.fclass[c].hot == hot && P.fclass[c].r16 == pl.r16 && P.fclass[c].split == pl.split && P.fclass[c].mr == pl.mr && P.fclass[c].gmem == (gmem && !pl.mr ? 1 : 0)) cls = (int)c;
     if (cls < 0) {
       cls = (int)P.fclass.size();
       P.fclass.emplace_back();
@@ -708,6 +736,7 @@ static int build_fft_plans(Plan &P) {
       P.fclass[cls].fbk = fbk;
       P.fclass[cls].hot = hot;
       P.fclass[cls].r16 = pl.r16;
+      P.fclass[cls].split = pl.split;
       P.fclass[cls].mr = pl.mr;
       P.fclass[cls].gmem = gmem && !pl.mr ? 1 : 0;
     }
@@ -781,10 +810,11 @@ static int build_fft_plans(Plan &P) {
     }
     if (!pl.blue) return;
     d2 *c = chirp.data() + pl.chirp_off;
-    for (int k = 0; k < pl.sz; k++) {
-      long long k2 = ((long long)k * k) % (2LL * pl.sz);
-      double a = M_PI * (double)k2 / (double)pl.sz;
-      c[k] = d2{std::cos(a), -std::sin(a)};  // exp(-i pi k^2/sz)
+    const int csz = pl.split ? pl.sz / pl.split : pl.sz;  // length of the chirp-z transform(s) of the row: the split kernels run two of sz / 2
+    for (int k = 0; k < csz; k++) {
+      long long k2 = ((long long)k * k) % (2LL * csz);
+      double a = M_PI * (double)k2 / (double)csz;
+      c[k] = d2{std::cos(a), -std::sin(a)};  // exp(-i pi k^2/csz)
     }
     // filter b_j = conj(c_|j|) wrapped to length L; Bhat = DFT_L(b) (direct O(L*sz) sum in
     // long double: setup only, keeps the table accurate to ~1e-17), stored at the DIT positions
@@ -796,7 +826,7 @@ static int build_fft_plans(Plan &P) {
     for (int k = 0; k < L; k++) {
       long double sr = c[0].x, si = -c[0].y;
       long long jk = 0;
-      for (int jj = 1; jj < pl.sz; jj++) {
+      for (int jj = 1; jj < csz; jj++) {
         // b_j + b_{L-j} term: conj(c_j) * (w^{jk} + w^{-jk}) = conj(c_j) * 2 cos(2 pi j k/L)
         jk += k;
         if (jk >= L) jk -= L;
@@ -825,7 +855,7 @@ static int build_fft_plans(Plan &P) {
     else if (fc.mr)
       fc.lds = std::max(fc.lds, (size_t)pl.fbk * pl.fac[0] * ((pl.fac[1] * pl.fac[2]) | 1) * 2 * P.esz);
     else if (fc.r16)
-      fc.lds = (size_t)fc.r16 * 272 * 8 + 240 * 2 * P.esz;
+      fc.lds = (size_t)(fc.split ? 2 : 1) * fc.r16 * 272 * 8 + 240 * 2 * P.esz;
     else
       fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 2 * P.esz);
   }
@@ -1171,7 +1201,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
       P.offA[ml] = poff + pan;
       poff += 2 * pan;
       P.ldk[ml] = roundup(P.wrows[ml] / 2, 128);  // whole 128-k tiles of k_leg_dir (zero padded)
-      long long pant = (long long)roundup(std::max(nd, 1), P.esz == 4 ? 32 : 16) * P.ldk[ml];  // k_leg_dir reads stages of 16 (fp64) | 32 (fp32) latitudes (LG_LS)
+      long long pant = (long long)roundup(std::max(nd, 1), 16) * P.ldk[ml];  // k_leg_dir reads stages of 16 latitudes in both precisions (LG_LS; the fp32 kernel's 32-latitude stages went in round 5)
       P.offTS[ml] = ptoff;
       P.offTA[ml] = ptoff + pant;
       ptoff += 2 * pant;
@@ -1373,7 +1403,7 @@ extern "C" int emi_setup_legpol(const emi_setup_t *cfg, const emi_legpol_io_t *i
         return rc;
       };
       if (put(P.d_P + P.offS[ml] * esz, pan)) bad = 1;
-      const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), esz == 4 ? 32 : 16);  // = the panel extent behind offTA (pant)
+      const int ldk = P.ldk[ml], ndp = roundup(std::max(nd, 1), 16);  // = the panel extent behind offTA (pant)
       std::vector<double> pt((size_t)2 * ndp * ldk, 0.0);
       for (int par = 0; par < 2; par++)
         for (int k = 0; k < nk; k++)
@@ -1818,6 +1848,59 @@ static int ensure_work(Plan &P, int bfpad, int nfb, emi_stream_t st) {
   return 0;
 }
 
+// Per-phase device timing with HIP event pairs recorded on the stream each kernel runs on.
+// Nothing is synchronised inside a transform call; emi_last_phase_ms() resolves the events lazily.
+struct PhaseTimer {
+  static const int MAXIV = 4096;
+  int n = 0, ncreated = 0;
+  bool on = false;
+  int kinds[MAXIV];        // 0 spectral pack / unpack, 1 Legendre, 2 FFT, 3 exchange (the all-to-all-v hook, on the stream it is queued on)
+  double xbytes = 0;       // bytes this task handed to the exchange hook since the measurement started (send side, peers only)
+  long long fft_kernels = 0;  // kernel launches of the FFT phases since the measurement started (launch_fft)
+#ifndef EMI_CPU_EMU
+  hipEvent_t e0[MAXIV], e1[MAXIV];
+  // keep: the intervals of earlier calls stay (accumulating mode, emi_set_profile(2)): nothing has to be resolved --
+  // i.e. no host synchronisation -- between the calls of a timed loop
+  void begin(bool on_, bool keep = false) {
+    on = on_;
+    if (!keep) n = 0, xbytes = 0, fft_kernels = 0;
+  }
+  int start(int kind, emi_stream_t s) {
+    if (!on || n >= MAXIV) return -1;
+    if (n >= ncreated) {  // events are created as the intervals are first used
+      (void)hipEventCreate(&e0[n]);
+      (void)hipEventCreate(&e1[n]);
+      ncreated = n + 1;
+    }
+    kinds[n] = kind;
+    (void)hipEventRecord(e0[n], s);
+    return n++;
+  }
+  void stop(int iv, emi_stream_t s) {
+    if (iv >= 0) (void)hipEventRecord(e1[iv], s);
+  }
+  void resolve(double *ms3, int *launches) {  // four entries each
+    for (int i = 0; i < 4; i++) ms3[i] = 0, launches[i] = 0;
+    if (!on) return;
+    for (int i = 0; i < n; i++) {
+      (void)hipEventSynchronize(e1[i]);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0[i], e1[i]);
+      ms3[kinds[i]] += ms;
+      launches[kinds[i]]++;
+    }
+  }
+#else
+  void begin(bool, bool = false) {}
+  int start(int, emi_stream_t) { return -1; }
+  void stop(int, emi_stream_t) {}
+  void resolve(double *ms3, int *launches) {
+    for (int i = 0; i < 4; i++) ms3[i] = 0, launches[i] = 0;
+  }
+#endif
+};
+static PhaseTimer g_pt;
+
 // TRLTOM / TRMTOL (trltom_mod.F90:96-136, trmtol_mod.F90:101-141): one all-to-all-v of whole
 // row blocks of the Fourier buffers.  to_fft: Legendre-side -> FFT-side (inverse transform).
 // The hook always sees ALL tasks of the job (one entry per task, zero bytes for tasks that are not peers of this exchange): with
@@ -1830,7 +1913,12 @@ static int hook_alltoallv(const void *sb, const std::vector<long long> &psc, voi
   std::vector<long long> sc(NA, 0), sd(NA, 0), rc(NA, 0), rd(NA, 0);
   for (int k = 0; k < npeers; k++) sc[first + k * stride] = psc[k], rc[first + k * stride] = prc[k];
   for (int r = 1; r < NA; r++) sd[r] = sd[r - 1] + sc[r - 1], rd[r] = rd[r - 1] + rc[r - 1];
-  if (G.a2a(G.a2a_user, sb, sc.data(), sd.data(), rb, rc.data(), rd.data(), NA, (void *)st) != 0) EMI_FAIL(EMI_ERR_RUNTIME, "all-to-all-v hook failed");
+  const int iv = g_pt.start(3, st);
+  for (int r = 0; r < NA; r++)
+    if (g_pt.on && r != G.myproc_all - 1) g_pt.xbytes += (double)sc[r];
+  const int rc_hook = G.a2a(G.a2a_user, sb, sc.data(), sd.data(), rb, rc.data(), rd.data(), NA, (void *)st);
+  g_pt.stop(iv, st);
+  if (rc_hook != 0) EMI_FAIL(EMI_ERR_RUNTIME, "all-to-all-v hook failed");
   return 0;
 }
 static int exchange(Plan &P, bool to_fft, int ldf, emi_stream_t st, char *FBl, char *FBf) {
@@ -1970,56 +2058,6 @@ static int pick_batch(Plan &P, int nfields, int depth) {
   return (int)std::min(cap, std::max(64LL, want));
 }
 
-// Per-phase device timing with HIP event pairs recorded on the stream each kernel runs on.
-// Nothing is synchronised inside a transform call; emi_last_phase_ms() resolves the events lazily.
-struct PhaseTimer {
-  static const int MAXIV = 4096;
-  int n = 0, ncreated = 0;
-  bool on = false;
-  int kinds[MAXIV];
-#ifndef EMI_CPU_EMU
-  hipEvent_t e0[MAXIV], e1[MAXIV];
-  // keep: the intervals of earlier calls stay (accumulating mode, emi_set_profile(2)): nothing has to be resolved --
-  // i.e. no host synchronisation -- between the calls of a timed loop
-  void begin(bool on_, bool keep = false) {
-    on = on_;
-    if (!keep) n = 0;
-  }
-  int start(int kind, emi_stream_t s) {
-    if (!on || n >= MAXIV) return -1;
-    if (n >= ncreated) {  // events are created as the intervals are first used
-      (void)hipEventCreate(&e0[n]);
-      (void)hipEventCreate(&e1[n]);
-      ncreated = n + 1;
-    }
-    kinds[n] = kind;
-    (void)hipEventRecord(e0[n], s);
-    return n++;
-  }
-  void stop(int iv, emi_stream_t s) {
-    if (iv >= 0) (void)hipEventRecord(e1[iv], s);
-  }
-  void resolve(double *ms3, int *launches) {
-    for (int i = 0; i < 3; i++) ms3[i] = 0, launches[i] = 0;
-    if (!on) return;
-    for (int i = 0; i < n; i++) {
-      (void)hipEventSynchronize(e1[i]);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, e0[i], e1[i]);
-      ms3[kinds[i]] += ms;
-      launches[kinds[i]]++;
-    }
-  }
-#else
-  void begin(bool, bool = false) {}
-  int start(int, emi_stream_t) { return -1; }
-  void stop(int, emi_stream_t) {}
-  void resolve(double *ms3, int *launches) {
-    for (int i = 0; i < 3; i++) ms3[i] = 0, launches[i] = 0;
-  }
-#endif
-};
-static PhaseTimer g_pt;
 
 static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, int nfld, char *FB, int ldf, int nproma,
                        emi_stream_t st) {
@@ -2030,6 +2068,7 @@ static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, in
     const long long nblocks = (long long)fc.lats.size() * nchunk;
     FftLaunchDev lc{fc.d_lats, (int)fc.lats.size(), nchunk, nblocks, adj ? 1 : 0, fc.d_rows};
     const int nthr = fc.nthr;
+    if (g_pt.on) g_pt.fft_kernels++;  // every class that reaches this point launches exactly one kernel
     if (fc.gmem) {  // work arrays in global memory, one slice per workgroup
       const size_t needb = (size_t)nblocks * fc.gm_elems * 2 * P.esz;
       if (needb > P.cap_fftscr) {
@@ -2061,6 +2100,21 @@ static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, in
         EMI_LAUNCH_P(P.esz, k_fft_inv_mr, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);
       else
         EMI_LAUNCH_P(P.esz, k_fft_dir_mr, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);
+      continue;
+    }
+    if (fc.r16 && fc.split) {
+      switch (fc.r16) {
+#define EMI_R16S_LAUNCH(r_)                                                                                                                 \
+  case r_:                                                                                                                                  \
+    if (inverse)                                                                                                                            \
+      EMI_LAUNCH_P(P.esz, k_fft_inv_r16s<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);      \
+    else                                                                                                                                    \
+      EMI_LAUNCH_P(P.esz, k_fft_dir_r16s<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);            \
+    break;
+        EMI_R16S_LIST(EMI_R16S_LAUNCH)
+#undef EMI_R16S_LAUNCH
+        default: EMI_FAIL(EMI_ERR_RUNTIME, "internal: no k_fft_*_r16s kernel for R1 = %d", fc.r16);
+      }
       continue;
     }
     if (fc.r16) {
@@ -2212,6 +2266,13 @@ static int set_lds_attrs() {
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_r16<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_R16_LIST(EMI_R16_ATTR)
 #undef EMI_R16_ATTR
+#define EMI_R16S_ATTR(r_)                                                                                                                    \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_R16S_LIST(EMI_R16S_ATTR)
+#undef EMI_R16S_ATTR
   done = true;
   return 0;
 }
@@ -3131,20 +3192,44 @@ extern "C" int emi_work_model(int kresol, int nfields, double *leg, double *fft,
 }
 
 extern "C" int emi_last_phase_ms(double *ms3) {
-  int l[3];
-  g_pt.resolve(ms3, l);
+  int l[4];
+  double ms[4];
+  g_pt.resolve(ms, l);
+  for (int i = 0; i < 3; i++) ms3[i] = ms[i];
   return EMI_SUCCESS;
 }
 
 extern "C" int emi_last_phase_launches(int *l3) {
-  double ms[3];
-  g_pt.resolve(ms, l3);
+  double ms[4];
+  int l[4];
+  g_pt.resolve(ms, l);
+  for (int i = 0; i < 3; i++) l3[i] = l[i];
+  return EMI_SUCCESS;
+}
+
+// TRMTOL / TRLTOM (and, with V-sets, TRLTOG / TRGTOL) of the calls since emi_set_profile: device time between an event in front of
+// and one behind the all-to-all-v hook on the stream the hook was given, the number of exchanges, the bytes this task sent.
+extern "C" int emi_last_exchange(double *ms, int *calls, double *bytes_sent) {
+  double m4[4];
+  int l[4];
+  g_pt.resolve(m4, l);
+  if (ms) *ms = m4[3];
+  if (calls) *calls = l[3];
+  if (bytes_sent) *bytes_sent = g_pt.xbytes;
+  return EMI_SUCCESS;
+}
+
+// kernel launches of the FFT phases since emi_set_profile (one FTINV or FTDIR of one field batch launches one kernel per length class)
+extern "C" int emi_last_fft_launches(long long *kernels) {
+  if (kernels) *kernels = g_pt.fft_kernels;
   return EMI_SUCCESS;
 }
 
 extern "C" int emi_set_profile(int on) {
   G.profile = on;
   g_pt.n = 0;  // a new measurement starts here
+  g_pt.xbytes = 0;
+  g_pt.fft_kernels = 0;
   return EMI_SUCCESS;
 }
 

@@ -2755,6 +2755,234 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
   R16_STAMP_END(4);
 }
 
+// ==========================================================================================
+// Split register-resident kernels k_fft_dir_r16s<R1> / k_fft_inv_r16s<R1> (round 6): a row whose half-length sz = 2 q is too long for
+// ONE register-resident convolution (2 sz - 1 > 4096) as TWO of them, side by side in one workgroup.  One decimation step turns the
+// complex transform of length sz into the transforms of its even and odd points, each of length q, and each of those is a chirp-z
+// convolution of work length 256 R1 >= 2 q - 1 on the r16_conv chain above (NLOEN of an octahedral grid is a multiple of four, so q is
+// an integer; the host checks it):
+//     direct :  Z_k = E_k + w^k O_k,  Z_{k+q} = E_k - w^k O_k,  w = exp(-2 pi i / sz),  E / O = DFT_q of z_{2j} / z_{2j+1};
+//     inverse:  z_{2j} = IDFT_q(Z_k + Z_{k+q}),  z_{2j+1} = IDFT_q((Z_k - Z_{k+q}) conj w^k).
+// At TCo1279 these are the rows of 4100 .. 5136 points, which ran on the in-place LDS kernels k_fft_*_hot<23 | 24> (work lengths 4608 /
+// 5120: 2.0 vector instructions per work point, 28.6 ns per row and field) -- the largest block of the FFT phase (48 ms per pair).
+// Workgroup = 512 threads = two halves of four waves; half h runs the convolution of the points of parity h on its own LDS plane, with the
+// chirp, the filter spectrum and the twiddle tables of length q shared by both; the stages in front of and behind the convolutions
+// (FOURIER_IN / FOURIER_OUT, the decimation step) use all 512 threads and one spectrum image of sz complex numbers across both planes.
+// A first version ran the two convolutions one after the other in a 256-thread workgroup and held the other half of the row in
+// registers: 20 registers on top of a chain that needs 117 of the 128 -- 276 bytes of scratch, and the scratch reloads sit between the
+// barriers of the exchanges: 62 ms per direction against 24 ms for the kernels it was to replace; at three waves per SIMD (168 registers,
+// still 76 bytes of scratch) 45 ms (profiles/r6_fft_experiments.txt).  Two halves hold nothing.
+// Same arithmetic in every decomposition (one expression tree per stage): the gathered fields stay bit-identical.
+// Replaces FTDIR / FTINV for these rows (ftdir_mod.F90:67-84, ftinv_mod.F90:65-84; FFTW plans of tpm_fftw.F90:251-377).
+// ==========================================================================================
+// FSC + the pairing of FOURIER_IN for one pair (k, k2 = sz - k), as fin_pair but without the chirp (applied behind the decimation step here)
+EMI_DEVFN void fin_pair_nc(real2 xa, real2 xb, unsigned k, unsigned k2, real_t fa, real_t fb, real_t fs, real2 wk, real2 &zk, real2 &zk2) {
+  EMI_FP_STRICT();
+  const real_t ba = fb * (real_t)k, bb = fb * (real_t)k2;
+  const real2 ya = mk2((xa.x * fa - xa.y * ba) * fs, (xa.y * fa + xa.x * ba) * fs);
+  const real2 yb = mk2((xb.x * fa - xb.y * bb) * fs, (xb.y * fa + xb.x * bb) * fs);
+  const real_t s1x = ya.x + yb.x, s1y = ya.y - yb.y, d1x = ya.x - yb.x, d1y = ya.y + yb.y;  // s = ya + conj yb, d = ya - conj yb
+  const real_t px = wk.x * d1x - wk.y * d1y, py = wk.x * d1y + wk.y * d1x;                   // w d
+  zk = mk2(s1x - py, s1y + px);                                                                // s + i w d
+  const real_t s2x = yb.x + ya.x, s2y = yb.y - ya.y, d2x = yb.x - ya.x, d2y = yb.y + ya.y;
+  const real_t qx = -wk.x * d2x - wk.y * d2y, qy = -wk.x * d2y + wk.y * d2x;                  // (-conj w) d
+  zk2 = mk2(s2x - qy, s2y + qx);
+}
+
+#ifndef EMI_R16S_WAVES
+#define EMI_R16S_WAVES 4  // waves per SIMD the split kernels are compiled for: two 8-wave workgroups per CU
+#endif
+EMI_DEVFN constexpr int r16s_lds_bytes(int R1) { return 2 * R1 * R16_ROWP * 8 + 240 * 2 * (int)sizeof(real_t); }
+
+template <int R1>
+EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_dir_r16s(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+                                                      int nproma) {
+  constexpr int H = R1 / 2, S = 256 * R1, PLB = R1 * R16_ROWP * 8;
+  constexpr unsigned SZ2 = sizeof(real2);
+  static_assert(r16_threads(R1) == 256, "k_fft_dir_r16s: the convolution of a half on 256 threads (R1 <= 16)");
+  EMI_LDS_DECL;
+  char *lds = EMI_LDS_PTR;
+  real2 *tw2s = (real2 *)(lds + 2 * PLB), *zbuf = (real2 *)lds;
+  const unsigned tid = (unsigned)EMI_TID, h = tid >> 8, t = tid & 255u;  // half h: the points 2 l + h of the complex row
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = bid / Lc.nchunk;
+  const FftRowDev rw_ = Lc.rows[li];
+  const int f0 = bid - li * Lc.nchunk;  // one field per workgroup
+  const int n = rw_.n, sz = rw_.sz, nmen = rw_.nmen, q = sz >> 1;
+  const int fb0 = rw_.fb0;
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
+  const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
+  const EmiBuf b_ch = emi_buf((const real2 *)T.chirp + rw_.chirp_off, (unsigned)q * SZ2);  // exp(-i pi l^2 / q), l < q
+  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + rw_.ptw_off0, 7u * 256u * SZ2);
+  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + rw_.bhat_off, (unsigned)S * SZ2);
+  const EmiBuf b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
+  if (tid < 240u) tw2s[tid] = ((const real2 *)T.tw256)[tid];
+  const GridFld gf = flds[f0];
+  // stage 1 (TRGTOL local copy): z_{2l+h} = x_{4l+2h} + i x_{4l+2h+1}, times the chirp of length q; l = t + 256 a
+  real2 v[H];
+  {
+    const GridRow gr = grid_row(gf, rw_.gpoff, nproma);
+    const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
+    if (flat) {  // whole row inside one NPROMA block and 2-element aligned (uniform): the row is one buffer, its tail reads as zero
+      const EmiBuf b_in = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned l = t + 256u * a;
+        v[a] = cmul(emi_buf_ld<real2>(b_in, (2u * l + h) * SZ2, 0), emi_buf_ld<real2>(b_ch, l * SZ2, 0));
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned l = t + 256u * a, o = 4u * l + 2u * h;
+        real2 z = mk2(0, 0);
+        if (l < (unsigned)q) {
+          if (grid_pair_ok(gr, o)) {
+            z = *(const real2 *)grid_ptr(gr, o);
+          } else {
+            z.x = *grid_ptr(gr, o);
+            z.y = *grid_ptr(gr, o + 1);
+          }
+        }
+        v[a] = cmul(z, emi_buf_ld<real2>(b_ch, l * SZ2, 0));
+      }
+    }
+  }
+  // E = DFT_q(even points) in half 0, O = DFT_q(odd points) in half 1: convolution, then the chirp again (1 / S: in the filter table)
+  r16_conv<R1, 0>(v, t, b_tw, b_bh, lds + h * PLB, tw2s);
+  EMI_LDS_SYNC();  // every thread has read its last plane values
+  // spectrum image across both planes: E_i at slot i, O_i at slot q + i
+#pragma unroll
+  for (int a = 0; a < H; a++) {
+    const unsigned i = t + 256u * a;
+    if (i < (unsigned)q) zbuf[h * (unsigned)q + i] = cmul(v[a], emi_buf_ld<real2>(b_ch, i * SZ2, 0));
+  }
+  EMI_LDS_SYNC();
+  // decimation step in place: Z_i = E_i + w^i O_i -> slot i, Z_{i+q} = E_i - w^i O_i -> slot q + i  (w^i = exp(-2 pi i 2 i / n))
+  for (unsigned i = tid; i < (unsigned)q; i += 512u) {
+    const real2 e = zbuf[i], tw = cmul(emi_buf_ld<real2>(b_rtw, 2u * i * SZ2, 0), zbuf[(unsigned)q + i]);
+    zbuf[i] = cadd(e, tw);
+    zbuf[(unsigned)q + i] = csub(e, tw);
+  }
+  EMI_LDS_SYNC();
+  // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
+  const real_t sc = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(rw_.rw / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)rw_.racthe);
+  for (int k = (int)tid; k <= nmen; k += 512) {
+    const int kb = (k == 0) ? 0 : sz - k;
+    const real2 za = zbuf[k], zb = zbuf[kb];
+    const real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
+    const real2 tt = cmuli(cmul(rtw[k], d1));
+    *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * f0) = mk2((s1.x - tt.x) * sc, (s1.y - tt.y) * sc);
+  }
+}
+
+template <int R1>
+EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_inv_r16s(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+                                                      int ldf, int nproma) {
+  constexpr int H = R1 / 2, S = 256 * R1, PLB = R1 * R16_ROWP * 8;
+  constexpr unsigned SZ2 = sizeof(real2);
+  static_assert(r16_threads(R1) == 256, "k_fft_inv_r16s: the convolution of a half on 256 threads (R1 <= 16)");
+  EMI_LDS_DECL;
+  char *lds = EMI_LDS_PTR;
+  real2 *tw2s = (real2 *)(lds + 2 * PLB), *zbuf = (real2 *)lds;
+  const unsigned tid = (unsigned)EMI_TID, h = tid >> 8, t = tid & 255u;
+  const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
+  const int li = bid / Lc.nchunk;
+  const FftRowDev rw_ = Lc.rows[li];
+  const int f0 = bid - li * Lc.nchunk;
+  const int n = rw_.n, sz = rw_.sz, nmen = rw_.nmen, q = sz >> 1;
+  const real_t racthe = (real_t)rw_.racthe;
+  const real_t adjw = (real_t)(rw_.rw / (double)rw_.n);  // DIR_TRANSAD only (Lc.adj)
+  const int fb0 = rw_.fb0;
+  const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
+  const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
+  const real2 *chirp = (const real2 *)T.chirp + rw_.chirp_off;
+  const EmiBuf b_ch = emi_buf(chirp, (unsigned)q * SZ2);
+  const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + rw_.ptw_off0, 7u * 256u * SZ2);
+  const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + rw_.bhat_off, (unsigned)S * SZ2);
+  const EmiBuf b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
+  if (tid < 240u) tw2s[tid] = ((const real2 *)T.tw256)[tid];
+  const GridFld gf = flds[f0];
+  // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}) for the pairs (k, sz - k), k <= sz / 2 = q, all 512
+  // threads, to the spectrum image across both planes (k = 0 writes the unused slot sz).  As k_fft_inv_r16: branch-free, the Fourier-row
+  // loads of a thread first, rows past NMEN read as zero through the descriptor; the chirp comes behind the decimation step.
+  {
+    constexpr int TRIPS = R1 / 4 + 1;  // pairs k = tid + 512 a <= q <= S / 2 = 128 R1
+    const int npair = q + 1;
+    const unsigned rowb = (unsigned)ldf * (unsigned)sizeof(real_t);
+    const EmiBuf b_fb = emi_buf(FB + (unsigned long long)(unsigned)fb0 * (unsigned)ldf + 2 * gf.src, (unsigned)nmen * rowb + SZ2);
+    real_t fa, fb;
+    fin_factors(gf.mode, racthe, fa, fb);
+    const real_t fs = Lc.adj ? adjw : (real_t)1.0;
+    real2 xa[TRIPS], xb[TRIPS];
+#pragma unroll
+    for (int a = 0; a < TRIPS; a++) {
+      const unsigned k = tid + 512u * a, k2 = (unsigned)sz - k;
+      if (!frow) {  // (uniform) one descriptor: k > NMEN -- and the idle lanes k >= npair of the last trip -- read zero or anything in range
+        xa[a] = emi_buf_ld<real2>(b_fb, k * rowb, 0);
+        xb[a] = emi_buf_ld<real2>(b_fb, k2 * rowb, 0);
+      } else {      // rows through the exchange-order table: clamped look-up, then a select
+        const unsigned ka = k < (unsigned)nmen ? k : (unsigned)nmen, kb = k2 < (unsigned)nmen ? k2 : (unsigned)nmen;
+        const real2 va = fin_raw(FB, frow[ka], ldf, gf.src), vb = fin_raw(FB, frow[kb], ldf, gf.src);
+        xa[a] = k <= (unsigned)nmen ? va : mk2(0, 0);
+        xb[a] = k2 <= (unsigned)nmen ? vb : mk2(0, 0);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TRIPS; a++) {
+      const unsigned k = tid + 512u * a, k2 = (unsigned)sz - k;
+      if (k < (unsigned)npair) {
+        real2 zk, zk2;
+        fin_pair_nc(xa[a], xb[a], k, k2, fa, fb, fs, cconj(emi_buf_ld<real2>(b_rtw, k * SZ2, 0)), zk, zk2);
+        zbuf[k] = zk;
+        zbuf[k2] = zk2;
+      }
+    }
+  }
+  EMI_LDS_SYNC();
+  // decimation step + chirp into the register layout of r16_conv: half 0 the spectrum of the even points, (Z_l + Z_{l+q}) conj c_l, half 1 that of
+  // the odd points, (Z_l - Z_{l+q}) conj w^l conj c_l; l = t + 256 a
+  real2 v[H];
+#pragma unroll
+  for (int a = 0; a < H; a++) {
+    const unsigned l = t + 256u * a;
+    real2 x = mk2(0, 0);
+    if (l < (unsigned)q) {
+      const real2 z0 = zbuf[l], z1 = zbuf[(unsigned)q + l];
+      x = h ? cmulc(csub(z0, z1), emi_buf_ld<real2>(b_rtw, 2u * l * SZ2, 0)) : cadd(z0, z1);
+    }
+    v[a] = cmulc(x, emi_buf_ld<real2>(b_ch, l * SZ2, 0));  // l >= q: zero chirp
+  }
+  EMI_LDS_SYNC();  // the planes are free for the exchanges
+  r16_conv<R1, 1>(v, t, b_tw, b_bh, lds + h * PLB, tw2s);
+  // stage 3 (TRLTOG local copy): z_{2l+h} = conv_l conj(chirp_l) / S; x_{4l+2h} = Re, x_{4l+2h+1} = Im, straight from the registers
+  {
+    const GridRow gr = grid_row(gf, rw_.gpoff, nproma);
+    const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
+    if (flat) {
+      const EmiBuf b_out = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned l = t + 256u * a;
+        if (l < (unsigned)q) emi_buf_st<real2>(b_out, (2u * l + h) * SZ2, 0, cmulc(v[a], emi_buf_ld<real2>(b_ch, l * SZ2, 0)));
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < H; a++) {
+        const unsigned l = t + 256u * a, o = 4u * l + 2u * h;
+        if (l < (unsigned)q) {
+          const real2 z = cmulc(v[a], chirp[l]);
+          if (grid_pair_ok(gr, o)) {
+            *(real2 *)grid_ptr(gr, o) = z;
+          } else {
+            *grid_ptr(gr, o) = z.x;
+            *grid_ptr(gr, o + 1) = z.y;
+          }
+        }
+      }
+    }
+  }
+}
+
 #include "emi_mr_body.h"
 
 // ==========================================================================================

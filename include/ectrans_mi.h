@@ -310,6 +310,13 @@ int emi_work_model(int kresol, int nfields, double *legendre_flops_per_direction
 int emi_last_phase_ms(double *ms3);
 /* Number of Legendre/FFT/pack phase intervals (one per field batch) behind those sums.      */
 int emi_last_phase_launches(int *l3);
+/* The exchanges (TRMTOL / TRLTOM; with V-sets also TRLTOG / TRGTOL) of the calls since emi_set_profile: device time between an event in
+ * front of and one behind the all-to-all-v hook on the stream the hook was given (ms), their number, the bytes this task sent to
+ * its peers.  With the field batches of a call pipelined the exchange of one batch runs beside the kernels of its neighbours, so
+ * this time overlaps the phase times above (bench.py: exchange_ms_per_step, overlap_frac).  NULL pointers are skipped.          */
+int emi_last_exchange(double *ms, int *calls, double *bytes_sent);
+/* Kernel launches of the FFT phases since emi_set_profile (one FTINV / FTDIR of a field batch = one launch per length class). */
+int emi_last_fft_launches(long long *kernels);
 /* HIP-event phase timers (default: env EMI_PROFILE): 0 off; 1 per call (emi_last_phase_ms = the last call);
  * 2 accumulated over all calls since this emi_set_profile(2) (nothing is resolved, hence nothing
  * synchronises, between the calls of a timed loop; up to 4096 intervals).                   */

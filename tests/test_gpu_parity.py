@@ -282,6 +282,58 @@ def test_register_resident_fft_kernels_adjoints(et, dev, precision, monkeypatch)
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
+# first / last row length of every class of the split kernels: k_fft_*_r16s<10> 4100 .. 5120, <12> 5124 .. 6144, <16> 6148 .. 8192
+R16S_ROWS = [4100, 4612, 5116, 5120, 5124, 5136, 6144, 6148, 7000, 8188, 8192]
+
+
+@pytest.mark.parametrize("precision,nproma", [(8, None), (4, None), (8, 1000), (4, 4094)])
+def test_split_register_resident_fft_kernels_match_oracle(et, dev, precision, nproma, monkeypatch):
+    """k_fft_dir_r16s / k_fft_inv_r16s (round 6: a row of more than 4096 points as TWO register-resident chirp-z convolutions of half its
+    half-length joined by one decimation step -- at TCo1279 the rows of 4100 .. 5136 points that ran on k_fft_*_hot<23 | 24>) against the
+    oracle: every class boundary, whole rows and NPROMA-cut rows, winds and derivatives (all FSC modes), both precisions."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
+    monkeypatch.setenv("EMI_FFT_R16S", "1")  # (the fp64 library leaves these rows on the in-place LDS kernels by default)
+    from oracle.oracle import Oracle as O
+    e_inv, e_dir = run_case(et, O, dev, 15, R16S_ROWS + R16S_ROWS[::-1], 2, 3, dict(scders=True, uvder=True, vorgp=True, divgp=True), nproma, precision=precision)
+    tol = TOL if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
+def test_split_and_lds_fft_kernels_agree(et, dev, monkeypatch):
+    """EMI_FFT_R16S=0 sends the same rows through the in-place LDS kernels (one convolution of twice the work length): the same
+    transform to rounding, and really another kernel."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")
+    to, back = dev
+    nloen = np.array(R16S_ROWS + R16S_ROWS[::-1], dtype=np.int32)
+    rng = np.random.default_rng(6)
+    outs = []
+    for off in (False, True):
+        monkeypatch.setenv("EMI_FFT_R16S", "0" if off else "1")
+        r = et.setup_trans(15, len(nloen), nloen)
+        ns2, ng = et.trans_inq(r, "nspec2"), et.trans_inq(r, "ngptot")
+        if not outs:
+            sp = random_spectrum(rng, et.trans_inq(r, "nasm0"), 15, ns2, 3, False)
+        gp = to(np.zeros((1, 3, ng)))
+        et.inv_trans(r, pspscalar=to(sp), pgp=gp)
+        s2 = to(np.zeros((ns2, 3)))
+        et.dir_trans(r, pspscalar=s2, pgp=gp)
+        outs.append((back(gp).copy(), back(s2).copy()))
+        et.trans_release(r)
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-13 and rel_err(outs[0][1], outs[1][1]) < 1e-13
+    assert not np.array_equal(outs[0][0], outs[1][0])  # really two different kernels
+
+
+@pytest.mark.parametrize("precision", [8, 4])
+def test_split_register_resident_fft_kernels_adjoints(et, dev, precision, monkeypatch):
+    """INV_TRANSAD / DIR_TRANSAD on rows that take the split kernels (their `adj` scalings): the reference's dot-product identity
+    (tests/trans/test_invtrans_adjoint.F90: 2000 epsilon)."""
+    monkeypatch.setenv("EMI_FFT_MR", "0")
+    monkeypatch.setenv("EMI_FFT_R16S", "1")
+    e_inv, e_dir = adjoint_case(et, dev, 15, R16S_ROWS + R16S_ROWS[::-1], 1, 2, nproma=3000, precision=precision)
+    tol = 1e-12 if precision == 8 else 2e-4
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
 def test_device_legendre_setup_matches_host_and_oracle(et, monkeypatch):
     """k_legpol (SUPOLF on the GPU, fp contraction off) against the host recurrence bit for bit and
     against the oracle: a full grid F64 / T127 (1e+-100 rescaling near the poles) and TCo639 rows."""

@@ -242,6 +242,16 @@ def test_bench_multi_rank_launch(ngpus, nprtrv):
     assert out["config"]["nprtrv"] == nprtrv and out["config"]["nprtrw"] * nprtrv == ngpus
     assert out["config"]["exchange_preflight"] == "ok"
     assert out["spectral_norm_rel_error"] < 1e-12
+    # the keys that make the first run on an 8-GPU node self-explaining
+    assert out["exchange_ms_per_step"] > 0 and (out["overlap_frac"] is None or 0.0 <= out["overlap_frac"] <= 1.0)
+    rp = out["rank_phase_ms_per_step"]
+    for k in ("ms_per_step", "spectral_pack_unpack", "legendre_mfma", "fft", "exchange"):
+        assert 0 <= rp[k]["min"] <= rp[k]["mean"] <= rp[k]["max"], (k, rp[k])
+    assert rp["legendre_mfma"]["min"] > 0 and rp["fft"]["min"] > 0
+    ex = out["exchange"]
+    assert ex["exchanges_per_step"] >= 2 and ex["bytes_sent_per_rank_and_step"] > 0 and ex["links_used_per_rank"] == max(out["config"]["nprtrw"] - 1, 1)
+    assert ex["bytes_per_link_per_step"] > 0 and ex["achieved_GBps_per_link"] > 0
+    assert out["fft_launches_per_direction"] >= 1
 
 
 def test_native_rccl_transport():
