@@ -62,8 +62,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
       tch = *(const int *)(gt + (long long)(s + 1) * stride);  // every thread (no branch: the compiler must be able to count it)
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (V == 4 || V == 6) {
-      const double *q = g + (V == 6 ? 0 : (long long)s * stride);  // V6: the same lines every stage (cache hits)
+    if (V == 4 || V == 6 || V == 50 || V == 51) {
+      const double *q = g + ((V == 6 || V == 51) ? 0 : (long long)s * stride);  // V6 / V51: the same lines every stage (cache hits)
       ra0 = *(const d2 *)q, ra1 = *(const d2 *)(q + 512), rb0 = *(const d2 *)(q + 1024), rb1 = *(const d2 *)(q + 1536);
       rb2 = *(const d2 *)(q + 2048), rb3 = *(const d2 *)(q + 2560);
       __builtin_amdgcn_sched_barrier(0);  // keep the loads here, ahead of the MFMAs (the compiler would sink them)
@@ -78,6 +78,25 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         rb2 = *(const d2 *)(q + 2048), rb3 = *(const d2 *)(q + 2560);
       }
     }
+    if (V >= 50) {
+      // V50 / V51 (round 6): ONE parity per wave -- wave (parity wm, column half wn) owns 64 latitudes x 64 columns of its
+      // parity as 4 x 4 fragments: 8 LDS fragment reads per 16 MFMAs instead of 12 (2 x (2 + 4)); same loads, LDS stores, barriers and
+      // MFMA count per wave and stage as V4 / V6.  (The epilogue it would need -- the parities exchanged through LDS for north = S + A,
+      // south = S - A -- is not part of the loop and not modelled.)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int kk = 4 * ks + (l >> 4);
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = As[(wm * 8 + kk) * LDA + i * 16 + (l & 15)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = Bs[(wm * 8 + kk) * LDB + wn * 64 + j * 16 + (l & 15)];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i >> 1][i & 1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i >> 1][i & 1][j], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int p = 0; p < 2; p++)
 #pragma unroll
@@ -639,6 +658,17 @@ int main() {
     int one = 1;
     hipMemcpyToSymbol(HIP_SYMBOL(g_random_operands), &one, sizeof(int));
     printf("random operand values in LDS (V1-V3 read them; V4+ overwrite them with the zero-filled source)\n");
+  }
+  if (getenv("PROBE_ONE_PARITY")) {  // round 6: one parity per wave (V50 / V51) against the kernels' two-parity fragments (V4 / V6), twice each
+    for (int rep = 0; rep < 2; rep++) {
+      run<4>(out, src, "two parities per wave, HBM-jumping loads");
+      run<50>(out, src, "ONE parity per wave, HBM-jumping loads");
+      run<6>(out, src, "two parities per wave, cache hits");
+      run<51>(out, src, "ONE parity per wave, cache hits");
+      run<4>(out, src, "two parities per wave, short tiles", 20);
+      run<50>(out, src, "ONE parity per wave, short tiles", 20);
+    }
+    return 0;
   }
   if (getenv("PROBE_ONLY_W4")) {
     run<0>(out, src, "MFMAs only");
