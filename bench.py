@@ -338,20 +338,21 @@ def recorded_fft_bound(N, nlev, nfld, esz, world, source_hash):
     when the counter file was taken on this very build of the library (same source hash)."""
     import glob
     import json
-    if (N, nlev, nfld, esz, world) != (1279, 137, 10, 8, 1):
+    if (N, nlev, nfld, world) != (1279, 137, 10, 1):
         return None
     here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_fft.json")), reverse=True):
+    pat = "*_pmc_fft.json" if esz == 8 else "*_pmc_fft_fp32.json"  # tools/pmc_fft.sh TAG 4 writes the fp32 library's table beside the fp64 one
+    for f in sorted(glob.glob(os.path.join(here, "profiles", pat)), reverse=True):
         try:
             js = json.load(open(f))
         except Exception:
             continue
-        if js.get("source_hash") == source_hash:
-            return {"bound": "SIMD instruction issue (fp64 vector ALU + LDS + other), chip clock lowered under this load",
+        if js.get("source_hash") == source_hash and int(js.get("precision", 8)) == esz:
+            return {"bound": "SIMD instruction issue (fp%d vector ALU + LDS + other), chip clock lowered under this load" % (8 * esz),
                     "simd_issue_share": js["simd_issue_share"], "wave_life_share": js["wave_life_share"],
                     "nonfp_valu_share": js.get("nonfp_valu_share"), "nonfp_valu_share_six_heaviest": js.get("nonfp_valu_share_six_heaviest"), "fft_ms_per_pair_under_profiler": js["fft_ms_per_pair"],
                     "source": os.path.basename(f)}
-    return {"bound": None, "source": "no profiles/*_pmc_fft.json for this build (source hash %s): re-run tools/pmc_fft.sh" % source_hash}
+    return {"bound": None, "source": "no profiles/%s for this build (source hash %s): re-run tools/pmc_fft.sh" % (pat, source_hash)}
 
 
 def recorded_traffic(N, nlev, nfld, esz, world, source_hash):
@@ -359,21 +360,26 @@ def recorded_traffic(N, nlev, nfld, esz, world, source_hash):
     tools/collect_profiles.sh on this exact workload; rocprofv3 cannot run inside the timed region).  Reported only for
     the workload AND the library build the counters were taken on (the file is stamped with ectrans_amd.source_hash());
     a stale file gives null and says so."""
-    if (N, nlev, nfld, esz, world) != (1279, 137, 10, 8, 1):
-        return None, "counters are collected on the default workload only"
+    if (N, nlev, nfld, world) != (1279, 137, 10, 1):
+        return None, "counters are collected on the default workload (TCo1279 137L x 10, one GPU) only"
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    pat = "*_pmc_traffic.json" if esz == 8 else "*_pmc_traffic_fp32.json"  # EMI_COLLECT_PRECISION=4 bash tools/collect_profiles.sh TAG
+    ns = "emi_f64::" if esz == 8 else "emi_f32::"
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pat)))
     for f in reversed(files):
         try:
             j = json.load(open(f))
             if j.get("source_hash") != source_hash:
                 continue
             k = j["kernels"]
-            vals = [k[n]["hbm_bytes_per_launch"] for n in ("emi_f64::k_leg_inv", "emi_f64::k_leg_dir")]
-            return sum(vals) / len(vals), os.path.basename(f)
+            vals = [k[ns + n]["hbm_bytes_per_launch"] for n in ("k_leg_inv", "k_leg_dir")]
+            note = os.path.basename(f)
+            if esz == 4:  # the guide calibrates FETCH_SIZE x 2 for 16-byte-per-lane loads only; the fp32 k_leg_dir loads 8 bytes per lane
+                note += " (fp32 k_leg_dir loads 8 B per lane: its read bytes = 2 x FETCH_SIZE are an upper bound, FETCH_SIZE itself the lower one)"
+            return sum(vals) / len(vals), note
         except (KeyError, ValueError, OSError):
             continue
-    return None, "no profiles/*_pmc_traffic.json for this build (source hash %s): re-run tools/collect_profiles.sh" % source_hash
+    return None, "no profiles/%s for this build (source hash %s): re-run tools/collect_profiles.sh" % (pat, source_hash)
 
 
 def exchange_report(rs, world, nprtrw, nprtrv, steps):

@@ -120,6 +120,17 @@ def main():
                     max(rel_err(back(s3o)[v], sr3[gidx][:, 1 + v * nlev + l3]) for v in range(nvar)))
     if own2:
         e_m2d = max(e_m2d, rel_err(back(s2o), sr3[gidx][:, 0:1]))
+    # ---- a PGP3A with room for one variable more than PSPSC3A names: the reference aborts (`IUBOUND(3) /= IF_SC3A_G3`, inv_trans.F90:557-561,
+    # dir_trans.F90:451-455) and so must every task here, together and before any exchange (only checked when every V-set owns a level: a
+    # task without PSPSC3A takes the count from the grid array and has nothing to compare it with, as with the reference's zero-level array)
+    if nlev >= nprv:
+        big = to(np.zeros((1, nvar + 1, nlev, ng)))
+        for fn, kw in ((et.inv_trans, dict(pspsc3a=sp3a)), (et.dir_trans, dict(pspsc3a=s3o))):
+            try:
+                fn(r, pgp3a=big, kvsetsc3a=kv3, **kw)
+                raise SystemExit("rank %d: a PGP3A with a spare variable was accepted" % rank)
+            except RuntimeError as e:
+                assert "THIRD DIMENSION OF PGP3A INCONSISTENT" in str(e), str(e)
     # ---- a call in which only the last V-set holds a field (the benchmark's surface field on its own): the other V-sets make no
     # TRMTOL / TRLTOM exchange at all -- transports must not need them (point-to-point blocks, no collective over all tasks)
     gp1 = to(np.zeros((1, 1, ng)))

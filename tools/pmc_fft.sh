@@ -1,7 +1,7 @@
 # SQ counters of the FFT kernels of one TCo1279 pair:  bash tools/pmc_fft.sh TAG [PRECISION = 8 | 4]   (through gpurun; three counter passes, kernel trace only)
 TAG=${1:-hot}
 PREC=${2:-8}
-FP=F64; [ "$PREC" = 4 ] && FP=F32
+FP=F64; SFX=""; [ "$PREC" = 4 ] && FP=F32 && SFX=_fp32
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${TAG}_pmc1 -- python3 tools/gpu_perf.py 1279 137 10 1 $PREC > gpurun_out/${TAG}_pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/${TAG}_pmc2 -- python3 tools/gpu_perf.py 1279 137 10 1 $PREC > gpurun_out/${TAG}_pmc2.log 2>&1
@@ -25,7 +25,7 @@ for f in glob.glob("gpurun_out/${TAG}_pmc1/**/*kernel_trace.csv",recursive=True)
     for r in csv.DictReader(open(f)):
         m=re.search(r'(k_fft_\w+(<\d+>)?)',r["Kernel_Name"])
         if m: dur[m.group(1)]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
-with open("gpurun_out/${TAG}_pmc_fft.txt","w") as fh:
+with open("gpurun_out/${TAG}_pmc_fft${SFX}.txt","w") as fh:
     fh.write("kernel ms clkGHz valu/wave lds/wave vmem/wave | share of SIMD time: valu lds any | wave life: wait_any wait_inst | lds conflict | VALU: fma add mul (${FP}; a packed fp32 instruction counts once) int32 int64 cvt per wave, non-fp share\n")
     for k in sorted(acc, key=lambda k:-dur[k]):
         a=acc[k]
@@ -39,7 +39,7 @@ with open("gpurun_out/${TAG}_pmc_fft.txt","w") as fh:
             a["SQ_WAIT_ANY"]/a["SQ_WAVE_CYCLES"],a["SQ_WAIT_INST_ANY"]/a["SQ_WAVE_CYCLES"],
             a["SQ_LDS_BANK_CONFLICT"]/max(1.0,a["SQ_LDS_IDX_ACTIVE"]),
             b["SQ_INSTS_VALU_FMA_${FP}"]/w3,b["SQ_INSTS_VALU_ADD_${FP}"]/w3,b["SQ_INSTS_VALU_MUL_${FP}"]/w3,b["SQ_INSTS_VALU_INT32"]/w3,b["SQ_INSTS_VALU_INT64"]/w3,b["SQ_INSTS_VALU_CVT"]/w3,nonfp(k)))
-print(open("gpurun_out/${TAG}_pmc_fft.txt").read())
+print(open("gpurun_out/${TAG}_pmc_fft${SFX}.txt").read())
 # machine-readable summary for bench.py's `fft_bound` block: duration-weighted issue shares of all FFT launches of one pair,
 # stamped with the hash of the library sources (bench.py quotes it only for the build it was taken on)
 import json, sys
@@ -58,6 +58,6 @@ js = {"source_hash": ectrans_amd.source_hash(), "workload": "tools/gpu_perf.py 1
                       "nonfp_valu_share": nonfp(k),
                       "lds_bank_conflict_share": acc[k]["SQ_LDS_BANK_CONFLICT"] / max(1.0, acc[k]["SQ_LDS_IDX_ACTIVE"])} for k in dur if acc[k].get("SQ_WAVES")},
       "method": "rocprofv3 --pmc, two passes (SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_BUSY_CYCLES; SQ_INSTS_* / SQ_LDS_*), kernel trace only; shares = counter (quad-cycles, summed over SIMDs) / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs / 4), weighted by launch duration"}
-json.dump(js, open("gpurun_out/${TAG}_pmc_fft.json", "w"), indent=1)
+json.dump(js, open("gpurun_out/${TAG}_pmc_fft${SFX}.json", "w"), indent=1)
 print(json.dumps({k: js[k] for k in ("fft_ms_per_pair", "simd_issue_share", "wave_life_share", "nonfp_valu_share", "nonfp_valu_share_six_heaviest", "source_hash")}))
 PY
