@@ -231,7 +231,7 @@ struct FftClass {  // one launch group of the FFT kernels: latitudes sharing a w
   int nthr = 0, fbk = 0;
   int hot = 0;  // > 0: specialised kernel k_fft_*_hot<hot> (EMI_HOT_PLAN_LIST)
   int r16 = 0;  // > 0: register-resident kernel k_fft_*_r16<r16> (EMI_R16_LIST)
-  int split = 0;  // 2: k_fft_*_r16s<r16> (EMI_R16S_LIST): the row as two convolutions of half its half-length
+  int split = 0;  // 2: k_fft_*_r16p<r16> (EMI_R16S_LIST): the row as two convolutions of half its half-length
   int mr = 0;   // 1: direct mixed-radix kernels k_fft_*_mr (EMI_MR_RADICES)
   int gmem = 0;  // 1: the work array does not fit the LDS; k_fft_*_gm on a global scratch buffer (elems: complex numbers per workgroup)
   long long gm_elems = 0;
@@ -561,14 +561,11 @@ static int build_fft_plans(Plan &P) {
       if (need > 1536)  // shorter rows: in-place kernels with several fields per workgroup
         for (int r : r1s)
           if (!pl.r16 && 256 * r >= need) pl.r16 = r;
-      // Split kernels (k_fft_*_r16s<R1>, round 6): a row too long for one register-resident convolution whose half-length is even runs as
-      // two convolutions of length sz / 2, side by side in one 8-wave workgroup, joined by one decimation step.  On by default in the fp32
-      // library only: there they beat the 1024-thread in-place LDS kernels of the long rows by 21 - 23 % (TCo2559: work lengths 6144 / 7680 /
-      // 8192, -45 ms per pair); in fp64 the exchanges move one real plane at a time (twice the workgroup barriers, each now over eight
-      // waves) and the same rows take 10 % LONGER than on k_fft_*_hot<23 | 24> (TCo1279: 54.4 against 49.6 ms per pair;
-      // profiles/r6_fft_experiments.txt).  EMI_FFT_R16S=1 / 0 forces them on / off (tests, A/B runs).
-      const char *e_r16s = getenv("EMI_FFT_R16S");
-      const bool use_r16s = e_r16s ? atoi(e_r16s) != 0 : (P.esz == 4);
+      // Split kernels (k_fft_*_r16p<R1>, round 6): a row too long for one register-resident convolution whose half-length is even runs as
+      // two convolutions of length sz / 2, one after the other, joined by one decimation step (emi_kernels_body.h).  TCo1279 fp64: 44.6
+      // against 48.2 ms per pair for the rows of k_fft_*_hot<23 | 24>; TCo2559 fp32: the rows of 4100 .. 8192 points 192 against 249 ms per
+      // pair (profiles/r6_fft_experiments.txt).  EMI_FFT_R16S=0: off (tests and A/B runs: the same rows through the in-place LDS kernels).
+      const bool use_r16s = !(getenv("EMI_FFT_R16S") && atoi(getenv("EMI_FFT_R16S")) == 0);
       if (!pl.r16 && need > 4096 && pl.sz % 2 == 0 && use_r16s) {
         static const int r1ss[] = {
 #define EMI_R16S_ROW(r_) r_,
@@ -665,7 +662,7 @@ static int build_fft_plans(Plan &P) {
     n_rtw += pl.sz + 1;
     if (pl.blue) {
       pl.chirp_off = (int)n_chirp;
-      n_chirp += pl.split ? pl.sz / pl.split : pl.sz;
+      n_chirp += pl.split ? pl.sz / 2 : pl.sz;
       pl.bhat_off = (int)n_bhat;
       n_bhat += pl.S;
     }
@@ -716,7 +713,6 @@ static int build_fft_plans(Plan &P) {
       fbk = 1;
       pl.fbk = 1;
       nthr = 16 * pl.r16 > 256 ? roundup(16 * pl.r16, 64) : 256;
-      if (pl.split) nthr = 512;  // k_fft_*_r16s: two halves of 256 threads, one convolution each
     }
     if (pl.mr) {
       hot = 0;
@@ -810,7 +806,7 @@ static int build_fft_plans(Plan &P) {
     }
     if (!pl.blue) return;
     d2 *c = chirp.data() + pl.chirp_off;
-    const int csz = pl.split ? pl.sz / pl.split : pl.sz;  // length of the chirp-z transform(s) of the row: the split kernels run two of sz / 2
+    const int csz = pl.split ? pl.sz / 2 : pl.sz;  // length of the chirp-z transform(s) of the row: the split kernels run two of sz / 2
     for (int k = 0; k < csz; k++) {
       long long k2 = ((long long)k * k) % (2LL * csz);
       double a = M_PI * (double)k2 / (double)csz;
@@ -855,7 +851,7 @@ static int build_fft_plans(Plan &P) {
     else if (fc.mr)
       fc.lds = std::max(fc.lds, (size_t)pl.fbk * pl.fac[0] * ((pl.fac[1] * pl.fac[2]) | 1) * 2 * P.esz);
     else if (fc.r16)
-      fc.lds = (size_t)(fc.split ? 2 : 1) * fc.r16 * 272 * 8 + 240 * 2 * P.esz;
+      fc.lds = (size_t)fc.r16 * 272 * 8 + (size_t)((fc.split ? 128 * fc.r16 : 0) + 240) * 2 * P.esz;  // plane (+ the parked half of k_fft_*_r16p) + small twiddles
     else
       fc.lds = std::max(fc.lds, (size_t)pl.fbk * FFT_LDS_ELEMS(pl.S) * 2 * P.esz);
   }
@@ -2104,16 +2100,16 @@ static int launch_fft(Plan &P, bool inverse, bool adj, const GridFld *d_flds, in
     }
     if (fc.r16 && fc.split) {
       switch (fc.r16) {
-#define EMI_R16S_LAUNCH(r_)                                                                                                                 \
+#define EMI_R16P_LAUNCH(r_)                                                                                                                 \
   case r_:                                                                                                                                  \
     if (inverse)                                                                                                                            \
-      EMI_LAUNCH_P(P.esz, k_fft_inv_r16s<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);      \
+      EMI_LAUNCH_P(P.esz, k_fft_inv_r16p<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (const RT *)FB, ldf, nproma);      \
     else                                                                                                                                    \
-      EMI_LAUNCH_P(P.esz, k_fft_dir_r16s<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);            \
+      EMI_LAUNCH_P(P.esz, k_fft_dir_r16p<r_>, nblocks, nthr, fc.lds, st, P.g, P.ftab, lc, d_flds, nfld, (RT *)FB, ldf, nproma);            \
     break;
-        EMI_R16S_LIST(EMI_R16S_LAUNCH)
-#undef EMI_R16S_LAUNCH
-        default: EMI_FAIL(EMI_ERR_RUNTIME, "internal: no k_fft_*_r16s kernel for R1 = %d", fc.r16);
+        EMI_R16S_LIST(EMI_R16P_LAUNCH)
+#undef EMI_R16P_LAUNCH
+        default: EMI_FAIL(EMI_ERR_RUNTIME, "internal: no k_fft_*_r16p kernel for R1 = %d", fc.r16);
       }
       continue;
     }
@@ -2266,13 +2262,13 @@ static int set_lds_attrs() {
   EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_r16<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EMI_R16_LIST(EMI_R16_ATTR)
 #undef EMI_R16_ATTR
-#define EMI_R16S_ATTR(r_)                                                                                                                    \
-  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_r16s<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  EMI_R16S_LIST(EMI_R16S_ATTR)
-#undef EMI_R16S_ATTR
+#define EMI_R16P_ATTR(r_)                                                                                                                    \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_inv_r16p<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f64::k_fft_dir_r16p<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_inv_r16p<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  EMI_CHECK(hipFuncSetAttribute((const void *)emi_f32::k_fft_dir_r16p<r_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EMI_R16S_LIST(EMI_R16P_ATTR)
+#undef EMI_R16P_ATTR
   done = true;
   return 0;
 }

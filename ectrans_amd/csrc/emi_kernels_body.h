@@ -2756,22 +2756,26 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T,
 }
 
 // ==========================================================================================
-// Split register-resident kernels k_fft_dir_r16s<R1> / k_fft_inv_r16s<R1> (round 6): a row whose half-length sz = 2 q is too long for
-// ONE register-resident convolution (2 sz - 1 > 4096) as TWO of them, side by side in one workgroup.  One decimation step turns the
-// complex transform of length sz into the transforms of its even and odd points, each of length q, and each of those is a chirp-z
-// convolution of work length 256 R1 >= 2 q - 1 on the r16_conv chain above (NLOEN of an octahedral grid is a multiple of four, so q is
-// an integer; the host checks it):
+// Split register-resident kernels k_fft_dir_r16p<R1> / k_fft_inv_r16p<R1> (round 6): a row whose half-length sz = 2 q is too long for ONE
+// register-resident convolution (2 sz - 1 > 4096) as TWO of them.  One decimation step turns the complex transform of length sz into the
+// transforms of its even and odd points, each of length q, and each of those is a chirp-z convolution of work length 256 R1 >= 2 q - 1 on
+// the r16_conv chain above (NLOEN of an octahedral grid is a multiple of four, so q is an integer; the host checks it):
 //     direct :  Z_k = E_k + w^k O_k,  Z_{k+q} = E_k - w^k O_k,  w = exp(-2 pi i / sz),  E / O = DFT_q of z_{2j} / z_{2j+1};
 //     inverse:  z_{2j} = IDFT_q(Z_k + Z_{k+q}),  z_{2j+1} = IDFT_q((Z_k - Z_{k+q}) conj w^k).
 // At TCo1279 these are the rows of 4100 .. 5136 points, which ran on the in-place LDS kernels k_fft_*_hot<23 | 24> (work lengths 4608 /
-// 5120: 2.0 vector instructions per work point, 28.6 ns per row and field) -- the largest block of the FFT phase (48 ms per pair).
-// Workgroup = 512 threads = two halves of four waves; half h runs the convolution of the points of parity h on its own LDS plane, with the
-// chirp, the filter spectrum and the twiddle tables of length q shared by both; the stages in front of and behind the convolutions
-// (FOURIER_IN / FOURIER_OUT, the decimation step) use all 512 threads and one spectrum image of sz complex numbers across both planes.
-// A first version ran the two convolutions one after the other in a 256-thread workgroup and held the other half of the row in
-// registers: 20 registers on top of a chain that needs 117 of the 128 -- 276 bytes of scratch, and the scratch reloads sit between the
-// barriers of the exchanges: 62 ms per direction against 24 ms for the kernels it was to replace; at three waves per SIMD (168 registers,
-// still 76 bytes of scratch) 45 ms (profiles/r6_fft_experiments.txt).  Two halves hold nothing.
+// 5120: 2.0 vector instructions per work point, 28.6 ns per row and field) -- the largest block of the FFT phase (48 ms per pair); at TCo2559
+// (fp32) the rows of 4100 .. 8192 points (work lengths 4608 .. 8192 of the 1024-thread in-place kernels).  The grid row is read / written
+// once as 32 contiguous bytes per lane (x_{4l} .. x_{4l+3} = z_{2l}, z_{2l+1}); the chirp, the filter spectrum and the twiddle tables are
+// those of length q for both halves.
+// The two convolutions run ONE AFTER THE OTHER on a 256-thread workgroup, and the half of the row that is not being convolved is PARKED in a
+// second LDS region -- every thread parks and fetches its own slots, so no barrier is needed for it.  The chain keeps its 117 - 120 registers
+// (fp64: 152 - 166 with the stage around it, three waves per SIMD; fp32: 114 - 124, four), nothing spills, and the exchanges couple four waves
+// as in k_fft_*_r16.  LDS: plane + q complex numbers + the small twiddles (46 KB in fp64 at R1 = 10: three workgroups per CU instead of
+// four; 34 KB in fp32: four).  Two earlier forms, both parity-green, both measured (profiles/r6_fft_experiments.txt): the other half held in
+// REGISTERS (20 on top of a chain that needs 117 of 128: 264 - 292 bytes of scratch, reloaded between the exchange barriers -- slower than the
+// kernels it was to replace), and two 4-wave halves side by side in a 512-thread workgroup, one convolution each (no scratch, but every
+// barrier of the exchanges couples eight waves and fp64 has three times as many of them: fp64 54.4 against 49.6 ms per pair for these
+// rows on the in-place kernels; this form: 44.6).
 // Same arithmetic in every decomposition (one expression tree per stage): the gathered fields stay bit-identical.
 // Replaces FTDIR / FTINV for these rows (ftdir_mod.F90:67-84, ftinv_mod.F90:65-84; FFTW plans of tpm_fftw.F90:251-377).
 // ==========================================================================================
@@ -2789,21 +2793,21 @@ EMI_DEVFN void fin_pair_nc(real2 xa, real2 xb, unsigned k, unsigned k2, real_t f
   zk2 = mk2(s2x - qy, s2y + qx);
 }
 
-#ifndef EMI_R16S_WAVES
-#define EMI_R16S_WAVES 4  // waves per SIMD the split kernels are compiled for: two 8-wave workgroups per CU
+EMI_DEVFN constexpr int r16p_lds_bytes(int R1) { return R1 * R16_ROWP * 8 + 128 * R1 * (int)sizeof(real2) + 240 * (int)sizeof(real2); }
+#ifndef EMI_R16P_WAVES_F32
+#define EMI_R16P_WAVES_F32 4  // fp32: 114 - 124 registers and 34 KB of LDS -- four workgroups per CU; fp64: 152 - 166 registers, 46 KB -- three
 #endif
-EMI_DEVFN constexpr int r16s_lds_bytes(int R1) { return 2 * R1 * R16_ROWP * 8 + 240 * 2 * (int)sizeof(real_t); }
+#define EMI_R16P_WAVES (sizeof(real_t) == 4 ? EMI_R16P_WAVES_F32 : 3)
 
 template <int R1>
-EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_dir_r16s(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
-                                                      int nproma) {
+EMI_KERNEL_LB2(256, EMI_R16P_WAVES) void k_fft_dir_r16p(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf, int nproma) {
   constexpr int H = R1 / 2, S = 256 * R1, PLB = R1 * R16_ROWP * 8;
   constexpr unsigned SZ2 = sizeof(real2);
-  static_assert(r16_threads(R1) == 256, "k_fft_dir_r16s: the convolution of a half on 256 threads (R1 <= 16)");
+  static_assert(r16_threads(R1) == 256, "k_fft_dir_r16p: 256 threads (R1 <= 16)");
   EMI_LDS_DECL;
   char *lds = EMI_LDS_PTR;
-  real2 *tw2s = (real2 *)(lds + 2 * PLB), *zbuf = (real2 *)lds;
-  const unsigned tid = (unsigned)EMI_TID, h = tid >> 8, t = tid & 255u;  // half h: the points 2 l + h of the complex row
+  real2 *zbuf = (real2 *)lds, *park = (real2 *)(lds + PLB), *tw2s = park + 128 * R1;
+  const unsigned t = (unsigned)EMI_TID;
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
   const FftRowDev rw_ = Lc.rows[li];
@@ -2812,63 +2816,79 @@ EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_dir_r16s(EmiGeomDev g, FftTabDev 
   const int fb0 = rw_.fb0;
   const int *frow = g.fftrow ? g.fftrow + fb0 : nullptr;
   const real2 *rtw = (const real2 *)T.rtw + rw_.rtw_off;
-  const EmiBuf b_ch = emi_buf((const real2 *)T.chirp + rw_.chirp_off, (unsigned)q * SZ2);  // exp(-i pi l^2 / q), l < q
+  const EmiBuf b_ch = emi_buf((const real2 *)T.chirp + rw_.chirp_off, (unsigned)q * SZ2);
   const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + rw_.ptw_off0, 7u * 256u * SZ2);
   const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + rw_.bhat_off, (unsigned)S * SZ2);
   const EmiBuf b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
-  if (tid < 240u) tw2s[tid] = ((const real2 *)T.tw256)[tid];
+  if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
-  // stage 1 (TRGTOL local copy): z_{2l+h} = x_{4l+2h} + i x_{4l+2h+1}, times the chirp of length q; l = t + 256 a
+  // stage 1: z_{2l} = x_{4l} + i x_{4l+1} (kept) and z_{2l+1} = x_{4l+2} + i x_{4l+3} (parked), both times the chirp of length q; l = t + 256 a
   real2 v[H];
   {
     const GridRow gr = grid_row(gf, rw_.gpoff, nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
-    if (flat) {  // whole row inside one NPROMA block and 2-element aligned (uniform): the row is one buffer, its tail reads as zero
+    if (flat) {
       const EmiBuf b_in = emi_buf(gr.p0 + gr.rem0, (unsigned)n * (unsigned)sizeof(real_t));
 #pragma unroll
       for (int a = 0; a < H; a++) {
         const unsigned l = t + 256u * a;
-        v[a] = cmul(emi_buf_ld<real2>(b_in, (2u * l + h) * SZ2, 0), emi_buf_ld<real2>(b_ch, l * SZ2, 0));
+        const real2 c = emi_buf_ld<real2>(b_ch, l * SZ2, 0);
+        v[a] = cmul(emi_buf_ld<real2>(b_in, 2u * l * SZ2, 0), c);
+        park[l] = cmul(emi_buf_ld<real2>(b_in, (2u * l + 1u) * SZ2, 0), c);
       }
     } else {
 #pragma unroll
       for (int a = 0; a < H; a++) {
-        const unsigned l = t + 256u * a, o = 4u * l + 2u * h;
-        real2 z = mk2(0, 0);
+        const unsigned l = t + 256u * a;
+        real2 ze = mk2(0, 0), zo = mk2(0, 0);
         if (l < (unsigned)q) {
-          if (grid_pair_ok(gr, o)) {
-            z = *(const real2 *)grid_ptr(gr, o);
+          if (grid_pair_ok(gr, 4u * l)) {
+            ze = *(const real2 *)grid_ptr(gr, 4u * l);
           } else {
-            z.x = *grid_ptr(gr, o);
-            z.y = *grid_ptr(gr, o + 1);
+            ze.x = *grid_ptr(gr, 4u * l);
+            ze.y = *grid_ptr(gr, 4u * l + 1);
+          }
+          if (grid_pair_ok(gr, 4u * l + 2)) {
+            zo = *(const real2 *)grid_ptr(gr, 4u * l + 2);
+          } else {
+            zo.x = *grid_ptr(gr, 4u * l + 2);
+            zo.y = *grid_ptr(gr, 4u * l + 3);
           }
         }
-        v[a] = cmul(z, emi_buf_ld<real2>(b_ch, l * SZ2, 0));
+        const real2 c = emi_buf_ld<real2>(b_ch, l * SZ2, 0);
+        v[a] = cmul(ze, c);
+        park[l] = cmul(zo, c);
       }
     }
   }
-  // E = DFT_q(even points) in half 0, O = DFT_q(odd points) in half 1: convolution, then the chirp again (1 / S: in the filter table)
-  r16_conv<R1, 0>(v, t, b_tw, b_bh, lds + h * PLB, tw2s);
+  r16_conv<R1, 0>(v, t, b_tw, b_bh, lds, tw2s);
+  // E_l = conv_l chirp_l takes the slot of the odd point it replaces (same thread, same slot: no barrier)
+#pragma unroll
+  for (int a = 0; a < H; a++) {
+    const unsigned l = t + 256u * a;
+    const real2 e = cmul(v[a], emi_buf_ld<real2>(b_ch, l * SZ2, 0));
+    v[a] = park[l];
+    park[l] = e;
+  }
+  r16_conv<R1, 0>(v, t, b_tw, b_bh, lds, tw2s);
   EMI_LDS_SYNC();  // every thread has read its last plane values
-  // spectrum image across both planes: E_i at slot i, O_i at slot q + i
+  // Z_i = E_i + w^i O_i -> park slot i, Z_{i+q} = E_i - w^i O_i -> plane slot i (both are read by other threads below)
 #pragma unroll
   for (int a = 0; a < H; a++) {
     const unsigned i = t + 256u * a;
-    if (i < (unsigned)q) zbuf[h * (unsigned)q + i] = cmul(v[a], emi_buf_ld<real2>(b_ch, i * SZ2, 0));
+    if (i < (unsigned)q) {
+      const real2 o = cmul(v[a], emi_buf_ld<real2>(b_ch, i * SZ2, 0));
+      const real2 tw = cmul(emi_buf_ld<real2>(b_rtw, 2u * i * SZ2, 0), o), e = park[i];
+      park[i] = cadd(e, tw);
+      zbuf[i] = csub(e, tw);
+    }
   }
   EMI_LDS_SYNC();
-  // decimation step in place: Z_i = E_i + w^i O_i -> slot i, Z_{i+q} = E_i - w^i O_i -> slot q + i  (w^i = exp(-2 pi i 2 i / n))
-  for (unsigned i = tid; i < (unsigned)q; i += 512u) {
-    const real2 e = zbuf[i], tw = cmul(emi_buf_ld<real2>(b_rtw, 2u * i * SZ2, 0), zbuf[(unsigned)q + i]);
-    zbuf[i] = cadd(e, tw);
-    zbuf[(unsigned)q + i] = csub(e, tw);
-  }
-  EMI_LDS_SYNC();
-  // stage 3 (FOURIER_OUT): X_k = 1/2 [ (Z_k + conj Z_{sz-k}) - i exp(-2 pi i k/n) (Z_k - conj Z_{sz-k}) ], k <= NMEN
+  // stage 3 (FOURIER_OUT): Z_k = park[k] (k < q) | zbuf[k - q] (k >= q)
   const real_t sc = (real_t)0.5 * (Lc.adj ? (real_t)1.0 : (real_t)(rw_.rw / (double)n)) * fft_dir_mode_scale(gf.mode, (real_t)rw_.racthe);
-  for (int k = (int)tid; k <= nmen; k += 512) {
+  for (int k = (int)t; k <= nmen; k += 256) {
     const int kb = (k == 0) ? 0 : sz - k;
-    const real2 za = zbuf[k], zb = zbuf[kb];
+    const real2 za = k < q ? park[k] : zbuf[k - q], zb = kb < q ? park[kb] : zbuf[kb - q];
     const real2 s1 = cadd(za, cconj(zb)), d1 = csub(za, cconj(zb));
     const real2 tt = cmuli(cmul(rtw[k], d1));
     *(real2 *)(FB + (unsigned long long)(unsigned)FROW(k) * (unsigned)ldf + 2 * f0) = mk2((s1.x - tt.x) * sc, (s1.y - tt.y) * sc);
@@ -2876,15 +2896,14 @@ EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_dir_r16s(EmiGeomDev g, FftTabDev 
 }
 
 template <int R1>
-EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_inv_r16s(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
-                                                      int ldf, int nproma) {
+EMI_KERNEL_LB2(256, EMI_R16P_WAVES) void k_fft_inv_r16p(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB, int ldf, int nproma) {
   constexpr int H = R1 / 2, S = 256 * R1, PLB = R1 * R16_ROWP * 8;
   constexpr unsigned SZ2 = sizeof(real2);
-  static_assert(r16_threads(R1) == 256, "k_fft_inv_r16s: the convolution of a half on 256 threads (R1 <= 16)");
+  static_assert(r16_threads(R1) == 256, "k_fft_inv_r16p: 256 threads (R1 <= 16)");
   EMI_LDS_DECL;
   char *lds = EMI_LDS_PTR;
-  real2 *tw2s = (real2 *)(lds + 2 * PLB), *zbuf = (real2 *)lds;
-  const unsigned tid = (unsigned)EMI_TID, h = tid >> 8, t = tid & 255u;
+  real2 *zbuf = (real2 *)lds, *park = (real2 *)(lds + PLB), *tw2s = park + 128 * R1;
+  const unsigned t = (unsigned)EMI_TID;
   const int bid = (int)xcd_swizzle(EMI_BID, Lc.nblocks, 8);
   const int li = bid / Lc.nchunk;
   const FftRowDev rw_ = Lc.rows[li];
@@ -2900,61 +2919,78 @@ EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_inv_r16s(EmiGeomDev g, FftTabDev 
   const EmiBuf b_tw = emi_buf((const real2 *)T.ptw + rw_.ptw_off0, 7u * 256u * SZ2);
   const EmiBuf b_bh = emi_buf((const real2 *)T.bhat + rw_.bhat_off, (unsigned)S * SZ2);
   const EmiBuf b_rtw = emi_buf(rtw, (unsigned)(sz + 1) * SZ2);
-  if (tid < 240u) tw2s[tid] = ((const real2 *)T.tw256)[tid];
+  if (t < 240u) tw2s[t] = ((const real2 *)T.tw256)[t];
   const GridFld gf = flds[f0];
-  // stage 1 (FOURIER_IN + FSC): Z_k = (X_k + conj X_{sz-k}) + i w^k (X_k - conj X_{sz-k}) for the pairs (k, sz - k), k <= sz / 2 = q, all 512
-  // threads, to the spectrum image across both planes (k = 0 writes the unused slot sz).  As k_fft_inv_r16: branch-free, the Fourier-row
-  // loads of a thread first, rows past NMEN read as zero through the descriptor; the chirp comes behind the decimation step.
+  // stage 1 (FOURIER_IN + FSC + decimation): the thread of the pair (k, q - k), k <= q / 2, loads X_k, X_{sz-k}, X_{q-k}, X_{q+k}, forms Z_k, Z_{sz-k},
+  // Z_{q-k}, Z_{q+k} and from them the spectrum of the even points (Z_j + Z_{j+q}) conj c_j -> plane slot j, and of the odd points
+  // (Z_j - Z_{j+q}) conj w^j conj c_j -> park slot j, for j = k and j = q - k
   {
-    constexpr int TRIPS = R1 / 4 + 1;  // pairs k = tid + 512 a <= q <= S / 2 = 128 R1
-    const int npair = q + 1;
+    constexpr int TRIPS = R1 / 4 + 1;  // pairs k = t + 256 a <= q / 2 <= S / 8
+    const int npair = q / 2 + 1;
     const unsigned rowb = (unsigned)ldf * (unsigned)sizeof(real_t);
     const EmiBuf b_fb = emi_buf(FB + (unsigned long long)(unsigned)fb0 * (unsigned)ldf + 2 * gf.src, (unsigned)nmen * rowb + SZ2);
     real_t fa, fb;
     fin_factors(gf.mode, racthe, fa, fb);
     const real_t fs = Lc.adj ? adjw : (real_t)1.0;
-    real2 xa[TRIPS], xb[TRIPS];
+    real2 xa[TRIPS], xb[TRIPS], xc[TRIPS], xd[TRIPS];
 #pragma unroll
     for (int a = 0; a < TRIPS; a++) {
-      const unsigned k = tid + 512u * a, k2 = (unsigned)sz - k;
-      if (!frow) {  // (uniform) one descriptor: k > NMEN -- and the idle lanes k >= npair of the last trip -- read zero or anything in range
+      const unsigned k = t + 256u * a;
+      const bool on = k < (unsigned)npair;
+      const unsigned k2 = (unsigned)sz - k, k3 = on ? (unsigned)q - k : 0u, k4 = (unsigned)q + k;
+      if (!frow) {
         xa[a] = emi_buf_ld<real2>(b_fb, k * rowb, 0);
         xb[a] = emi_buf_ld<real2>(b_fb, k2 * rowb, 0);
-      } else {      // rows through the exchange-order table: clamped look-up, then a select
-        const unsigned ka = k < (unsigned)nmen ? k : (unsigned)nmen, kb = k2 < (unsigned)nmen ? k2 : (unsigned)nmen;
-        const real2 va = fin_raw(FB, frow[ka], ldf, gf.src), vb = fin_raw(FB, frow[kb], ldf, gf.src);
-        xa[a] = k <= (unsigned)nmen ? va : mk2(0, 0);
-        xb[a] = k2 <= (unsigned)nmen ? vb : mk2(0, 0);
+        xc[a] = emi_buf_ld<real2>(b_fb, k3 * rowb, 0);
+        xd[a] = emi_buf_ld<real2>(b_fb, k4 * rowb, 0);
+      } else {
+        const unsigned nm = (unsigned)nmen;
+        const real2 va = fin_raw(FB, frow[k < nm ? k : nm], ldf, gf.src), vb = fin_raw(FB, frow[k2 < nm ? k2 : nm], ldf, gf.src);
+        const real2 vc = fin_raw(FB, frow[k3 < nm ? k3 : nm], ldf, gf.src), vd = fin_raw(FB, frow[k4 < nm ? k4 : nm], ldf, gf.src);
+        xa[a] = k <= nm ? va : mk2(0, 0);
+        xb[a] = k2 <= nm ? vb : mk2(0, 0);
+        xc[a] = k3 <= nm ? vc : mk2(0, 0);
+        xd[a] = k4 <= nm ? vd : mk2(0, 0);
       }
     }
 #pragma unroll
     for (int a = 0; a < TRIPS; a++) {
-      const unsigned k = tid + 512u * a, k2 = (unsigned)sz - k;
+      const unsigned k = t + 256u * a;
       if (k < (unsigned)npair) {
-        real2 zk, zk2;
-        fin_pair_nc(xa[a], xb[a], k, k2, fa, fb, fs, cconj(emi_buf_ld<real2>(b_rtw, k * SZ2, 0)), zk, zk2);
-        zbuf[k] = zk;
-        zbuf[k2] = zk2;
+        const unsigned k2 = (unsigned)sz - k, k3 = (unsigned)q - k, k4 = (unsigned)q + k;
+        real2 z1, z2, z3, z4;
+        fin_pair_nc(xa[a], xb[a], k, k2, fa, fb, fs, cconj(emi_buf_ld<real2>(b_rtw, k * SZ2, 0)), z1, z2);    // Z_k, Z_{sz-k}
+        fin_pair_nc(xc[a], xd[a], k3, k4, fa, fb, fs, cconj(emi_buf_ld<real2>(b_rtw, k3 * SZ2, 0)), z3, z4);  // Z_{q-k}, Z_{q+k}
+        const real2 c1 = emi_buf_ld<real2>(b_ch, k * SZ2, 0), c3 = emi_buf_ld<real2>(b_ch, k3 * SZ2, 0);      // k3 = q (k = 0): zero, slot unused
+        const real2 w1 = emi_buf_ld<real2>(b_rtw, 2u * k * SZ2, 0), w3 = emi_buf_ld<real2>(b_rtw, 2u * k3 * SZ2, 0);
+        zbuf[k] = cmulc(cadd(z1, z4), c1);
+        park[k] = cmulc(cmulc(csub(z1, z4), w1), c1);
+        if (k3 < (unsigned)q) {
+          zbuf[k3] = cmulc(cadd(z3, z2), c3);
+          park[k3] = cmulc(cmulc(csub(z3, z2), w3), c3);
+        }
       }
     }
   }
   EMI_LDS_SYNC();
-  // decimation step + chirp into the register layout of r16_conv: half 0 the spectrum of the even points, (Z_l + Z_{l+q}) conj c_l, half 1 that of
-  // the odd points, (Z_l - Z_{l+q}) conj w^l conj c_l; l = t + 256 a
   real2 v[H];
 #pragma unroll
   for (int a = 0; a < H; a++) {
     const unsigned l = t + 256u * a;
-    real2 x = mk2(0, 0);
-    if (l < (unsigned)q) {
-      const real2 z0 = zbuf[l], z1 = zbuf[(unsigned)q + l];
-      x = h ? cmulc(csub(z0, z1), emi_buf_ld<real2>(b_rtw, 2u * l * SZ2, 0)) : cadd(z0, z1);
-    }
-    v[a] = cmulc(x, emi_buf_ld<real2>(b_ch, l * SZ2, 0));  // l >= q: zero chirp
+    v[a] = (l < (unsigned)q) ? zbuf[l] : mk2(0, 0);
   }
-  EMI_LDS_SYNC();  // the planes are free for the exchanges
-  r16_conv<R1, 1>(v, t, b_tw, b_bh, lds + h * PLB, tw2s);
-  // stage 3 (TRLTOG local copy): z_{2l+h} = conv_l conj(chirp_l) / S; x_{4l+2h} = Re, x_{4l+2h+1} = Im, straight from the registers
+  EMI_LDS_SYNC();  // the plane is free for the exchanges
+  r16_conv<R1, 1>(v, t, b_tw, b_bh, lds, tw2s);
+  // z_{2l} = conv_l conj(chirp_l) / S waits in the slot of the odd spectrum value it replaces (same thread, same slot)
+#pragma unroll
+  for (int a = 0; a < H; a++) {
+    const unsigned l = t + 256u * a;
+    const real2 z = cmulc(v[a], emi_buf_ld<real2>(b_ch, l * SZ2, 0));
+    v[a] = (l < (unsigned)q) ? park[l] : mk2(0, 0);
+    if (l < (unsigned)q) park[l] = z;
+  }
+  r16_conv<R1, 1>(v, t, b_tw, b_bh, lds, tw2s);
+  // stage 3 (TRLTOG local copy): x_{4l} .. x_{4l+3} = Re, Im z_{2l}, Re, Im z_{2l+1}: 32 contiguous bytes per lane
   {
     const GridRow gr = grid_row(gf, rw_.gpoff, nproma);
     const bool flat = (gr.rem0 + (unsigned)n <= gr.np) && ((((uintptr_t)(gr.p0 + gr.rem0)) & (2 * sizeof(real_t) - 1)) == 0);
@@ -2963,19 +2999,28 @@ EMI_KERNEL_LB2(512, EMI_R16S_WAVES) void k_fft_inv_r16s(EmiGeomDev g, FftTabDev 
 #pragma unroll
       for (int a = 0; a < H; a++) {
         const unsigned l = t + 256u * a;
-        if (l < (unsigned)q) emi_buf_st<real2>(b_out, (2u * l + h) * SZ2, 0, cmulc(v[a], emi_buf_ld<real2>(b_ch, l * SZ2, 0)));
+        if (l < (unsigned)q) {
+          emi_buf_st<real2>(b_out, 2u * l * SZ2, 0, park[l]);
+          emi_buf_st<real2>(b_out, (2u * l + 1u) * SZ2, 0, cmulc(v[a], emi_buf_ld<real2>(b_ch, l * SZ2, 0)));
+        }
       }
     } else {
 #pragma unroll
       for (int a = 0; a < H; a++) {
-        const unsigned l = t + 256u * a, o = 4u * l + 2u * h;
+        const unsigned l = t + 256u * a;
         if (l < (unsigned)q) {
-          const real2 z = cmulc(v[a], chirp[l]);
-          if (grid_pair_ok(gr, o)) {
-            *(real2 *)grid_ptr(gr, o) = z;
+          const real2 ze = park[l], zo = cmulc(v[a], chirp[l]);
+          if (grid_pair_ok(gr, 4u * l)) {
+            *(real2 *)grid_ptr(gr, 4u * l) = ze;
           } else {
-            *grid_ptr(gr, o) = z.x;
-            *grid_ptr(gr, o + 1) = z.y;
+            *grid_ptr(gr, 4u * l) = ze.x;
+            *grid_ptr(gr, 4u * l + 1) = ze.y;
+          }
+          if (grid_pair_ok(gr, 4u * l + 2)) {
+            *(real2 *)grid_ptr(gr, 4u * l + 2) = zo;
+          } else {
+            *grid_ptr(gr, 4u * l + 2) = zo.x;
+            *grid_ptr(gr, 4u * l + 3) = zo.y;
           }
         }
       }

@@ -98,7 +98,7 @@ struct FftPlanDev {
   int lds_class;
   int mr;   // 1: direct mixed-radix kernels k_fft_*_mr: fac = A, B, C (B, C may be 1), ptw_off[0 / 1] the twiddles after pass 1 / 2, perm = LDS position of coefficient k
   int r16;  // > 0: register-resident kernels k_fft_*_r16<r16>, S = 256 r16; ptw_off[0]: the 7 x 256 digit twiddles, bhat in [k2][16 k0 + k1] order
-  int split;  // 2: k_fft_*_r16s<r16> -- the row as two convolutions of half-length sz / 2 (chirp and filter tables of that length); else 0
+  int split;  // 2: k_fft_*_r16p<r16> -- the row as two convolutions of half-length sz / 2 (chirp and filter tables of that length); else 0
 };
 struct FftTabDev {
   const void *tw;              // real2 tables of the library precision: e^{-2 pi i k/S}
@@ -149,7 +149,7 @@ struct FftLaunchDev {
 // rows of TCo1279; R1 = 20: 21.2 against 15.8): their first / last butterflies hold 72 / 80 data registers of the 128 a wave
 // may use at four waves per SIMD, and 16 R1 threads make five-wave workgroups of which only three fit a CU.
 #define EMI_R16_LIST(X) X(8) X(10) X(12) X(16)
-// ... and of the split kernels k_fft_*_r16s<R1> (round 6): rows of 512 R1' < NLOEN <= 512 R1 as two convolutions of work length 256 R1
+// ... and of the split kernels k_fft_*_r16p<R1> (round 6): rows of 512 R1' < NLOEN <= 512 R1 as two convolutions of work length 256 R1
 // (R1' = the entry before; 8 is not in the list because rows up to 4096 points fit one convolution of the list above).  fp64 TCo1279: R1 = 10
 // carries the rows of 4100 .. 5120 points, R1 = 12 the eight longest; fp32 TCo2559: 10, 12 and 16 carry 4100 .. 8192.
 #define EMI_R16S_LIST(X) X(10) X(12) X(16)

@@ -129,15 +129,15 @@ def test_register_resident_fft_kernels_adjoints(et, monkeypatch):
     assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
 
 
-R16S_ROWS = [4100, 5116, 5124]  # k_fft_*_r16s<10> (first, last but one row length), <12>; the GPU tier runs the full list and R1 = 16
+R16S_ROWS = [4100, 5116, 5124]  # k_fft_*_r16p<10> (first, last but one row length), <12>; the GPU tier runs the full list and R1 = 16
 
 
 @pytest.mark.parametrize("nproma", [None, 1000])
 def test_split_register_resident_fft_kernels(et, nproma, monkeypatch):
-    """k_fft_dir_r16s / k_fft_inv_r16s (round 6): rows of more than 4096 points as two register-resident convolutions of a quarter of the
-    row length joined by one decimation step; whole rows (32 contiguous bytes per lane) and NPROMA blocks that cut them (element path)."""
+    """k_fft_dir_r16p / k_fft_inv_r16p (round 6): rows of more than 4096 points as two register-resident convolutions of a quarter of the
+    row length (one after the other, the idle half parked in LDS) joined by one decimation step; whole rows (32 contiguous bytes per
+    lane) and NPROMA blocks that cut them (element path)."""
     monkeypatch.setenv("EMI_FFT_MR", "0")  # keep rows with a 23-smooth half-length off the direct mixed-radix kernels
-    monkeypatch.setenv("EMI_FFT_R16S", "1")  # (the fp64 library leaves these rows on the in-place LDS kernels by default)
     e_inv, e_dir = run_case(et, Oracle, XP, 15, R16S_ROWS + R16S_ROWS[::-1], 1, 1, dict(scders=True, uvder=True), nproma)
     assert e_inv < TOL and e_dir < TOL, (e_inv, e_dir)
 
@@ -145,7 +145,6 @@ def test_split_register_resident_fft_kernels(et, nproma, monkeypatch):
 def test_split_register_resident_fft_kernels_adjoints(et, monkeypatch):
     """the `adj` scalings of the split kernels: dot-product identity of INV_TRANSAD / DIR_TRANSAD"""
     monkeypatch.setenv("EMI_FFT_MR", "0")
-    monkeypatch.setenv("EMI_FFT_R16S", "1")
     e_inv, e_dir = adjoint_case(et, XP, 15, R16S_ROWS[:2] + R16S_ROWS[1::-1], 1, 1, nproma=3000)
     assert e_inv < 1e-12 and e_dir < 1e-12, (e_inv, e_dir)
 

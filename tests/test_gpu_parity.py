@@ -145,6 +145,8 @@ def test_specialised_fft_kernels_match_oracle(et, dev, half, precision, monkeypa
     """k_fft_inv_hot / k_fft_dir_hot (the Bluestein work lengths 1280 ... 5120 that carry TCo1279): a
     16-latitude grid whose rows select each of them, against the oracle."""
     monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
+    monkeypatch.setenv("EMI_FFT_R16S", "0")  # ... and the rows of more than 4096 points off the split kernels (round 6): the in-place kernels of the work
+    # lengths 4608 ... 8192 still carry every such row whose half-length is odd (NLOEN = 2 mod 4: not on an octahedral grid, but any caller grid)
     from oracle.oracle import Oracle as O
     nsc = 3 if half[0] > 1000 else 9  # short rows: 13 Fourier fields + derivatives = ragged chunks of 2, 4 and 8 fields
     e_inv, e_dir = run_case(et, O, dev, 15, half + half[::-1], 2, nsc, dict(scders=True, uvder=True), None, precision=precision)
@@ -156,6 +158,7 @@ def test_specialised_and_generic_fft_kernels_agree(et, dev, monkeypatch):
     """The specialised kernels run the same passes in the same order; only the compiler's fma
     contraction may differ: agreement to a few ulp."""
     monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
+    monkeypatch.setenv("EMI_FFT_R16S", "0")  # (rows of more than 4096 points: the in-place kernels, not the split ones)
     to, back = dev
     nloen = np.array(HOT_A + HOT_A[::-1], dtype=np.int32)
     rng = np.random.default_rng(5)
@@ -282,17 +285,18 @@ def test_register_resident_fft_kernels_adjoints(et, dev, precision, monkeypatch)
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
-# first / last row length of every class of the split kernels: k_fft_*_r16s<10> 4100 .. 5120, <12> 5124 .. 6144, <16> 6148 .. 8192
-R16S_ROWS = [4100, 4612, 5116, 5120, 5124, 5136, 6144, 6148, 7000, 8188, 8192]
+# first / last row length of every class of the split kernels: k_fft_*_r16p<10> 4100 .. 5120, <12> 5124 .. 6144, <16> 6148 .. 8192; 4102 and 6146 have an
+# odd half-length (no split: the in-place kernels beside the split ones in one call)
+R16S_ROWS = [4100, 4102, 4612, 5116, 5120, 5124, 5136, 6144, 6146, 6148, 7000, 8188, 8192]
 
 
 @pytest.mark.parametrize("precision,nproma", [(8, None), (4, None), (8, 1000), (4, 4094)])
 def test_split_register_resident_fft_kernels_match_oracle(et, dev, precision, nproma, monkeypatch):
-    """k_fft_dir_r16s / k_fft_inv_r16s (round 6: a row of more than 4096 points as TWO register-resident chirp-z convolutions of half its
-    half-length joined by one decimation step -- at TCo1279 the rows of 4100 .. 5136 points that ran on k_fft_*_hot<23 | 24>) against the
-    oracle: every class boundary, whole rows and NPROMA-cut rows, winds and derivatives (all FSC modes), both precisions."""
+    """k_fft_dir_r16p / k_fft_inv_r16p (round 6: a row of more than 4096 points as TWO register-resident chirp-z convolutions of half its
+    half-length, one after the other with the idle half parked in LDS, joined by one decimation step -- at TCo1279 the rows of 4100 .. 5136
+    points that ran on k_fft_*_hot<23 | 24>) against the oracle: every class boundary, whole rows and NPROMA-cut rows, winds and
+    derivatives (all FSC modes), both precisions."""
     monkeypatch.setenv("EMI_FFT_MR", "0")  # some of these rows have a 23-smooth half-length: keep them off the direct mixed-radix kernels
-    monkeypatch.setenv("EMI_FFT_R16S", "1")  # (the fp64 library leaves these rows on the in-place LDS kernels by default)
     from oracle.oracle import Oracle as O
     e_inv, e_dir = run_case(et, O, dev, 15, R16S_ROWS + R16S_ROWS[::-1], 2, 3, dict(scders=True, uvder=True, vorgp=True, divgp=True), nproma, precision=precision)
     tol = TOL if precision == 8 else 3e-5
@@ -328,7 +332,6 @@ def test_split_register_resident_fft_kernels_adjoints(et, dev, precision, monkey
     """INV_TRANSAD / DIR_TRANSAD on rows that take the split kernels (their `adj` scalings): the reference's dot-product identity
     (tests/trans/test_invtrans_adjoint.F90: 2000 epsilon)."""
     monkeypatch.setenv("EMI_FFT_MR", "0")
-    monkeypatch.setenv("EMI_FFT_R16S", "1")
     e_inv, e_dir = adjoint_case(et, dev, 15, R16S_ROWS + R16S_ROWS[::-1], 1, 2, nproma=3000, precision=precision)
     tol = 1e-12 if precision == 8 else 2e-4
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
