@@ -303,6 +303,19 @@ def test_split_register_resident_fft_kernels_match_oracle(et, dev, precision, np
     assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
 
 
+@pytest.mark.parametrize("precision", [8, 4])
+def test_long_row_fft_kernels_through_the_exchange_order_tables(et, dev, precision, monkeypatch):
+    """The register-resident, split, specialised in-place and direct mixed-radix kernels with the Fourier rows addressed through the
+    exchange-order table (g.fftrow: what several tasks use; EMI_TEST_PATHS bit 0 switches it on for one task): the clamped look-ups and
+    selects of FOURIER_IN, the table rows of FOURIER_OUT.  Rows of every kernel family in one grid."""
+    monkeypatch.setenv("EMI_TEST_PATHS", "1")
+    from oracle.oracle import Oracle as O
+    rows = [1540, 2052, 3076, 4092, 4100, 4102, 5120, 5124, 6146, 2048, 3840, 4800]  # r16<8..16>, r16p<10 | 12>, hot<23>, hot<9>, mr (2^a 3 5 half-lengths)
+    e_inv, e_dir = run_case(et, O, dev, 15, rows + rows[::-1], 1, 2, dict(scders=True, uvder=True), None, precision=precision)
+    tol = TOL if precision == 8 else 3e-5
+    assert e_inv < tol and e_dir < tol, (e_inv, e_dir)
+
+
 def test_split_and_lds_fft_kernels_agree(et, dev, monkeypatch):
     """EMI_FFT_R16S=0 sends the same rows through the in-place LDS kernels (one convolution of twice the work length): the same
     transform to rounding, and really another kernel."""
