@@ -2557,8 +2557,18 @@ EMI_DEVFN void r16_conv(real2 *vio, const unsigned t, const EmiBuf &b_tw, const 
 #define R16_STAMP_END(n_) ((void)0)
 #endif
 
+// Waves per SIMD the register-resident kernels are compiled for.  fp32: four (106 - 116 registers).  fp64 (round 6, same-box A/B, TCo1279, ms per
+// direction at four -> three waves): the direct kernels R1 = 8 | 10 | 12 | 16: 3.99 -> 3.71 | 5.11 -> 4.89 | 6.13 -> 5.62 | 15.35 -> 14.89 -- with
+// 144 - 162 instead of 99 - 128 registers the chain keeps more of its table loads in flight and R1 = 12 sheds its scratch; the inverse kernels gain
+// only at R1 = 12 (6.87 -> 6.41; R1 = 8 | 10 | 16: 4.22 -> 4.21 | 5.29 -> 5.40 | 15.89 -> 16.00).  LDS (26 - 39 KB) would allow four or more workgroups
+// per CU either way; three run.
+#ifndef EMI_R16_WAVES_F32
+#define EMI_R16_WAVES_F32 4
+#endif
+#define EMI_R16_WAVES_DIR (sizeof(real_t) == 8 ? 3 : EMI_R16_WAVES_F32)
+#define EMI_R16_WAVES_INV(R1_) (sizeof(real_t) == 8 ? ((R1_) == 12 ? 3 : 4) : EMI_R16_WAVES_F32)
 template <int R1>
-EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
+EMI_KERNEL_LB2(r16_threads(R1), EMI_R16_WAVES_DIR) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, real_t *FB, int ldf,
                                                    int nproma) {
   constexpr int H = R1 / 2, NT = r16_threads(R1), S = 256 * R1;
   constexpr unsigned SZ2 = sizeof(real2);
@@ -2638,7 +2648,7 @@ EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_dir_r16(EmiGeomDev g, FftTabDev T,
 }
 
 template <int R1>
-EMI_KERNEL_LB2(r16_threads(R1), 4) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
+EMI_KERNEL_LB2(r16_threads(R1), EMI_R16_WAVES_INV(R1)) void k_fft_inv_r16(EmiGeomDev g, FftTabDev T, FftLaunchDev Lc, const GridFld *flds, int nfld, const real_t *FB,
                                                    int ldf, int nproma) {
   constexpr int H = R1 / 2, NT = r16_threads(R1), S = 256 * R1;
   constexpr unsigned SZ2 = sizeof(real2);
